@@ -1,0 +1,40 @@
+"""TEST INFRASTRUCTURE ONLY -- the parity cases shared by make_golden.py, tests/ and smoke().
+
+Each case is fully determined by seeds, so inputs/checkpoints are regenerated wherever a test runs;
+only the (sub-sampled) *reference outputs* are stored, in tests/golden/<case>.npz."""
+from __future__ import annotations
+
+import torch
+
+DEMO_K = [[518.86, 0.0, 325.58], [0.0, 519.47, 253.74], [0.0, 0.0, 1.0]]   # assets/demo/intrinsics.npy (rounded)
+
+CASES = {
+    # BASELINE.json configs[0]: V2 ViT-S/14, single 462x616 RGB (scripts/demo.py shape after resize), bs=1
+    "vits_462x616_b1": dict(arch="vits14", H=462, W=616, B=1, camera=False, ckpt_seed=123, img_seed=1),
+    # demo-shaped input with the demo's GT pinhole intrinsics (pad-free, resized 480x640 -> 490x644)
+    "vits_480x640_b2_cam": dict(arch="vits14", H=480, W=640, B=2, camera=True, ckpt_seed=123, img_seed=2),
+    # KITTI-like wide image: aspect padding (60,61) + down-resize (SURVEY.md 8d shape policy table)
+    "vits_375x1242_b1": dict(arch="vits14", H=375, W=1242, B=1, camera=False, ckpt_seed=123, img_seed=3),
+    "vitb_518x518_b1": dict(arch="vitb14", H=518, W=518, B=1, camera=False, ckpt_seed=124, img_seed=4),
+    # BASELINE.json configs[1] at bs=1 (same network shape as the headline bs=8 workload)
+    "vitl_518x518_b1": dict(arch="vitl14", H=518, W=518, B=1, camera=False, ckpt_seed=125, img_seed=5),
+}
+
+
+def case_inputs(case: dict):
+    g = torch.Generator().manual_seed(case["img_seed"])
+    rgb = torch.randint(0, 256, (case["B"], 3, case["H"], case["W"]), dtype=torch.uint8, generator=g)
+    cam = torch.tensor(DEMO_K, dtype=torch.float32) if case["camera"] else None
+    return rgb, cam
+
+
+def digest(out: dict) -> dict:
+    """Compact, deterministic sub-sampling of an infer() result (keeps fixtures small)."""
+    d = {"intrinsics": out["intrinsics"].float().numpy()}
+    for k in ("depth", "confidence", "radius"):
+        d[k] = out[k][:, :, 3::7, 5::7].float().contiguous().numpy()
+    for k in ("points", "rays"):
+        d[k] = out[k][:, :, 3::11, 5::11].float().contiguous().numpy()
+    d["depth_features"] = out["depth_features"][:, 1::8, ::2, ::2].float().contiguous().numpy()
+    d["depth_mean"] = out["depth"].double().mean().reshape(1).numpy()
+    return d
