@@ -1,0 +1,211 @@
+/* unidepth_hip.h -- C-ABI of the MI355X (gfx950) kernel library behind UniDepthV2.infer().
+ *
+ * The reference has no FFI on this path: every op below replaces a torch call made by the reference's
+ * Python modules (file:line relative to the reference tree).  Conventions mirror the reference's own
+ * native-op convention (unidepth/ops/extract_patches/src/extract_patches.cpp:3-6, ops/knn/src/knn.cu:130,330-341)
+ * minus the torch types: raw device pointers + sizes, the caller owns every buffer (incl. workspace),
+ * work is enqueued on the hipStream_t passed in (`void* stream`; NULL = default stream), no hidden
+ * allocation, no host sync.  Return value: 0 = OK, negative = UD_ERR_* (the Python side raises RuntimeError).
+ * All functions are stateless and re-entrant; one process per GPU.
+ *
+ * Activations are fp16 (MFMA operands) or fp32 (residual streams, statistics, outputs); weights are fp16,
+ * [N, K] row-major with K contiguous and K padded to a multiple of 64 (zeros).
+ */
+#ifndef UNIDEPTH_HIP_H
+#define UNIDEPTH_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UD_OK 0
+#define UD_ERR_BAD_ARG (-1)
+#define UD_ERR_LAUNCH (-2)
+#define UD_ERR_UNSUPPORTED (-3)
+
+/* ---- GEMM epilogues ------------------------------------------------------------------------------- */
+#define UD_EPI_F16 0   /* out(fp16)[row, n] = act(acc + bias[n] + add[.., n])                                      */
+#define UD_EPI_F32 1   /* out(fp32)[row, n] (+)= acc + bias[n] + add[.., n]; optional fp16 copy out2 = act2(result)  */
+#define UD_EPI_QKV 2   /* n <  vsplit: out(fp16) row-major;  n >= vsplit: out2(fp16) = V^T [img][head][64][kv_ld]    */
+#define UD_EPI_D2S 3   /* ConvTranspose(k=s) depth-to-space: out(fp32 NHWC) += acc + bias[o]; out2 fp16 = act2(..)   */
+#define UD_EPI_HEAD 4  /* y = sum_n lrelu(acc + bias[n]) * w2[n] + b2;  out(fp32)[m] = exp(clip(y,-8,8) + post_add) */
+
+#define UD_ACT_NONE 0
+#define UD_ACT_GELU 1   /* exact erf GELU (nn.GELU default; reference metadinov2/mlp.py:35-41, layers/mlp.py:27) */
+#define UD_ACT_LRELU 2  /* LeakyReLU(0.01) (reference layers/upsample.py:164) */
+
+#define UD_A_DENSE 0          /* A is [M, lda] row-major                                              */
+#define UD_A_CONV3_ZERO 1     /* A rows are gathered 3x3 taps of an NHWC image, zero padding           */
+#define UD_A_CONV3_REFLECT 2  /* same, reflect padding (reference decoder.py:199-226)                   */
+
+/* C[M,N] = A[M,K] * W[N,K]^T on v_mfma_f32_16x16x32_f16 tiles, fp32 accumulate.
+ * Replaces: nn.Linear / F.linear everywhere on the path (metadinov2/attention.py:53,60; mlp.py:36-40;
+ * layers/attention.py:117-122,139; layers/mlp.py:30-33; decoder.py:44,145), the patch-embed Conv2d
+ * (metadinov2/patch_embed.py:66-88), ConvTranspose2d (decoder.py:166-173), 3x3/1x1 Conv2d
+ * (layers/upsample.py:148-163,208-214; decoder.py:199-226) as implicit GEMMs. */
+typedef struct UdGemm {
+  const void* A;
+  const void* W;
+  const float* bias;      /* [N] fp32 or NULL */
+  void* out;
+  void* out2;
+  const float* add;       /* optional fp32 [*, ldadd] added before activation; row = (m % rows_in) + add_row_off */
+  const void* zeros;      /* >= 256 B of zeros in device memory (padding source for conv A-modes) */
+  const float* w2;        /* UD_EPI_HEAD: [N] second-layer (1x1 conv) weights */
+  int M, N, K;            /* K = padded reduction length (multiple of 64) */
+  int lda, ldw, ldc, ldc2, ldadd;
+  int amode, epi, act, act2, accumulate;
+  int rows_in, rows_out, row_off, add_row_off;   /* output row = (m / rows_in) * rows_out + (m % rows_in) + row_off; rows_in = 0 -> identity */
+  /* conv A-modes: row m -> image m / rows_img, pixel p = m % rows_img (valid if p < Himg*Wimg) */
+  int Himg, Wimg, Cin, cstride, coff, rows_img;
+  long long img_stride;   /* elements between images of A */
+  /* UD_EPI_QKV */
+  int vsplit, tok_per_img, kv_ld, heads_v;
+  /* UD_EPI_D2S: n = (a*k + c)*Co + o ; input row m -> image m / rows_in_img, p = m % rows_in_img -> (y, x) on [Hin, Win] */
+  int d2s_k, d2s_Co, d2s_Hin, d2s_Win, d2s_rows_in_img;
+  long long d2s_out_img_pix;   /* pixels between images in the output */
+  /* UD_EPI_HEAD */
+  float b2, post_add;
+  /* groups: blockIdx.z = g offsets (elements) */
+  int groups;
+  long long gA, gW, gBias, gOut, gOut2, gW2;
+  float b2_g1, post_add_g1;    /* group 1 constants for UD_EPI_HEAD */
+} UdGemm;
+
+int ud_gemm_f16(const UdGemm* desc, void* stream);
+
+/* ---- LayerNorm (statistics only; the affine is folded into the consumer's weights at load time) ----
+ * y(fp16)[orow, :] = (x[irow, :] - mean) * rsqrt(var + eps), biased variance (F.layer_norm).
+ * Replaces nn.LayerNorm at metadinov2/block.py:85-89 (eps 1e-6, dinov2.py:167), dinov2.py:254,336-342 (eps 1e-5),
+ * layers/attention.py:115-116, layers/mlp.py:29, decoder.py:186-188.
+ * Row mapping: for r in [0, rows): img = r / rows_per_img, p = r % rows_per_img;
+ *   irow = img * in_rows_per_img + p + in_row_off;  orow = img * out_rows_per_img + p + out_row_off. */
+typedef struct UdLayerNorm {
+  const float* x; void* y;
+  int rows, D, ldx, ldy;
+  float eps;
+  int rows_per_img, in_rows_per_img, in_row_off, out_rows_per_img, out_row_off;
+} UdLayerNorm;
+int ud_layernorm_f32_f16(const UdLayerNorm* desc, void* stream);
+
+/* ---- fused multi-head attention forward, head_dim 64 (padded), no mask, fp16 in/out, fp32 softmax ----
+ * O = softmax(Q K^T * scale) V per (image, head).  Replaces F.scaled_dot_product_attention at
+ * metadinov2/attention.py:58 and layers/attention.py:136-138 (and xformers memory_efficient_attention :77).
+ * Q [img*q_rows_per_img + i, h*64 + d] (ldq), K likewise (ldk), Vt = V^T [img][h][64][kv_ld], O like Q (ldo).
+ * kv_img_stride_zero != 0: all images share image 0's K/V (single GT camera broadcast, decoder.py:400). */
+typedef struct UdAttention {
+  const void* Q; const void* K; const void* Vt; void* O;
+  int B, H, Nq, Nk;
+  int ldq, ldk, ldo, kv_ld;
+  int q_rows_per_img, k_rows_per_img;
+  float scale;
+  int kv_broadcast;
+} UdAttention;
+int ud_attention_f16(const UdAttention* desc, void* stream);
+
+/* ---- pre-processing + im2col for the 14x14 patch embedding ---------------------------------------------
+ * Replaces unidepthv2.py:288-297 (/255, ImageNet mean/std, zero pad, bilinear align_corners=False resize) and
+ * the unfold implied by Conv2d(k=s=14) (patch_embed.py:71-88).  rgb: uint8 (is_u8) or fp32 [B,3,H,W].
+ * patches(fp16)[img*hw + py*w + px, c*196 + i*14 + j], row stride ldp (>= 588, pad cols untouched). */
+typedef struct UdPreprocess {
+  const void* rgb; void* patches;
+  int B, H, W;            /* source image */
+  int pad_l, pad_t, Hp, Wp;   /* padded size (before resize) */
+  int Hn, Wn;             /* network input size (multiples of 14) */
+  int ldp;
+  int is_u8, normalize;
+  float mean[3], inv_std[3];
+} UdPreprocess;
+int ud_preprocess_patches(const UdPreprocess* desc, void* stream);
+
+/* ---- small helpers ----------------------------------------------------------------------------------- */
+/* dst(fp32)[img*rows_per_img + row_off, :D] = src[:D]  (cls token + pos_embed[0]; dinov2.py:316-317) */
+int ud_fill_rows_f32(float* dst, const float* src, int n_img, int rows_per_img, int row_off, int D, int ld, void* stream);
+
+/* camera head tail (decoder.py:85-99 fill_intrinsics, :361-403 run_camera; unidepthv2.py:92-108 _postprocess_intrinsics):
+ * raw[(b*4 + j) * raw_stride] = j-th raw camera parameter of image b -> intr4 [B,4] = (fx,fy,cx,cy) at network
+ * resolution, K33 [B,9] row-major, Kinv33 [B,9] (closed-form pinhole inverse), Kpost33 [B,9] = K with
+ * fx,fy,cx,cy /= resize_factor and cx -= pad_l, cy -= pad_t (the matrix infer() returns). */
+int ud_camera_intrinsics(const float* raw, int raw_stride, float* intr4, float* K33, float* Kinv33, float* Kpost33,
+                         int B, int Hn, int Wn, float resize_factor, int pad_l, int pad_t, void* stream);
+
+/* rays [nb,3,Hn,Wn] fp32 = normalise(Kinv @ [u+0.5, v+0.5, 1]) (utils/coordinate.py:4-20 pixel centres).
+ * gt_mode 0: predicted camera, norm clamp 1e-5 (decoder.py:389-393);
+ * gt_mode 1: user camera (utils/camera.py:254-266 Pinhole.unproject: divide by z.clip(1e-4); :88-92 norm clamp 1e-4). */
+int ud_rays_from_kinv(const float* Kinv33, float* rays, int nb, int Hn, int Wn, int gt_mode, void* stream);
+
+/* ray embedding (decoder.py:234-253): antialiased bilinear down-sample of rays [nb,3,Hn,Wn] to (h,w)
+ * (utils/geometric.py:227-252), renormalise (clip 1e-4), polar/azimuth, C/2 log-spaced sine bands each
+ * (utils/positional_embedding.py:218-256; `scales` = the C/2 band frequencies, fp32), then LayerNorm statistics
+ * (eps) -> xhat fp16 [img*rows_per_img + token, ldy]. */
+typedef struct UdRayEmbed {
+  const float* rays; const float* scales; void* xhat;
+  int nb, Hn, Wn, h, w, C, ldy, rows_per_img;
+  float eps;
+} UdRayEmbed;
+int ud_ray_embed(const UdRayEmbed* desc, void* stream);
+
+/* x2 bilinear up-sampling, align_corners=False (nn.Upsample in layers/upsample.py:215-217), NHWC fp32 in [B,H,W,C] (row stride ldin).
+ * mode 0: out fp32 [B,2H,2W,C]; mode 1: out = LayerNorm-statistics(fp16) of the up-sampled pixel (eps), row stride ldy. */
+typedef struct UdUpsample2x {
+  const void* in; void* out;
+  int B, H, W, C, ldin, ldy, mode;
+  float eps;
+  int in_img_rows;   /* rows (pixels) between consecutive images of `in`; 0 -> H*W */
+} UdUpsample2x;
+int ud_upsample2x_nhwc(const UdUpsample2x* desc, void* stream);
+
+/* bilinear resize, align_corners=True (decoder.py:299-301,309-311), NHWC fp16 -> NHWC fp16, G groups */
+typedef struct UdResizeAC {
+  const void* in; void* out;
+  int G, B, Hin, Win, Hout, Wout, C;
+} UdResizeAC;
+int ud_resize_ac_nhwc_f16(const UdResizeAC* desc, void* stream);
+
+/* output assembly (decoder.py:456-462, unidepthv2.py:375-377, :310-339) for the no-resample case and generic
+ * fp32 NCHW bilinear(align_corners=False) resize + crop used by _postprocess (unidepthv2.py:80-89). */
+typedef struct UdFinalize {
+  const float* radius_net;  /* [B,Hn,Wn] */
+  const float* conf_net;    /* [B,Hn,Wn] */
+  const float* rays_net;    /* [nb_rays,3,Hn,Wn] */
+  float* confidence; float* radius; float* depth; float* points; float* rays;   /* outputs at [.,.,Ho,Wo] */
+  int B, nb_rays, Hn, Wn;
+  int Hp, Wp;               /* padded (pre-crop) size the network maps are resized to */
+  int pad_l, pad_t, Ho, Wo; /* crop */
+} UdFinalize;
+int ud_finalize_outputs(const UdFinalize* desc, void* stream);
+
+/* NHWC fp32 (row stride ld, rows_per_img rows per image) -> NCHW fp32 [B,C,h*w]  (depth_features, decoder.py:265-267) */
+int ud_nhwc_to_nchw_f32(const float* in, float* out, int B, int hw, int C, int ld, int rows_per_img, void* stream);
+
+/* ---- launch programs: a recorded list of the ops above replayed with one call (host-side runtime) ---- */
+typedef struct UdProgram UdProgram;
+UdProgram* ud_program_create(void);
+void ud_program_destroy(UdProgram*);
+int ud_program_size(const UdProgram*);
+int ud_program_add_gemm(UdProgram*, const UdGemm*);
+int ud_program_add_layernorm(UdProgram*, const UdLayerNorm*);
+int ud_program_add_attention(UdProgram*, const UdAttention*);
+int ud_program_add_preprocess(UdProgram*, const UdPreprocess*);
+int ud_program_add_fill_rows(UdProgram*, float* dst, const float* src, int n_img, int rows_per_img, int row_off, int D, int ld);
+int ud_program_add_camera_intrinsics(UdProgram*, const float* raw, int raw_stride, float* intr4, float* K33, float* Kinv33, float* Kpost33,
+                                     int B, int Hn, int Wn, float resize_factor, int pad_l, int pad_t);
+int ud_program_add_rays(UdProgram*, const float* Kinv33, float* rays, int nb, int Hn, int Wn, int gt_mode);
+int ud_program_add_ray_embed(UdProgram*, const UdRayEmbed*);
+int ud_program_add_upsample2x(UdProgram*, const UdUpsample2x*);
+int ud_program_add_resize_ac(UdProgram*, const UdResizeAC*);
+int ud_program_add_finalize(UdProgram*, const UdFinalize*);
+int ud_program_add_nhwc_to_nchw(UdProgram*, const float* in, float* out, int B, int hw, int C, int ld, int rows_per_img);
+/* run ops [first, last) on `stream`; returns 0 or the first failing op's error code */
+int ud_program_run(const UdProgram*, int first, int last, void* stream);
+
+/* library info; ud_struct_size(i): sizeof the i-th descriptor struct in declaration order (UdGemm = 0 ...) */
+int ud_version(void);
+int ud_struct_size(int which);
+const char* ud_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

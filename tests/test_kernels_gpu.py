@@ -1,0 +1,355 @@
+"""Kernel-level numerics: every C-ABI op of libunidepth_hip.so against a plain PyTorch fp32 statement of the same
+op on the same (fp16-rounded) operands.  Tolerances: fp32-accumulated fp16 products -> rel-L2 <= 2e-3 against the
+fp32 result of fp16-rounded inputs is loose; we require <= 1e-3 for outputs stored in fp16 (their own rounding is
+2^-11 ~ 4.9e-4 per element) and <= 2e-5 for fp32 outputs."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from unidepth_amd import ops as _ops
+    return _ops
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+@pytest.mark.parametrize("M,N,K,act", [(300, 128, 64, 0), (1000, 384, 320, 1), (129, 64, 128, 2), (77, 32, 192, 0), (5000, 1024, 1024, 1), (32, 512, 512, 0)])
+def test_gemm_f16_dense(ops, M, N, K, act):
+    A = rnd(M, K, seed=1).half()
+    W = rnd(N, K, scale=K ** -0.5, seed=2).half()
+    bias = rnd(N, seed=3)
+    out = torch.zeros(M, N, dtype=torch.half, device="cuda")
+    ops.gemm(A=A, W=W, bias=bias, out=out, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, epi=ops.UD_EPI_F16, act=act)
+    ref = A.float() @ W.float().t() + bias
+    ref = [lambda x: x, F.gelu, lambda x: F.leaky_relu(x, 0.01)][act](ref)
+    torch.cuda.synchronize()
+    assert rel(out.float(), ref) < 1e-3
+
+
+def test_gemm_f32_accumulate_remap_add(ops):
+    # patch-embed style: rows_in=hw tokens/img -> rows_out=Npad with offset 1, + pos-embed add, then accumulate pass
+    B, hw, Npad, K, N = 3, 50, 56, 128, 256
+    M = B * hw
+    A = rnd(M, K, seed=1).half()
+    W = rnd(N, K, scale=K ** -0.5, seed=2).half()
+    bias = rnd(N, seed=3)
+    pos = rnd(hw + 1, N, seed=4)
+    x = torch.zeros(B * Npad, N, device="cuda")
+    x2 = torch.zeros(B * Npad, N, dtype=torch.half, device="cuda")
+    kw = dict(A=A, W=W, bias=bias, out=x, out2=x2, add=pos, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, ldc2=N, ldadd=N,
+              epi=ops.UD_EPI_F32, rows_in=hw, rows_out=Npad, row_off=1, add_row_off=1, act2=ops.UD_ACT_LRELU)
+    ops.gemm(**kw)
+    ref = (A.float() @ W.float().t() + bias).view(B, hw, N) + pos[1:]
+    torch.cuda.synchronize()
+    got = x.view(B, Npad, N)
+    assert rel(got[:, 1:hw + 1], ref) < 2e-5
+    assert got[:, 0].abs().max() == 0 and got[:, hw + 1:].abs().max() == 0
+    assert rel(x2.view(B, Npad, N)[:, 1:hw + 1].float(), F.leaky_relu(ref, 0.01)) < 1e-3
+    kw["accumulate"] = 1
+    ops.gemm(**kw)
+    torch.cuda.synchronize()
+    assert rel(x.view(B, Npad, N)[:, 1:hw + 1], 2 * ref) < 2e-5
+
+
+def test_gemm_qkv_epilogue(ops):
+    B, Npad, D, H = 2, 72, 128, 2          # D = H*64, tokens per image 72 (multiple of 8)
+    M, N, K = B * Npad, 3 * D, D
+    kv_ld = 128
+    A = rnd(M, K, seed=1).half()
+    W = rnd(N, K, scale=K ** -0.5, seed=2).half()
+    bias = rnd(N, seed=3)
+    qk = torch.zeros(M, 2 * D, dtype=torch.half, device="cuda")
+    vt = torch.zeros(B, H, 64, kv_ld, dtype=torch.half, device="cuda")
+    ops.gemm(A=A, W=W, bias=bias, out=qk, out2=vt, M=M, N=N, K=K, lda=K, ldw=K, ldc=2 * D, epi=ops.UD_EPI_QKV,
+             vsplit=2 * D, tok_per_img=Npad, kv_ld=kv_ld, heads_v=H)
+    ref = A.float() @ W.float().t() + bias
+    torch.cuda.synchronize()
+    assert rel(qk.float(), ref[:, :2 * D]) < 1e-3
+    vref = ref[:, 2 * D:].view(B, Npad, H, 64).permute(0, 2, 3, 1)          # [B,H,64,Npad]
+    assert rel(vt[..., :Npad].float(), vref) < 1e-3
+    assert vt[..., Npad:].abs().max() == 0
+
+
+@pytest.mark.parametrize("mode,Cin,Cout,H,W,rows_pad", [(1, 64, 128, 9, 11, 5), (2, 64, 64, 10, 7, 0), (1, 48, 32, 6, 6, 0), (2, 32, 32, 12, 9, 0)])
+def test_gemm_conv3x3(ops, mode, Cin, Cout, H, W, rows_pad):
+    B = 2
+    rows_img = H * W + rows_pad
+    cstride, coff = Cin + 16, 8                                # exercise pixel stride / channel offset
+    x = rnd(B, rows_img, cstride, seed=1).half()
+    wt = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=2)
+    bias = rnd(Cout, seed=3)
+    Kp = ((9 * Cin + 63) // 64) * 64
+    Wg = torch.zeros(Cout, Kp, device="cuda")
+    Wg[:, :9 * Cin] = wt.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin)      # k = (tap, cin)
+    Wg = Wg.half()
+    zeros = torch.zeros(256, dtype=torch.half, device="cuda")
+    M = B * rows_img
+    out = torch.zeros(M, Cout, dtype=torch.half, device="cuda")
+    ops.gemm(A=x, W=Wg, bias=bias, out=out, zeros=zeros, M=M, N=Cout, K=Kp, lda=0, ldw=Kp, ldc=Cout, amode=mode,
+             epi=ops.UD_EPI_F16, act=ops.UD_ACT_LRELU, Himg=H, Wimg=W, Cin=Cin, cstride=cstride, coff=coff,
+             rows_img=rows_img, img_stride=rows_img * cstride)
+    xin = x[:, :H * W, coff:coff + Cin].float().view(B, H, W, Cin).permute(0, 3, 1, 2)
+    if mode == 2:
+        xin = F.pad(xin, (1, 1, 1, 1), mode="reflect")
+        ref = F.conv2d(xin, Wg[:, :9 * Cin].float().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), bias)
+    else:
+        ref = F.conv2d(xin, Wg[:, :9 * Cin].float().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), bias, padding=1)
+    ref = F.leaky_relu(ref, 0.01).permute(0, 2, 3, 1).reshape(B, H * W, Cout)
+    torch.cuda.synchronize()
+    assert rel(out.view(B, rows_img, Cout)[:, :H * W].float(), ref) < 1e-3
+
+
+@pytest.mark.parametrize("k", [1, 2, 4])
+def test_gemm_d2s_convtranspose(ops, k):
+    B, Hin, Win, Cin, Co = 2, 5, 7, 64, 64
+    rows_in = Hin * Win + 5
+    x = rnd(B, rows_in, Cin, seed=1).half()
+    wt = rnd(Cin, Co, k, k, scale=Cin ** -0.5, seed=2)                   # ConvTranspose2d layout [Cin, Cout, k, k]
+    bias = rnd(Co, seed=3)
+    Wg = wt.permute(2, 3, 1, 0).reshape(k * k * Co, Cin).contiguous().half()   # n = (a*k + c)*Co + o
+    Hout, Wout = Hin * k, Win * k
+    lat = rnd(B, Hout * Wout, Co, seed=4)
+    lat0 = lat.clone()
+    lat16 = torch.zeros(B, Hout * Wout, Co, dtype=torch.half, device="cuda")
+    ops.gemm(A=x, W=Wg, bias=bias, out=lat, out2=lat16, M=B * rows_in, N=k * k * Co, K=Cin, lda=Cin, ldw=Cin, ldc=Co,
+             ldc2=Co, epi=ops.UD_EPI_D2S, act2=ops.UD_ACT_LRELU, d2s_k=k, d2s_Co=Co, d2s_Hin=Hin, d2s_Win=Win,
+             d2s_rows_in_img=rows_in, d2s_out_img_pix=Hout * Wout)
+    xin = x[:, :Hin * Win].float().view(B, Hin, Win, Cin).permute(0, 3, 1, 2)
+    ref = F.conv_transpose2d(xin, Wg.float().view(k, k, Co, Cin).permute(3, 2, 0, 1), bias, stride=k)
+    ref = lat0.view(B, Hout, Wout, Co) + ref.permute(0, 2, 3, 1)
+    torch.cuda.synchronize()
+    assert rel(lat.view(B, Hout, Wout, Co), ref) < 2e-4
+    assert rel(lat16.view(B, Hout, Wout, Co).float(), F.leaky_relu(ref, 0.01)) < 1e-3
+
+
+def test_gemm_head_epilogue(ops):
+    G, B, H, W, Cin = 2, 1, 20, 13, 64
+    x = rnd(G, B, H * W, Cin, seed=1).half()
+    wt = rnd(G, 32, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=2)
+    b1 = rnd(G, 32, seed=3)
+    w2 = rnd(G, 32, scale=0.3, seed=4)
+    b2 = [0.1, -0.2]
+    Kp = 9 * Cin
+    Wg = wt.permute(0, 1, 3, 4, 2).reshape(G, 32, Kp).half().contiguous()
+    zeros = torch.zeros(256, dtype=torch.half, device="cuda")
+    M = B * H * W
+    out = torch.zeros(G, M, device="cuda")
+    ops.gemm(A=x, W=Wg, bias=b1, out=out, zeros=zeros, w2=w2, M=M, N=32, K=Kp, ldw=Kp, amode=ops.UD_A_CONV3_REFLECT,
+             epi=ops.UD_EPI_HEAD, Himg=H, Wimg=W, Cin=Cin, cstride=Cin, coff=0, rows_img=H * W, img_stride=H * W * Cin,
+             b2=b2[0], post_add=2.0, b2_g1=b2[1], post_add_g1=0.0, groups=2, gA=B * H * W * Cin, gW=32 * Kp, gBias=32,
+             gOut=M, gW2=32)
+    torch.cuda.synchronize()
+    for g in range(G):
+        xin = F.pad(x[g].float().view(B, H, W, Cin).permute(0, 3, 1, 2), (1, 1, 1, 1), mode="reflect")
+        y = F.conv2d(xin, Wg[g].float().view(32, 3, 3, Cin).permute(0, 3, 1, 2), b1[g])
+        y = F.conv2d(F.leaky_relu(y, 0.01), w2[g].view(1, 32, 1, 1), torch.tensor([b2[g]], device="cuda"))
+        ref = torch.exp(y.clip(-8, 8) + (2.0 if g == 0 else 0.0)).reshape(-1)
+        assert rel(out[g], ref) < 1e-3, g
+
+
+@pytest.mark.parametrize("D,eps", [(1024, 1e-6), (384, 1e-5), (768, 1e-6), (512, 1e-5), (96, 1e-5)])
+def test_layernorm(ops, D, eps):
+    B, rows_in, rows_out, n = 3, 21, 24, 19
+    x = rnd(B * rows_in, D, seed=1) * 3 + 0.7
+    y = torch.zeros(B * rows_out, D, dtype=torch.half, device="cuda")
+    ops.layernorm(x=x, y=y, rows=B * n, D=D, ldx=D, ldy=D, eps=eps, rows_per_img=n, in_rows_per_img=rows_in, in_row_off=1,
+                  out_rows_per_img=rows_out, out_row_off=0)
+    ref = F.layer_norm(x.view(B, rows_in, D)[:, 1:1 + n], (D,), eps=eps)
+    torch.cuda.synchronize()
+    assert rel(y.view(B, rows_out, D)[:, :n].float(), ref) < 6e-4
+    assert y.view(B, rows_out, D)[:, n:].abs().max() == 0
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,bc", [(2, 3, 1370, 1370, 0), (1, 2, 200, 77, 0), (3, 8, 4, 4, 0), (2, 2, 130, 1369, 1)])
+def test_attention(ops, B, H, Nq, Nk, bc):
+    D = H * 64
+    qr, kr = ((Nq + 7) // 8) * 8, ((Nk + 7) // 8) * 8
+    kv_ld = ((Nk + 63) // 64) * 64
+    Bk = 1 if bc else B
+    q = rnd(B, qr, D, seed=1).half()
+    kk = rnd(Bk, kr, D, seed=2).half()
+    v = rnd(Bk, kr, D, seed=3).half()
+    vt = torch.zeros(Bk, H, 64, kv_ld, dtype=torch.half, device="cuda")
+    vt[..., :Nk] = v[:, :Nk].view(Bk, Nk, H, 64).permute(0, 2, 3, 1)
+    o = torch.zeros(B, qr, D, dtype=torch.half, device="cuda")
+    scale = 0.125
+    ops.attention(Q=q, K=kk, Vt=vt, O=o, B=B, H=H, Nq=Nq, Nk=Nk, ldq=D, ldk=D, ldo=D, kv_ld=kv_ld, q_rows_per_img=qr,
+                  k_rows_per_img=kr, scale=scale, kv_broadcast=bc)
+    qf = q[:, :Nq].float().view(B, Nq, H, 64).permute(0, 2, 1, 3)
+    kf = kk[:, :Nk].float().view(Bk, Nk, H, 64).permute(0, 2, 1, 3).expand(B, -1, -1, -1)
+    vf = v[:, :Nk].float().view(Bk, Nk, H, 64).permute(0, 2, 1, 3).expand(B, -1, -1, -1)
+    ref = torch.softmax(qf @ kf.transpose(-1, -2) * scale, dim=-1) @ vf
+    ref = ref.permute(0, 2, 1, 3).reshape(B, Nq, D)
+    torch.cuda.synchronize()
+    assert rel(o[:, :Nq].float(), ref) < 2e-3
+    assert qr == Nq or o[:, Nq:].abs().max() == 0
+
+
+def test_attention_spiked_rows(ops):
+    """online-softmax rescale path: one key row dominates late in the sequence (max jumps at a late tile)."""
+    B, H, N = 1, 1, 300
+    q = rnd(B, 304, 64, seed=1).half()
+    kk = rnd(B, 304, 64, seed=2).half()
+    kk[0, 250] = q[0, 3] * 4.0
+    v = rnd(B, 304, 64, seed=3).half()
+    vt = torch.zeros(B, H, 64, 320, dtype=torch.half, device="cuda")
+    vt[..., :N] = v[:, :N].view(B, N, H, 64).permute(0, 2, 3, 1)
+    o = torch.zeros(B, 304, 64, dtype=torch.half, device="cuda")
+    ops.attention(Q=q, K=kk, Vt=vt, O=o, B=B, H=H, Nq=N, Nk=N, ldq=64, ldk=64, ldo=64, kv_ld=320, q_rows_per_img=304,
+                  k_rows_per_img=304, scale=1.0, kv_broadcast=0)
+    ref = torch.softmax(q[:, :N].float() @ kk[:, :N].float().transpose(-1, -2), dim=-1) @ v[:, :N].float()
+    torch.cuda.synchronize()
+    assert rel(o[:, :N].float(), ref) < 2e-3
+
+
+@pytest.mark.parametrize("H,W,pads,Hn,Wn,u8", [(28, 42, (0, 0, 0, 0), 28, 42, True), (30, 50, (0, 0, 3, 4), 28, 42, True), (20, 33, (2, 3, 0, 0), 42, 56, False)])
+def test_preprocess_patches(ops, H, W, pads, Hn, Wn, u8):
+    import ctypes as C
+    B = 2
+    pl, pr, pt, pb = pads
+    Hp, Wp = H + pt + pb, W + pl + pr
+    g = torch.Generator().manual_seed(0)
+    rgb = torch.randint(0, 256, (B, 3, H, W), dtype=torch.uint8, generator=g).cuda()
+    src = rgb if u8 else rgb.float()
+    hw = (Hn // 14) * (Wn // 14)
+    ldp = 640
+    patches = torch.zeros(B * hw, ldp, dtype=torch.half, device="cuda")
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    d = ops.mk(ops.UdPreprocess, rgb=src, patches=patches, B=B, H=H, W=W, pad_l=pl, pad_t=pt, Hp=Hp, Wp=Wp, Hn=Hn, Wn=Wn,
+               ldp=ldp, is_u8=int(u8), normalize=1, mean=mean, inv_std=tuple(1.0 / s for s in std))
+    ops.check(ops.lib.ud_preprocess_patches(C.byref(d), ops.cur_stream()))
+    x = rgb.float() / 255.0
+    x = (x - torch.tensor(mean, device="cuda").view(1, 3, 1, 1)) / torch.tensor(std, device="cuda").view(1, 3, 1, 1)
+    x = F.pad(x, (pl, pr, pt, pb))
+    x = F.interpolate(x, size=(Hn, Wn), mode="bilinear", align_corners=False)
+    ref = F.unfold(x, kernel_size=14, stride=14).transpose(1, 2).reshape(B * hw, 588)
+    torch.cuda.synchronize()
+    assert rel(patches[:, :588].float(), ref) < 6e-4
+    assert patches[:, 588:].abs().max() == 0
+
+
+def test_camera_rays_embed(ops):
+    import ctypes as C
+    from oracle.restate import OracleV2
+    B, Hn, Wn, h, w, Cc = 2, 42, 56, 3, 4, 256
+    raw = rnd(B, 4, scale=0.3, seed=1)
+    intr = torch.zeros(B, 4, device="cuda"); K = torch.zeros(B, 9, device="cuda"); Ki = torch.zeros(B, 9, device="cuda")
+    Kp = torch.zeros(B, 9, device="cuda")
+    ops.check(ops.lib.ud_camera_intrinsics(raw.data_ptr(), 1, intr.data_ptr(), K.data_ptr(), Ki.data_ptr(), Kp.data_ptr(), B, Hn, Wn,
+                                           0.5, 3, 2, ops.cur_stream()))
+    diag = (Hn ** 2 + Wn ** 2) ** 0.5
+    ref_intr = torch.stack([raw[:, 0].exp() * 0.7 * diag, raw[:, 1].exp() * 0.7 * diag, raw[:, 2].sigmoid() * Wn, raw[:, 3].sigmoid() * Hn], 1)
+    torch.cuda.synchronize()
+    assert rel(intr, ref_intr) < 1e-6
+    kp_ref = torch.stack([ref_intr[:, 0] / 0.5, ref_intr[:, 1] / 0.5, ref_intr[:, 2] / 0.5 - 3, ref_intr[:, 3] / 0.5 - 2], 1)
+    assert rel(Kp[:, [0, 4, 2, 5]], kp_ref) < 1e-6
+    rays = torch.zeros(B, 3, Hn, Wn, device="cuda")
+    ops.check(ops.lib.ud_rays_from_kinv(Ki.data_ptr(), rays.data_ptr(), B, Hn, Wn, 0, ops.cur_stream()))
+    Kref, rref = OracleV2._rays_from_intrinsics(ref_intr.cpu(), Hn, Wn)
+    torch.cuda.synchronize()
+    assert rel(rays.cpu(), rref) < 1e-6
+    assert rel(K.view(B, 3, 3).cpu(), Kref) < 1e-6
+    # embedding + LN statistics
+    nb = Cc // 2
+    scales = (2.0 ** torch.linspace(0.0, math.log2(max(h, w) // 2), steps=nb)).cuda()
+    rows = 16
+    xhat = torch.zeros(B * rows, Cc, dtype=torch.half, device="cuda")
+    d = ops.mk(ops.UdRayEmbed, rays=rays, scales=scales, xhat=xhat, nb=B, Hn=Hn, Wn=Wn, h=h, w=w, C=Cc, ldy=Cc, rows_per_img=rows, eps=1e-5)
+    ops.check(ops.lib.ud_ray_embed(C.byref(d), ops.cur_stream()))
+
+    class _O:  # borrow the oracle's method with a minimal self
+        a = {"C": Cc}
+    emb = OracleV2._embed_rays(_O, rref.reshape(B, 3, -1).permute(0, 2, 1), Hn, Wn, h, w)
+    ref = F.layer_norm(emb, (Cc,), eps=1e-5)
+    torch.cuda.synchronize()
+    assert rel(xhat.view(B, rows, Cc)[:, :h * w].float().cpu(), ref) < 2e-3
+
+
+@pytest.mark.parametrize("C_,mode", [(64, 0), (128, 1), (96, 1), (512, 0)])
+def test_upsample2x(ops, C_, mode):
+    import ctypes as C
+    B, H, W = 2, 5, 7
+    x = rnd(B, H, W, C_, seed=1)
+    ref = F.interpolate(x.permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    if mode == 0:
+        out = torch.zeros(B, 2 * H, 2 * W, C_, device="cuda")
+    else:
+        out = torch.zeros(B, 2 * H, 2 * W, C_, dtype=torch.half, device="cuda")
+        ref = F.layer_norm(ref, (C_,), eps=1e-5)
+    d = ops.mk(ops.UdUpsample2x, in_=x, out=out, B=B, H=H, W=W, C=C_, ldin=C_, ldy=C_, mode=mode, eps=1e-5)
+    ops.check(ops.lib.ud_upsample2x_nhwc(C.byref(d), ops.cur_stream()))
+    torch.cuda.synchronize()
+    assert rel(out.float(), ref) < (2e-6 if mode == 0 else 6e-4)
+
+
+def test_resize_ac_and_finalize_and_transpose(ops):
+    import ctypes as C
+    G, B, Hin, Win, Hout, Wout, C_ = 2, 2, 6, 9, 14, 28, 64
+    x = rnd(G, B, Hin, Win, C_, seed=1).half()
+    out = torch.zeros(G, B, Hout, Wout, C_, dtype=torch.half, device="cuda")
+    d = ops.mk(ops.UdResizeAC, in_=x, out=out, G=G, B=B, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, C=C_)
+    ops.check(ops.lib.ud_resize_ac_nhwc_f16(C.byref(d), ops.cur_stream()))
+    ref = F.interpolate(x.float().view(G * B, Hin, Win, C_).permute(0, 3, 1, 2), size=(Hout, Wout), mode="bilinear", align_corners=True)
+    torch.cuda.synchronize()
+    assert rel(out.float().view(G * B, Hout, Wout, C_).permute(0, 3, 1, 2), ref) < 6e-4
+
+    # finalize: network maps [Hn,Wn] -> resize to padded (Hp,Wp) -> crop
+    for (Hn, Wn, Hp, Wp, pl, pt, Ho, Wo, nbr) in [(14, 28, 14, 28, 0, 0, 14, 28, 2), (14, 28, 20, 37, 3, 2, 15, 30, 2), (14, 28, 20, 37, 0, 1, 18, 37, 1)]:
+        radius = rnd(B, 1, Hn, Wn, seed=2).abs() + 0.5
+        conf = rnd(B, 1, Hn, Wn, seed=3).abs()
+        rays = F.normalize(rnd(nbr, 3, Hn, Wn, seed=4), dim=1)
+        o = {k: torch.zeros(B if k != "rays" else nbr, c, Ho, Wo, device="cuda") for k, c in
+             [("confidence", 1), ("radius", 1), ("depth", 1), ("points", 3), ("rays", 3)]}
+        d = ops.mk(ops.UdFinalize, radius_net=radius, conf_net=conf, rays_net=rays, confidence=o["confidence"], radius=o["radius"],
+                   depth=o["depth"], points=o["points"], rays=o["rays"], B=B, nb_rays=nbr, Hn=Hn, Wn=Wn, Hp=Hp, Wp=Wp,
+                   pad_l=pl, pad_t=pt, Ho=Ho, Wo=Wo)
+        ops.check(ops.lib.ud_finalize_outputs(C.byref(d), ops.cur_stream()))
+
+        def post(t):
+            t = F.interpolate(t, size=(Hp, Wp), mode="bilinear", align_corners=False)
+            return t[..., pt:pt + Ho, pl:pl + Wo]
+        pts = post(rays * radius)
+        rr = post(rays)
+        torch.cuda.synchronize()
+        assert rel(o["confidence"], post(conf)) < 1e-6
+        assert rel(o["points"], pts) < 1e-6
+        assert rel(o["radius"], pts.norm(dim=1, keepdim=True)) < 1e-6
+        assert rel(o["depth"], pts[:, -1:]) < 1e-6
+        assert rel(o["rays"], rr / rr.norm(dim=1, keepdim=True).clip(min=1e-5)) < 1e-6
+
+    xin = rnd(2, 40, 72, seed=5)
+    outT = torch.zeros(2, 70, 37, device="cuda")
+    ops.check(ops.lib.ud_nhwc_to_nchw_f32(xin.data_ptr(), outT.data_ptr(), 2, 37, 70, 72, 40, ops.cur_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(outT, xin[:, :37, :70].permute(0, 2, 1))
+
+
+def test_program_replay_matches_eager(ops):
+    M, N, K = 256, 128, 128
+    A = rnd(M, K, seed=1).half(); W = rnd(N, K, scale=K ** -0.5, seed=2).half()
+    o1 = torch.zeros(M, N, dtype=torch.half, device="cuda"); o2 = torch.zeros_like(o1)
+    ops.gemm(A=A, W=W, out=o1, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, epi=ops.UD_EPI_F16)
+    prog = ops.Program()
+    prog.gemm(A=A, W=W, out=o2, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, epi=ops.UD_EPI_F16)
+    assert len(prog) == 1
+    prog.run()
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2)
+    with pytest.raises(RuntimeError):
+        ops.gemm(A=A, W=W, out=o1, M=M, N=N, K=100, lda=K, ldw=K, ldc=N, epi=ops.UD_EPI_F16)   # K % 64 != 0 -> error code

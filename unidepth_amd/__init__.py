@@ -1,0 +1,17 @@
+"""unidepth_amd -- MI355X (gfx950) native engine for the UniDepthV2 `infer()` path.
+
+Public surface mirrors the reference (lpiccinelli-eth/UniDepth, unidepth/models/__init__.py):
+    from unidepth_amd import UniDepthV2
+    model = UniDepthV2.from_pretrained(dir_or_repo).to("cuda").eval(); out = model.infer(rgb, camera)
+All device arithmetic runs in libunidepth_hip.so (hand-written HIP); importing this package without the
+built library raises ImportError -- there is no CPU / eager-PyTorch fallback."""
+from . import _lib  # noqa: F401  (fails loudly when the HIP library is missing)
+
+__all__ = ["UniDepthV2"]
+
+
+def __getattr__(name):
+    if name == "UniDepthV2":
+        from .unidepthv2 import UniDepthV2
+        return UniDepthV2
+    raise AttributeError(name)

@@ -1,0 +1,28 @@
+// Error plumbing + library info for the C-ABI (include/unidepth_hip.h).
+#include <string.h>
+#include "../../include/unidepth_hip.h"
+
+static thread_local char g_err[256] = "";
+
+void ud_set_error(const char* msg) {
+  strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1);
+  g_err[sizeof(g_err) - 1] = 0;
+}
+
+extern "C" const char* ud_last_error(void) { return g_err; }
+extern "C" int ud_version(void) { return 100; }
+
+// struct sizes, so the Python binding can verify its ctypes mirror of include/unidepth_hip.h
+extern "C" int ud_struct_size(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(UdGemm);
+    case 1: return (int)sizeof(UdLayerNorm);
+    case 2: return (int)sizeof(UdAttention);
+    case 3: return (int)sizeof(UdPreprocess);
+    case 4: return (int)sizeof(UdRayEmbed);
+    case 5: return (int)sizeof(UdUpsample2x);
+    case 6: return (int)sizeof(UdResizeAC);
+    case 7: return (int)sizeof(UdFinalize);
+    default: return -1;
+  }
+}

@@ -1,0 +1,214 @@
+// Fused multi-head attention forward for gfx950 (flash style, online softmax), head_dim = 64, fp16 operands,
+// fp32 scores / statistics / accumulators.  One workgroup = 4 waves x 32 query rows; K and V^T tiles of 64 keys
+// are staged through LDS (register-staged, double buffered: the global loads of tile t+1 are issued before the
+// MFMAs of tile t and written to LDS after them).
+//
+// MFMA orientation (v_mfma_f32_32x32x16_f16), chosen so that softmax is lane-local:
+//   S^T[key][q] = K[key][:] . Q[q][:]      (A = K fragment from LDS, B = Q fragment held in registers)
+//     -> lane (q = lane & 31) holds 16 of the 32 keys of a block, the partner lane ^ 32 the other 16:
+//        row max / row sum = in-register reduction + one cross-lane exchange.
+//   O^T[d][q]  += V^T[d][key] . P^T[key][q] (A = V^T fragment from LDS, B = the exponentiated S^T registers,
+//        re-used in place: the accumulator layout of S^T is exactly a valid B-operand layout once the k-slots
+//        of the MFMA are mapped to keys {4h+8g+e}; the V^T fragment is read with the same key permutation).
+//     -> the per-row rescale factor alpha is per lane, no shuffles in the main loop.
+// V arrives pre-transposed ([head][d][key], written by the QKV GEMM epilogue), so both LDS tiles are filled with
+// 16-byte row-contiguous loads.  LDS layouts: K [64][64] halves with the 16-byte chunk index XOR-swizzled by
+// (key >> 1) & 7 (conflict-free ds_read_b128); V^T [64 d][64 keys] with rows padded to 136 bytes
+// (conflict-free ds_read_b64 for 32 consecutive d).
+#include "ud_common.h"
+
+namespace {
+
+constexpr int KT = 64;             // keys per tile
+constexpr int KS_BYTES = 64 * 128;
+constexpr int VS_STRIDE = 136;
+constexpr int VS_BYTES = 64 * VS_STRIDE;
+constexpr int STAGE = KS_BYTES + VS_BYTES;
+
+__global__ __launch_bounds__(256) void attention_kernel(const UdAttention p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = tid >> 6;
+  const int hh = lane >> 5;
+  const int ql = lane & 31;
+  const int head = blockIdx.y;
+  const int img = blockIdx.z;
+  const int kimg = p.kv_broadcast ? 0 : img;
+  const int q0 = blockIdx.x * 128 + wv * 32;
+
+  const half_t* Q = (const half_t*)p.Q;
+  const half_t* K = (const half_t*)p.K;
+  const half_t* Vt = (const half_t*)p.Vt + ((size_t)kimg * p.H + head) * 64 * (size_t)p.kv_ld;
+
+  // ---- Q fragments (B operand): q = ql, d = ks*16 + hh*8 .. +8
+  half8 qf[4];
+  {
+    int qr = q0 + ql;
+    qr = qr < p.Nq ? qr : p.Nq - 1;
+    const half_t* qp = Q + ((size_t)img * p.q_rows_per_img + qr) * p.ldq + head * 64 + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const half8*)(qp + ks * 16);
+  }
+
+  // ---- tile loader geometry: 512 16-byte chunks per operand tile, 2 per thread
+  const int nt = (p.Nk + KT - 1) / KT;
+  half8 kreg[2], vreg[2];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + 256 * i;
+      const int row = c >> 3, ch = c & 7;
+      int key = kt * KT + row;
+      key = key < p.Nk ? key : p.Nk - 1;
+      kreg[i] = *(const half8*)(K + ((size_t)kimg * p.k_rows_per_img + key) * p.ldk + head * 64 + ch * 8);
+      vreg[i] = *(const half8*)(Vt + (size_t)row * p.kv_ld + kt * KT + ch * 8);   // row = d
+    }
+  };
+  auto lstore = [&](int stage) {
+    char* sb = smem + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + 256 * i;
+      const int row = c >> 3, ch = c & 7;
+      *(half8*)(sb + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = kreg[i];
+      half4 lo, hi;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        lo[e] = vreg[i][e];
+        hi[e] = vreg[i][4 + e];
+      }
+      char* vp = sb + KS_BYTES + row * VS_STRIDE + ch * 16;
+      *(half4*)vp = lo;
+      *(half4*)(vp + 8) = hi;
+    }
+  };
+
+  f32x16 o[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.0f;
+  float m_i = -1.0e30f;
+  float l_i = 0.0f;
+  const float c = p.scale * 1.4426950408889634f;
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  const int kswz = (ql >> 1) & 7;   // (key >> 1) & 7 for key = kb*32 + ql
+  for (int kt = 0; kt < nt; ++kt) {
+    if (kt + 1 < nt) gload(kt + 1);
+    const char* sb = smem + (kt & 1) * STAGE;
+
+    // ---- S^T = K Q^T  (two 32-key blocks)
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
+      const char* kp = sb + (kb * 32 + ql) * 128;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const half8 kf = *(const half8*)(kp + (((ks * 2 + hh) ^ kswz) << 4));
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kb], 0, 0, 0);
+      }
+    }
+    // ---- mask the key tail (last tile only)
+    if (kt == nt - 1 && (p.Nk & (KT - 1))) {
+      const int kbase = kt * KT + 4 * hh;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2);
+          if (key >= p.Nk) s[kb][r] = -1.0e30f;
+        }
+    }
+    // ---- online softmax (lane-local + partner lane ^ 32)
+    float mt = s[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[kb][r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_i, mt);
+    const float alpha = __builtin_amdgcn_exp2f((m_i - m_new) * c);
+    m_i = m_new;
+    const float mc = m_new * c;
+    float ls = 0.0f;
+    half8 pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float pv = __builtin_amdgcn_exp2f(s[kb][t * 8 + e] * c - mc);
+          ls += pv;
+          pf[kb][t][e] = (half_t)pv;
+        }
+    l_i = l_i * alpha + ls;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+
+    // ---- O^T += V^T P^T
+    const char* vs = sb + KS_BYTES;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const char* vrow = vs + (db * 32 + ql) * VS_STRIDE + hh * 8;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const half4 lo = *(const half4*)(vrow + (kb * 32 + t * 16) * 2);
+          const half4 hi = *(const half4*)(vrow + (kb * 32 + t * 16 + 8) * 2);
+          half8 vf;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            vf[e] = lo[e];
+            vf[4 + e] = hi[e];
+          }
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][t], o[db], 0, 0, 0);
+        }
+    }
+
+    if (kt + 1 < nt) lstore((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- normalise and store O[q][head*64 + d]
+  const float l_tot = l_i + __shfl_xor(l_i, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qr = q0 + ql;
+  if (qr < p.Nq) {
+    half_t* op = (half_t*)p.O + ((size_t)img * p.q_rows_per_img + qr) * p.ldo + head * 64 + 4 * hh;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        half4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (half_t)(o[db][g * 4 + e] * inv);
+        *(half4*)(op + db * 32 + g * 8) = h;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int ud_attention_f16(const UdAttention* desc, void* stream) {
+  const UdAttention& d = *desc;
+  if (!d.Q || !d.K || !d.Vt || !d.O || d.B <= 0 || d.H <= 0 || d.Nq <= 0 || d.Nk <= 0 || (d.ldq & 7) || (d.ldk & 7) ||
+      (d.ldo & 3) || (d.kv_ld & 63) || d.kv_ld < ((d.Nk + 63) & ~63)) {
+    ud_set_error("ud_attention_f16: bad argument (ldq/ldk % 8, kv_ld % 64, kv_ld >= roundup(Nk, 64))");
+    return UD_ERR_BAD_ARG;
+  }
+  dim3 grid((d.Nq + 127) / 128, d.H, d.B);
+  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, (hipStream_t)stream, d);
+  UD_CHECK_LAUNCH("ud_attention_f16 launch");
+  return UD_OK;
+}

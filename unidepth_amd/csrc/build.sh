@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build libunidepth_hip.so for gfx950 in-tree (cross-compiles without a GPU).  Usage: csrc/build.sh [extra hipcc flags]
+set -e
+cd "$(dirname "$0")"
+OUT=../libunidepth_hip.so
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result"
+mkdir -p build
+pids=()
+for f in gemm.hip attention.hip layernorm.hip pointwise.hip; do
+  ( hipcc $FLAGS "$@" -c $f -o build/${f%.hip}.o ) &
+  pids+=($!)
+done
+( hipcc $FLAGS -x hip -c api.cpp -o build/api.o ) & pids+=($!)
+( hipcc $FLAGS -x hip -c program.cpp -o build/program.o ) & pids+=($!)
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o $OUT
+echo "built $(realpath $OUT)"

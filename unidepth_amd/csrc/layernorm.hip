@@ -1,0 +1,73 @@
+// LayerNorm statistics kernel: fp32 rows -> normalised fp16 rows (affine folded into the consumer GEMM's weights).
+// HBM-bound: one wave64 per row, 16-byte loads, two-pass (mean, then centred variance) entirely in registers,
+// wavefront reductions via cross-lane shuffles.  Algorithmic bytes per row: 4*D read + 2*D written.
+#include "ud_common.h"
+
+namespace {
+
+template <int NIT>  // D <= NIT * 256
+__global__ __launch_bounds__(256) void layernorm_kernel(const UdLayerNorm p) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= p.rows) return;
+  const int img = r / p.rows_per_img;
+  const int pp = r - img * p.rows_per_img;
+  const size_t irow = (size_t)img * p.in_rows_per_img + pp + p.in_row_off;
+  const size_t orow = (size_t)img * p.out_rows_per_img + pp + p.out_row_off;
+  const float* x = p.x + irow * p.ldx;
+  half_t* y = (half_t*)p.y + orow * p.ldy;
+  f32x4 v[NIT];
+  float s = 0.0f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 256 + lane * 4;
+    if (c < p.D) {
+      v[it] = *(const f32x4*)(x + c);
+      s += (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]);
+    } else {
+      v[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const float mean = ud_wave_sum(s) / (float)p.D;
+  float q = 0.0f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 256 + lane * 4;
+    if (c < p.D) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[it][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(ud_wave_sum(q) / (float)p.D + p.eps);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 256 + lane * 4;
+    if (c < p.D) {
+      half4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = (half_t)((v[it][e] - mean) * rstd);
+      *(half4*)(y + c) = h;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int ud_layernorm_f32_f16(const UdLayerNorm* desc, void* stream) {
+  const UdLayerNorm& d = *desc;
+  if (!d.x || !d.y || d.rows <= 0 || d.D <= 0 || (d.D & 3) || d.D > 2048 || (d.ldx & 3) || (d.ldy & 3) || d.rows_per_img <= 0) {
+    ud_set_error("ud_layernorm_f32_f16: bad argument (D % 4 == 0, D <= 2048)");
+    return UD_ERR_BAD_ARG;
+  }
+  dim3 grid((d.rows + 3) / 4);
+  hipStream_t s = (hipStream_t)stream;
+  if (d.D <= 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, d);
+  else if (d.D <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, d);
+  else if (d.D <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, s, d);
+  else hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, s, d);
+  UD_CHECK_LAUNCH("ud_layernorm_f32_f16 launch");
+  return UD_OK;
+}

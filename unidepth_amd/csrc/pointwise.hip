@@ -1,0 +1,434 @@
+// HBM-bound / latency-bound kernels of the infer() path: pre-processing + im2col, camera tail, ray generation,
+// ray angle embedding (+LayerNorm statistics), bilinear resamplers, output assembly, layout change.
+// All are coalesced along the fastest-varying dimension, 8/16-byte accesses where layout allows, wave64 reductions.
+#include "ud_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ preprocess
+// one thread per (patch row m, k) element; k fastest -> coalesced 2-byte stores, near-coalesced source reads.
+__global__ __launch_bounds__(256) void preprocess_kernel(const UdPreprocess p) {
+  const int hgrid = p.Hn / 14, wgrid = p.Wn / 14;
+  const long long total = (long long)p.B * hgrid * wgrid * 588;
+  const float sy = (float)p.Hp / (float)p.Hn, sx = (float)p.Wp / (float)p.Wn;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int k = (int)(idx % 588);
+    const long long m = idx / 588;
+    const int px = (int)(m % wgrid);
+    const int py = (int)((m / wgrid) % hgrid);
+    const int img = (int)(m / ((long long)wgrid * hgrid));
+    const int c = k / 196, ij = k - c * 196;
+    const int i = ij / 14, j = ij - i * 14;
+    const int oy = py * 14 + i, ox = px * 14 + j;
+    // bilinear, align_corners=False, source = zero-padded normalised image [Hp, Wp]
+    float fy = sy * ((float)oy + 0.5f) - 0.5f;
+    float fx = sx * ((float)ox + 0.5f) - 0.5f;
+    fy = fy < 0.0f ? 0.0f : fy;
+    fx = fx < 0.0f ? 0.0f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < p.Hp - 1), x1 = x0 + (x0 < p.Wp - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    auto sample = [&](int yy, int xx) -> float {
+      yy -= p.pad_t;
+      xx -= p.pad_l;
+      if ((unsigned)yy >= (unsigned)p.H || (unsigned)xx >= (unsigned)p.W) return 0.0f;   // pad = 0 after normalisation
+      const size_t off = (((size_t)img * 3 + c) * p.H + yy) * p.W + xx;
+      float v = p.is_u8 ? (float)((const unsigned char*)p.rgb)[off] : ((const float*)p.rgb)[off];
+      if (p.normalize) v = (v / 255.0f - p.mean[c]) * p.inv_std[c];
+      return v;
+    };
+    float v;
+    if (ly == 0.0f && lx == 0.0f) {
+      v = sample(y0, x0);
+    } else {
+      const float v00 = sample(y0, x0), v01 = sample(y0, x1), v10 = sample(y1, x0), v11 = sample(y1, x1);
+      v = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
+    }
+    ((half_t*)p.patches)[m * p.ldp + k] = (half_t)v;
+  }
+}
+
+__global__ void fill_rows_kernel(float* dst, const float* src, int n_img, int rows_per_img, int row_off, int D, int ld) {
+  const int img = blockIdx.y;
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < D; c += gridDim.x * 256)
+    dst[((size_t)img * rows_per_img + row_off) * ld + c] = src[c];
+}
+
+// ------------------------------------------------------------------------------------------------ camera tail
+__global__ void camera_kernel(const float* raw, int raw_stride, float* intr4, float* K33, float* Kinv33, float* Kpost33, int B,
+                              int Hn, int Wn, float rf, int pad_l, int pad_t) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const float* o = raw + (size_t)b * 4 * raw_stride;
+  const float diag = sqrtf((float)Hn * (float)Hn + (float)Wn * (float)Wn);
+  const float fx = expf(o[0]) * (0.7f * diag);
+  const float fy = expf(o[raw_stride]) * (0.7f * diag);
+  const float cx = (1.0f / (1.0f + expf(-o[2 * raw_stride]))) * (float)Wn;
+  const float cy = (1.0f / (1.0f + expf(-o[3 * raw_stride]))) * (float)Hn;
+  intr4[b * 4 + 0] = fx; intr4[b * 4 + 1] = fy; intr4[b * 4 + 2] = cx; intr4[b * 4 + 3] = cy;
+  float* K = K33 + b * 9;
+  K[0] = fx; K[1] = 0.f; K[2] = cx; K[3] = 0.f; K[4] = fy; K[5] = cy; K[6] = 0.f; K[7] = 0.f; K[8] = 1.f;
+  float* Ki = Kinv33 + b * 9;
+  Ki[0] = 1.0f / fx; Ki[1] = 0.f; Ki[2] = -cx / fx; Ki[3] = 0.f; Ki[4] = 1.0f / fy; Ki[5] = -cy / fy; Ki[6] = 0.f; Ki[7] = 0.f; Ki[8] = 1.f;
+  float* Kp = Kpost33 + b * 9;
+  Kp[0] = fx / rf; Kp[1] = 0.f; Kp[2] = cx / rf - (float)pad_l; Kp[3] = 0.f; Kp[4] = fy / rf; Kp[5] = cy / rf - (float)pad_t;
+  Kp[6] = 0.f; Kp[7] = 0.f; Kp[8] = 1.f;
+}
+
+__global__ __launch_bounds__(256) void rays_kernel(const float* Kinv33, float* rays, int nb, int Hn, int Wn, int gt_mode) {
+  const int b = blockIdx.y;
+  const float* Ki = Kinv33 + b * 9;
+  const float k0 = Ki[0], k1 = Ki[1], k2 = Ki[2], k3 = Ki[3], k4 = Ki[4], k5 = Ki[5], k6 = Ki[6], k7 = Ki[7], k8 = Ki[8];
+  const int HW = Hn * Wn;
+  for (int pix = blockIdx.x * 256 + threadIdx.x; pix < HW; pix += gridDim.x * 256) {
+    const int v = pix / Wn, u = pix - v * Wn;
+    const float uf = (float)u + 0.5f, vf = (float)v + 0.5f;
+    float x = k0 * uf + k1 * vf + k2;
+    float y = k3 * uf + k4 * vf + k5;
+    float z = k6 * uf + k7 * vf + k8;
+    float nmin = 1e-5f;
+    if (gt_mode) {
+      const float zc = fmaxf(z, 1e-4f);
+      x /= zc; y /= zc; z /= zc;
+      nmin = 1e-4f;
+    }
+    const float inv = 1.0f / fmaxf(sqrtf(x * x + y * y + z * z), nmin);
+    float* r = rays + (size_t)b * 3 * HW + pix;
+    r[0] = x * inv; r[HW] = y * inv; r[2 * (size_t)HW] = z * inv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ ray embedding
+// one wave per output token: lanes split the (<= 4*scale^2) taps of the separable antialias triangle filter,
+// wave reduction, then each lane evaluates C/64 sine bands; LayerNorm statistics over C via wave reductions.
+__global__ __launch_bounds__(256) void ray_embed_kernel(const UdRayEmbed p) {
+  const int lane = threadIdx.x & 63;
+  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int hw = p.h * p.w;
+  if (tok >= p.nb * hw) return;
+  const int img = tok / hw;
+  const int t = tok - img * hw;
+  const int ty = t / p.w, tx = t - ty * p.w;
+  const float sy = (float)p.Hn / (float)p.h, sx = (float)p.Wn / (float)p.w;
+  const float supy = sy >= 1.0f ? sy : 1.0f, supx = sx >= 1.0f ? sx : 1.0f;
+  const float invy = sy >= 1.0f ? 1.0f / sy : 1.0f, invx = sx >= 1.0f ? 1.0f / sx : 1.0f;
+  const float cy = sy * ((float)ty + 0.5f), cx = sx * ((float)tx + 0.5f);
+  int ymin = (int)(cy - supy + 0.5f); ymin = ymin < 0 ? 0 : ymin;
+  int ymax = (int)(cy + supy + 0.5f); ymax = ymax > p.Hn ? p.Hn : ymax;
+  int xmin = (int)(cx - supx + 0.5f); xmin = xmin < 0 ? 0 : xmin;
+  int xmax = (int)(cx + supx + 0.5f); xmax = xmax > p.Wn ? p.Wn : xmax;
+  const int ny = ymax - ymin, nx = xmax - xmin;
+  const size_t HW = (size_t)p.Hn * p.Wn;
+  const float* r = p.rays + (size_t)img * 3 * HW;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, wsum = 0.f;
+  for (int i = lane; i < ny * nx; i += 64) {
+    const int iy = i / nx, ix = i - iy * nx;
+    float wy = 1.0f - fabsf(((float)(iy + ymin) - cy + 0.5f) * invy);
+    float wx = 1.0f - fabsf(((float)(ix + xmin) - cx + 0.5f) * invx);
+    wy = wy < 0.f ? 0.f : wy;
+    wx = wx < 0.f ? 0.f : wx;
+    const float w = wy * wx;
+    const size_t off = (size_t)(iy + ymin) * p.Wn + (ix + xmin);
+    a0 += w * r[off]; a1 += w * r[off + HW]; a2 += w * r[off + 2 * HW];
+    wsum += w;
+  }
+  a0 = ud_wave_sum(a0); a1 = ud_wave_sum(a1); a2 = ud_wave_sum(a2); wsum = ud_wave_sum(wsum);
+  const float iw = 1.0f / wsum;
+  float x = a0 * iw, y = a1 * iw, z = a2 * iw;
+  const float inv = 1.0f / fmaxf(sqrtf(x * x + y * y + z * z), 1e-4f);
+  x *= inv; y *= inv; z *= inv;
+  const float polar = acosf(z);
+  const float xc = fmaxf(fabsf(x), 1e-3f) * (x >= 0.0f ? 1.0f : -1.0f);
+  const float az = atan2f(y, xc);
+  const int nbands = p.C >> 1;
+  const float PI = 3.14159265358979323846f;
+  // C <= 512 -> up to 8 values per lane
+  float vals[8];
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int c = it * 64 + lane;
+    float v = 0.f;
+    if (c < p.C) {
+      const bool second = c >= nbands;
+      const float ang = second ? az : polar;
+      const float sc = p.scales[second ? c - nbands : c];
+      v = sinf(ang * sc * PI);
+      s += v;
+    }
+    vals[it] = v;
+  }
+  const float mean = ud_wave_sum(s) / (float)p.C;
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int c = it * 64 + lane;
+    if (c < p.C) {
+      const float d = vals[it] - mean;
+      q += d * d;
+    }
+  }
+  const float rstd = rsqrtf(ud_wave_sum(q) / (float)p.C + p.eps);
+  half_t* yrow = (half_t*)p.xhat + ((size_t)img * p.rows_per_img + t) * p.ldy;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int c = it * 64 + lane;
+    if (c < p.C) yrow[c] = (half_t)((vals[it] - mean) * rstd);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ x2 up-sampling
+// thread = 4 channels of one output pixel (16-byte fp32 loads); mode 1 additionally normalises the pixel over C.
+template <int MODE>
+__global__ __launch_bounds__(256) void upsample2x_kernel(const UdUpsample2x p) {
+  const int Ho = p.H * 2, Wo = p.W * 2;
+  const int G = p.C >> 2;                     // threads per pixel
+  const int ppb = 256 / G;                    // pixels per block (G divides into 256 with remainder ignored)
+  const int tl = threadIdx.x;
+  const int pl = tl / G, cg = tl - pl * G;
+  const long long npix = (long long)p.B * Ho * Wo;
+  __shared__ float red[2][256];
+  for (long long base = (long long)blockIdx.x * ppb; base < npix; base += (long long)gridDim.x * ppb) {
+    const long long pix = base + pl;
+    const bool active = pl < ppb && pix < npix;
+    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int ox = 0, oy = 0, b = 0;
+    if (active) {
+      ox = (int)(pix % Wo);
+      oy = (int)((pix / Wo) % Ho);
+      b = (int)(pix / ((long long)Wo * Ho));
+      float fy = 0.5f * ((float)oy + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+      float fx = 0.5f * ((float)ox + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+      const int y0 = (int)fy, x0 = (int)fx;
+      const int y1 = y0 + (y0 < p.H - 1), x1 = x0 + (x0 < p.W - 1);
+      const float ly = fy - (float)y0, lx = fx - (float)x0;
+      const float* in = (const float*)p.in + (size_t)b * (p.in_img_rows > 0 ? p.in_img_rows : p.H * p.W) * p.ldin + cg * 4;
+      const f32x4 v00 = *(const f32x4*)(in + ((size_t)y0 * p.W + x0) * p.ldin);
+      const f32x4 v01 = *(const f32x4*)(in + ((size_t)y0 * p.W + x1) * p.ldin);
+      const f32x4 v10 = *(const f32x4*)(in + ((size_t)y1 * p.W + x0) * p.ldin);
+      const f32x4 v11 = *(const f32x4*)(in + ((size_t)y1 * p.W + x1) * p.ldin);
+      v = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
+    }
+    if constexpr (MODE == 0) {
+      if (active) *(f32x4*)((float*)p.out + (size_t)pix * p.ldy + cg * 4) = v;
+    } else {
+      // LayerNorm statistics across the G threads of the pixel (LDS tree-free: G <= 64 partials summed serially)
+      red[0][tl] = (v[0] + v[1]) + (v[2] + v[3]);
+      __syncthreads();
+      float mean = 0.f;
+      if (active) {
+        for (int g = 0; g < G; ++g) mean += red[0][pl * G + g];
+        mean /= (float)p.C;
+      }
+      float q = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) q += (v[e] - mean) * (v[e] - mean);
+      red[1][tl] = q;
+      __syncthreads();
+      if (active) {
+        float var = 0.f;
+        for (int g = 0; g < G; ++g) var += red[1][pl * G + g];
+        const float rstd = rsqrtf(var / (float)p.C + p.eps);
+        half4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (half_t)((v[e] - mean) * rstd);
+        *(half4*)((half_t*)p.out + (size_t)pix * p.ldy + cg * 4) = h;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ align_corners=True resize
+__global__ __launch_bounds__(256) void resize_ac_kernel(const UdResizeAC p) {
+  const int CG = p.C >> 3;
+  const long long total = (long long)p.G * p.B * p.Hout * p.Wout * CG;
+  const float sy = p.Hout > 1 ? (float)(p.Hin - 1) / (float)(p.Hout - 1) : 0.f;
+  const float sx = p.Wout > 1 ? (float)(p.Win - 1) / (float)(p.Wout - 1) : 0.f;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int cg = (int)(idx % CG);
+    long long pix = idx / CG;
+    const int ox = (int)(pix % p.Wout);
+    const int oy = (int)((pix / p.Wout) % p.Hout);
+    const long long gb = pix / ((long long)p.Wout * p.Hout);
+    const float fy = sy * (float)oy, fx = sx * (float)ox;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < p.Hin - 1), x1 = x0 + (x0 < p.Win - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const half_t* in = (const half_t*)p.in + (size_t)gb * p.Hin * p.Win * p.C + cg * 8;
+    const half8 h00 = *(const half8*)(in + ((size_t)y0 * p.Win + x0) * p.C);
+    const half8 h01 = *(const half8*)(in + ((size_t)y0 * p.Win + x1) * p.C);
+    const half8 h10 = *(const half8*)(in + ((size_t)y1 * p.Win + x0) * p.C);
+    const half8 h11 = *(const half8*)(in + ((size_t)y1 * p.Win + x1) * p.C);
+    half8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float top = (1.0f - lx) * (float)h00[e] + lx * (float)h01[e];
+      const float bot = (1.0f - lx) * (float)h10[e] + lx * (float)h11[e];
+      o[e] = (half_t)((1.0f - ly) * top + ly * bot);
+    }
+    *(half8*)((half_t*)p.out + (size_t)pix * p.C + cg * 8) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ output assembly
+__global__ __launch_bounds__(256) void finalize_kernel(const UdFinalize p) {
+  const long long total = (long long)p.B * p.Ho * p.Wo;
+  const float sy = (float)p.Hn / (float)p.Hp, sx = (float)p.Wn / (float)p.Wp;
+  const size_t HWn = (size_t)p.Hn * p.Wn, HWo = (size_t)p.Ho * p.Wo;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int ox = (int)(idx % p.Wo);
+    const int oy = (int)((idx / p.Wo) % p.Ho);
+    const int b = (int)(idx / ((long long)p.Wo * p.Ho));
+    float fy = sy * ((float)(oy + p.pad_t) + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+    float fx = sx * ((float)(ox + p.pad_l) + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < p.Hn - 1), x1 = x0 + (x0 < p.Wn - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float w00 = (1.0f - ly) * (1.0f - lx), w01 = (1.0f - ly) * lx, w10 = ly * (1.0f - lx), w11 = ly * lx;
+    const size_t o00 = (size_t)y0 * p.Wn + x0, o01 = (size_t)y0 * p.Wn + x1, o10 = (size_t)y1 * p.Wn + x0, o11 = (size_t)y1 * p.Wn + x1;
+    const float* rad = p.radius_net + (size_t)b * HWn;
+    const float* cf = p.conf_net + (size_t)b * HWn;
+    const float* ry = p.rays_net + (size_t)(p.nb_rays == 1 ? 0 : b) * 3 * HWn;
+    const float r00 = rad[o00], r01 = rad[o01], r10 = rad[o10], r11 = rad[o11];
+    const float conf = w00 * cf[o00] + w01 * cf[o01] + w10 * cf[o10] + w11 * cf[o11];
+    float pt[3], rr[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float* rc = ry + ch * HWn;
+      const float a = rc[o00], bq = rc[o01], cq = rc[o10], d = rc[o11];
+      rr[ch] = w00 * a + w01 * bq + w10 * cq + w11 * d;
+      pt[ch] = w00 * (a * r00) + w01 * (bq * r01) + w10 * (cq * r10) + w11 * (d * r11);
+    }
+    const size_t po = (size_t)oy * p.Wo + ox;
+    p.confidence[(size_t)b * HWo + po] = conf;
+    p.radius[(size_t)b * HWo + po] = sqrtf(pt[0] * pt[0] + pt[1] * pt[1] + pt[2] * pt[2]);
+    p.depth[(size_t)b * HWo + po] = pt[2];
+    const float rn = 1.0f / fmaxf(sqrtf(rr[0] * rr[0] + rr[1] * rr[1] + rr[2] * rr[2]), 1e-5f);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      p.points[((size_t)b * 3 + ch) * HWo + po] = pt[ch];
+      if (p.nb_rays != 1 || b == 0) p.rays[((size_t)b * 3 + ch) * HWo + po] = rr[ch] * rn;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ NHWC -> NCHW
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* in, float* out, int B, int hw, int C, int ld, int rows_per_img) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z;
+  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4) {
+    const int pp = p0 + r, c = c0 + tx;
+    tile[r][tx] = (pp < hw && c < C) ? in[((size_t)b * rows_per_img + pp) * ld + c] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const int c = c0 + r, pp = p0 + tx;
+    if (pp < hw && c < C) out[((size_t)b * C + c) * hw + pp] = tile[tx][r];
+  }
+}
+
+inline int grid_for(long long total, int per_block = 256, int cap = 256 * 16) {
+  long long g = (total + per_block - 1) / per_block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int ud_preprocess_patches(const UdPreprocess* desc, void* stream) {
+  const UdPreprocess& d = *desc;
+  if (!d.rgb || !d.patches || d.B <= 0 || d.Hn % 14 || d.Wn % 14 || d.ldp < 588 || d.Hp < d.H + d.pad_t || d.Wp < d.W + d.pad_l) {
+    ud_set_error("ud_preprocess_patches: bad argument");
+    return UD_ERR_BAD_ARG;
+  }
+  const long long total = (long long)d.B * (d.Hn / 14) * (d.Wn / 14) * 588;
+  hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, d);
+  UD_CHECK_LAUNCH("ud_preprocess_patches launch");
+  return UD_OK;
+}
+
+extern "C" int ud_fill_rows_f32(float* dst, const float* src, int n_img, int rows_per_img, int row_off, int D, int ld, void* stream) {
+  if (!dst || !src || n_img <= 0 || D <= 0) { ud_set_error("ud_fill_rows_f32: bad argument"); return UD_ERR_BAD_ARG; }
+  hipLaunchKernelGGL(fill_rows_kernel, dim3((D + 255) / 256, n_img), dim3(256), 0, (hipStream_t)stream, dst, src, n_img, rows_per_img, row_off, D, ld);
+  UD_CHECK_LAUNCH("ud_fill_rows_f32 launch");
+  return UD_OK;
+}
+
+extern "C" int ud_camera_intrinsics(const float* raw, int raw_stride, float* intr4, float* K33, float* Kinv33, float* Kpost33, int B,
+                                    int Hn, int Wn, float resize_factor, int pad_l, int pad_t, void* stream) {
+  if (!raw || !intr4 || !K33 || !Kinv33 || !Kpost33 || B <= 0 || raw_stride <= 0 || !(resize_factor > 0.f)) {
+    ud_set_error("ud_camera_intrinsics: bad argument");
+    return UD_ERR_BAD_ARG;
+  }
+  hipLaunchKernelGGL(camera_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, raw, raw_stride, intr4, K33, Kinv33, Kpost33, B, Hn,
+                     Wn, resize_factor, pad_l, pad_t);
+  UD_CHECK_LAUNCH("ud_camera_intrinsics launch");
+  return UD_OK;
+}
+
+extern "C" int ud_rays_from_kinv(const float* Kinv33, float* rays, int nb, int Hn, int Wn, int gt_mode, void* stream) {
+  if (!Kinv33 || !rays || nb <= 0 || Hn <= 0 || Wn <= 0) { ud_set_error("ud_rays_from_kinv: bad argument"); return UD_ERR_BAD_ARG; }
+  hipLaunchKernelGGL(rays_kernel, dim3(grid_for((long long)Hn * Wn, 256, 1024), nb), dim3(256), 0, (hipStream_t)stream, Kinv33, rays, nb, Hn, Wn, gt_mode);
+  UD_CHECK_LAUNCH("ud_rays_from_kinv launch");
+  return UD_OK;
+}
+
+extern "C" int ud_ray_embed(const UdRayEmbed* desc, void* stream) {
+  const UdRayEmbed& d = *desc;
+  if (!d.rays || !d.scales || !d.xhat || d.nb <= 0 || d.C > 512 || (d.C & 1) || d.h <= 0 || d.w <= 0) {
+    ud_set_error("ud_ray_embed: bad argument (C <= 512)");
+    return UD_ERR_BAD_ARG;
+  }
+  const int ntok = d.nb * d.h * d.w;
+  hipLaunchKernelGGL(ray_embed_kernel, dim3((ntok + 3) / 4), dim3(256), 0, (hipStream_t)stream, d);
+  UD_CHECK_LAUNCH("ud_ray_embed launch");
+  return UD_OK;
+}
+
+extern "C" int ud_upsample2x_nhwc(const UdUpsample2x* desc, void* stream) {
+  const UdUpsample2x& d = *desc;
+  if (!d.in || !d.out || d.B <= 0 || (d.C & 3) || d.C > 1024 || (d.ldin & 3) || (d.ldy & 3)) {
+    ud_set_error("ud_upsample2x_nhwc: bad argument");
+    return UD_ERR_BAD_ARG;
+  }
+  const int G = d.C >> 2;
+  const int ppb = 256 / G;
+  const long long npix = (long long)d.B * d.H * 2 * d.W * 2;
+  const int grid = grid_for(npix, ppb, 256 * 32);
+  if (d.mode == 0) hipLaunchKernelGGL(upsample2x_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d);
+  else hipLaunchKernelGGL(upsample2x_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, d);
+  UD_CHECK_LAUNCH("ud_upsample2x_nhwc launch");
+  return UD_OK;
+}
+
+extern "C" int ud_resize_ac_nhwc_f16(const UdResizeAC* desc, void* stream) {
+  const UdResizeAC& d = *desc;
+  if (!d.in || !d.out || d.G <= 0 || d.B <= 0 || (d.C & 7)) { ud_set_error("ud_resize_ac_nhwc_f16: bad argument"); return UD_ERR_BAD_ARG; }
+  const long long total = (long long)d.G * d.B * d.Hout * d.Wout * (d.C >> 3);
+  hipLaunchKernelGGL(resize_ac_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, d);
+  UD_CHECK_LAUNCH("ud_resize_ac_nhwc_f16 launch");
+  return UD_OK;
+}
+
+extern "C" int ud_finalize_outputs(const UdFinalize* desc, void* stream) {
+  const UdFinalize& d = *desc;
+  if (!d.radius_net || !d.conf_net || !d.rays_net || !d.confidence || !d.radius || !d.depth || !d.points || !d.rays || d.B <= 0 ||
+      d.Ho + d.pad_t > d.Hp || d.Wo + d.pad_l > d.Wp) {
+    ud_set_error("ud_finalize_outputs: bad argument");
+    return UD_ERR_BAD_ARG;
+  }
+  hipLaunchKernelGGL(finalize_kernel, dim3(grid_for((long long)d.B * d.Ho * d.Wo, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, d);
+  UD_CHECK_LAUNCH("ud_finalize_outputs launch");
+  return UD_OK;
+}
+
+extern "C" int ud_nhwc_to_nchw_f32(const float* in, float* out, int B, int hw, int C, int ld, int rows_per_img, void* stream) {
+  if (!in || !out || B <= 0 || hw <= 0 || C <= 0) { ud_set_error("ud_nhwc_to_nchw_f32: bad argument"); return UD_ERR_BAD_ARG; }
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((hw + 63) / 64, (C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, in, out, B, hw, C, ld, rows_per_img);
+  UD_CHECK_LAUNCH("ud_nhwc_to_nchw_f32 launch");
+  return UD_OK;
+}

@@ -1,0 +1,87 @@
+// Launch programs: the host-side runtime piece of the engine.  A forward pass is recorded once per
+// (model, batch, shape) as a flat list of kernel descriptors and replayed with ONE call from Python, so the
+// per-launch host cost is a C++ switch instead of a ctypes round trip (the recorded range can also be captured
+// into a hipGraph by the caller: every launch goes to the stream passed to ud_program_run).
+#include <vector>
+#include <new>
+#include "../../include/unidepth_hip.h"
+
+void ud_set_error(const char* msg);
+
+namespace {
+enum Kind { K_GEMM, K_LN, K_ATTN, K_PRE, K_FILL, K_CAM, K_RAYS, K_EMBED, K_UP2, K_RESIZE, K_FINAL, K_T };
+struct FillArgs { float* dst; const float* src; int n_img, rows_per_img, row_off, D, ld; };
+struct CamArgs { const float* raw; int raw_stride; float* intr4; float* K33; float* Kinv33; float* Kpost33; int B, Hn, Wn; float rf; int pad_l, pad_t; };
+struct RaysArgs { const float* Kinv33; float* rays; int nb, Hn, Wn, gt_mode; };
+struct TArgs { const float* in; float* out; int B, hw, C, ld, rows_per_img; };
+struct Op {
+  Kind kind;
+  union {
+    UdGemm gemm; UdLayerNorm ln; UdAttention attn; UdPreprocess pre; FillArgs fill; CamArgs cam; RaysArgs rays;
+    UdRayEmbed embed; UdUpsample2x up2; UdResizeAC resize; UdFinalize fin; TArgs t;
+  };
+  Op() {}
+};
+}  // namespace
+
+struct UdProgram { std::vector<Op> ops; };
+
+extern "C" {
+UdProgram* ud_program_create(void) { return new (std::nothrow) UdProgram(); }
+void ud_program_destroy(UdProgram* p) { delete p; }
+int ud_program_size(const UdProgram* p) { return p ? (int)p->ops.size() : 0; }
+
+#define ADD(KIND, FIELD, SRC)       \
+  if (!p) return UD_ERR_BAD_ARG;    \
+  Op op; op.kind = KIND; op.FIELD = SRC; p->ops.push_back(op); return (int)p->ops.size() - 1;
+
+int ud_program_add_gemm(UdProgram* p, const UdGemm* d) { ADD(K_GEMM, gemm, *d) }
+int ud_program_add_layernorm(UdProgram* p, const UdLayerNorm* d) { ADD(K_LN, ln, *d) }
+int ud_program_add_attention(UdProgram* p, const UdAttention* d) { ADD(K_ATTN, attn, *d) }
+int ud_program_add_preprocess(UdProgram* p, const UdPreprocess* d) { ADD(K_PRE, pre, *d) }
+int ud_program_add_fill_rows(UdProgram* p, float* dst, const float* src, int n_img, int rows_per_img, int row_off, int D, int ld) {
+  FillArgs a = {dst, src, n_img, rows_per_img, row_off, D, ld};
+  ADD(K_FILL, fill, a)
+}
+int ud_program_add_camera_intrinsics(UdProgram* p, const float* raw, int raw_stride, float* intr4, float* K33, float* Kinv33, float* Kpost33,
+                                     int B, int Hn, int Wn, float resize_factor, int pad_l, int pad_t) {
+  CamArgs a = {raw, raw_stride, intr4, K33, Kinv33, Kpost33, B, Hn, Wn, resize_factor, pad_l, pad_t};
+  ADD(K_CAM, cam, a)
+}
+int ud_program_add_rays(UdProgram* p, const float* Kinv33, float* rays, int nb, int Hn, int Wn, int gt_mode) {
+  RaysArgs a = {Kinv33, rays, nb, Hn, Wn, gt_mode};
+  ADD(K_RAYS, rays, a)
+}
+int ud_program_add_ray_embed(UdProgram* p, const UdRayEmbed* d) { ADD(K_EMBED, embed, *d) }
+int ud_program_add_upsample2x(UdProgram* p, const UdUpsample2x* d) { ADD(K_UP2, up2, *d) }
+int ud_program_add_resize_ac(UdProgram* p, const UdResizeAC* d) { ADD(K_RESIZE, resize, *d) }
+int ud_program_add_finalize(UdProgram* p, const UdFinalize* d) { ADD(K_FINAL, fin, *d) }
+int ud_program_add_nhwc_to_nchw(UdProgram* p, const float* in, float* out, int B, int hw, int C, int ld, int rows_per_img) {
+  TArgs a = {in, out, B, hw, C, ld, rows_per_img};
+  ADD(K_T, t, a)
+}
+
+int ud_program_run(const UdProgram* p, int first, int last, void* stream) {
+  if (!p || first < 0 || last > (int)p->ops.size() || first > last) { ud_set_error("ud_program_run: bad range"); return UD_ERR_BAD_ARG; }
+  for (int i = first; i < last; ++i) {
+    const Op& op = p->ops[i];
+    int rc = UD_OK;
+    switch (op.kind) {
+      case K_GEMM: rc = ud_gemm_f16(&op.gemm, stream); break;
+      case K_LN: rc = ud_layernorm_f32_f16(&op.ln, stream); break;
+      case K_ATTN: rc = ud_attention_f16(&op.attn, stream); break;
+      case K_PRE: rc = ud_preprocess_patches(&op.pre, stream); break;
+      case K_FILL: rc = ud_fill_rows_f32(op.fill.dst, op.fill.src, op.fill.n_img, op.fill.rows_per_img, op.fill.row_off, op.fill.D, op.fill.ld, stream); break;
+      case K_CAM: rc = ud_camera_intrinsics(op.cam.raw, op.cam.raw_stride, op.cam.intr4, op.cam.K33, op.cam.Kinv33, op.cam.Kpost33, op.cam.B, op.cam.Hn, op.cam.Wn, op.cam.rf, op.cam.pad_l, op.cam.pad_t, stream); break;
+      case K_RAYS: rc = ud_rays_from_kinv(op.rays.Kinv33, op.rays.rays, op.rays.nb, op.rays.Hn, op.rays.Wn, op.rays.gt_mode, stream); break;
+      case K_EMBED: rc = ud_ray_embed(&op.embed, stream); break;
+      case K_UP2: rc = ud_upsample2x_nhwc(&op.up2, stream); break;
+      case K_RESIZE: rc = ud_resize_ac_nhwc_f16(&op.resize, stream); break;
+      case K_FINAL: rc = ud_finalize_outputs(&op.fin, stream); break;
+      case K_T: rc = ud_nhwc_to_nchw_f32(op.t.in, op.t.out, op.t.B, op.t.hw, op.t.C, op.t.ld, op.t.rows_per_img, stream); break;
+    }
+    if (rc != UD_OK) return rc;
+  }
+  return UD_OK;
+}
+}

@@ -1,0 +1,119 @@
+"""Thin host-side helpers over the C-ABI: build descriptors from torch tensors (device memory + streams are
+PyTorch-ROCm's; all arithmetic is in libunidepth_hip.so) and record / replay launch programs."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (UD_A_CONV3_REFLECT, UD_A_CONV3_ZERO, UD_A_DENSE, UD_ACT_GELU, UD_ACT_LRELU, UD_ACT_NONE,  # noqa: F401
+                   UD_EPI_D2S, UD_EPI_F16, UD_EPI_F32, UD_EPI_HEAD, UD_EPI_QKV, UdAttention, UdFinalize, UdGemm,
+                   UdLayerNorm, UdPreprocess, UdRayEmbed, UdResizeAC, UdUpsample2x, check, lib)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    assert t.is_cuda, "device tensor expected"
+    return t.data_ptr()
+
+
+def cur_stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def mk(struct, **kw):
+    """Fill a descriptor struct; tensors become device pointers (an int is taken as a raw address)."""
+    d = struct()
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            v = v.data_ptr()
+        elif isinstance(v, (tuple, list)):
+            v = (C.c_float * len(v))(*v)
+        setattr(d, k, v)
+    return d
+
+
+# ---- eager single-op entry points (used by the kernel-level tests) -------------------------------------
+def gemm(**kw):
+    check(lib.ud_gemm_f16(C.byref(mk(UdGemm, **kw)), cur_stream()), "ud_gemm_f16")
+
+
+def layernorm(**kw):
+    check(lib.ud_layernorm_f32_f16(C.byref(mk(UdLayerNorm, **kw)), cur_stream()), "ud_layernorm_f32_f16")
+
+
+def attention(**kw):
+    check(lib.ud_attention_f16(C.byref(mk(UdAttention, **kw)), cur_stream()), "ud_attention_f16")
+
+
+class Program:
+    """Recorded list of kernel launches (UdProgram): built once per (batch, shape), replayed per infer()."""
+
+    def __init__(self):
+        self.h = lib.ud_program_create()
+        if not self.h:
+            raise MemoryError("ud_program_create")
+        self.keep = []          # keep tensors referenced by raw pointers alive
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib.ud_program_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def __len__(self):
+        return lib.ud_program_size(self.h)
+
+    def _k(self, kw):
+        self.keep.extend(v for v in kw.values() if isinstance(v, torch.Tensor))
+
+    def gemm(self, **kw):
+        self._k(kw); return check(lib.ud_program_add_gemm(self.h, C.byref(mk(UdGemm, **kw))))
+
+    def layernorm(self, **kw):
+        self._k(kw); return check(lib.ud_program_add_layernorm(self.h, C.byref(mk(UdLayerNorm, **kw))))
+
+    def attention(self, **kw):
+        self._k(kw); return check(lib.ud_program_add_attention(self.h, C.byref(mk(UdAttention, **kw))))
+
+    def preprocess(self, **kw):
+        self._k(kw); return check(lib.ud_program_add_preprocess(self.h, C.byref(mk(UdPreprocess, **kw))))
+
+    def fill_rows(self, dst, src, n_img, rows_per_img, row_off, D, ld):
+        self.keep += [dst, src]
+        return check(lib.ud_program_add_fill_rows(self.h, ptr(dst), ptr(src), n_img, rows_per_img, row_off, D, ld))
+
+    def camera_intrinsics(self, raw, raw_stride, intr4, K33, Kinv33, Kpost33, B, Hn, Wn, rf, pad_l, pad_t):
+        self.keep += [raw, intr4, K33, Kinv33, Kpost33]
+        return check(lib.ud_program_add_camera_intrinsics(self.h, ptr(raw), raw_stride, ptr(intr4), ptr(K33), ptr(Kinv33),
+                                                          ptr(Kpost33), B, Hn, Wn, rf, pad_l, pad_t))
+
+    def rays(self, Kinv33, rays, nb, Hn, Wn, gt_mode):
+        self.keep += [Kinv33, rays]
+        return check(lib.ud_program_add_rays(self.h, ptr(Kinv33), ptr(rays), nb, Hn, Wn, gt_mode))
+
+    def ray_embed(self, **kw):
+        self._k(kw); return check(lib.ud_program_add_ray_embed(self.h, C.byref(mk(UdRayEmbed, **kw))))
+
+    def upsample2x(self, **kw):
+        self._k(kw); return check(lib.ud_program_add_upsample2x(self.h, C.byref(mk(UdUpsample2x, **kw))))
+
+    def resize_ac(self, **kw):
+        self._k(kw); return check(lib.ud_program_add_resize_ac(self.h, C.byref(mk(UdResizeAC, **kw))))
+
+    def finalize(self, **kw):
+        self._k(kw); return check(lib.ud_program_add_finalize(self.h, C.byref(mk(UdFinalize, **kw))))
+
+    def nhwc_to_nchw(self, src, dst, B, hw, Cc, ld, rows_per_img):
+        self.keep += [src, dst]
+        return check(lib.ud_program_add_nhwc_to_nchw(self.h, ptr(src), ptr(dst), B, hw, Cc, ld, rows_per_img))
+
+    def run(self, first=0, last=None, stream=None):
+        last = len(self) if last is None else last
+        check(lib.ud_program_run(self.h, first, last, cur_stream() if stream is None else stream), "ud_program_run")
