@@ -1,0 +1,456 @@
+"""UniDepthV2 on MI355X: same Python surface as the reference model wrapper
+(unidepth/models/unidepthv2/unidepthv2.py:111-467), all device arithmetic in libunidepth_hip.so.
+
+    model = UniDepthV2.from_pretrained(dir_or_repo).to("cuda").eval()
+    model.resolution_level = 9            # optional, as in the reference (unidepthv2.py:252-260)
+    out = model.infer(rgb, camera=None, normalize=True)
+    # -> dict(confidence, intrinsics, radius, depth, points, rays, depth_features)   (unidepthv2.py:311-339)
+
+How a call runs: the shape policy (pure integer/float host logic, unidepthv2.py:36-77) picks the network
+resolution; a *launch program* for (batch, input shape, camera batch) is recorded once -- ~260 kernel descriptors
+over a fixed set of device buffers -- and replayed by one C call (ops.Program / csrc/program.cpp); only the output
+assembly kernel is issued per call because it writes into fresh caller-owned tensors.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+import warnings
+from typing import Optional
+
+import torch
+
+from . import ops
+from .ops import (UD_A_CONV3_REFLECT, UD_A_CONV3_ZERO, UD_ACT_GELU, UD_ACT_LRELU, UD_ACT_NONE, UD_EPI_D2S, UD_EPI_F16,
+                  UD_EPI_F32, UD_EPI_HEAD, UD_EPI_QKV)
+from .weights import arch_of, pack
+
+IMAGENET_DATASET_MEAN = (0.485, 0.456, 0.406)      # unidepth/utils/constants.py:12
+IMAGENET_DATASET_STD = (0.229, 0.224, 0.225)       # unidepth/utils/constants.py:13
+
+
+# ------------------------------------------------------------------------------------------ shape policy (host)
+def get_paddings(original_shape, aspect_ratio_range):
+    """Aspect-ratio padding policy; mirrors unidepthv2.py:36-58 (returns (l, r, t, b), (H, W))."""
+    H, W = original_shape
+    ratio = W / H
+    lo, hi = aspect_ratio_range
+    target = min(hi, max(lo, ratio))
+    if ratio > target:                     # too wide -> pad rows
+        Hn = int(W / target)
+        top = (Hn - H) // 2
+        return (0, 0, top, Hn - H - top), (Hn, W)
+    Wn = int(H * target)                   # too tall -> pad columns
+    left = (Wn - W) // 2
+    return (left, Wn - W - left, 0, 0), (H, Wn)
+
+
+def get_resize_factor(original_shape, pixels_range, shape_multiplier=14):
+    """Area clamp + round up to the patch multiple; mirrors unidepthv2.py:61-77."""
+    H, W = original_shape
+    n = H * W
+    lo, hi = pixels_range
+    rf = (min(hi, max(lo, n)) / n) ** 0.5
+    new_w, new_h = int(W * rf), int(H * rf)
+    return rf, (math.ceil(new_h / shape_multiplier) * shape_multiplier, math.ceil(new_w / shape_multiplier) * shape_multiplier)
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+class _Plan:
+    """Device buffers + recorded launch program for one (batch, image shape, camera batch, dtype) signature."""
+
+    def __init__(self, model: "UniDepthV2", B, H, W, cam_nb, is_u8, normalize, pixels_bounds):
+        w, a, dev = model._w, model._arch, model.device
+        meta = w["meta"]
+        D, C, heads, Hd = a["D"], a["C"], a["heads"], a["dec_heads"]
+        sc = model.shape_constraints
+        self.B, self.H, self.W = B, H, W
+        self.paddings, (self.Hp, self.Wp) = get_paddings((H, W), sc["ratio_bounds"])
+        pl, pr, pt, pb = self.paddings
+        self.rf, (Hn, Wn) = get_resize_factor((self.Hp, self.Wp), pixels_bounds)
+        self.Hn, self.Wn = Hn, Wn
+        h, wg = Hn // 14, Wn // 14
+        self.h, self.w = h, wg
+        hw = h * wg
+        N = hw + 1
+        Np = _rup(N, 8)               # token rows per image (encoder stream)
+        hwp = _rup(hw, 8)             # token rows per image (decoder streams)
+        Nkp = _rup(N, 64)
+        hwkp = _rup(hw, 64)
+        self.cam_nb = cam_nb
+        nb = cam_nb if cam_nb else B  # batch of the ray tensors (a single GT camera broadcasts: decoder.py:400)
+        f16, f32 = torch.float16, torch.float32
+
+        def z(*shape, dtype=f16):
+            return torch.zeros(*shape, dtype=dtype, device=dev)
+
+        P = ops.Program()
+        self.prog = P
+        zeros = z(256)
+        # ---------------- inputs
+        self.rgb = torch.zeros(B, 3, H, W, dtype=torch.uint8 if is_u8 else f32, device=dev)
+        patches = z(B * hw, 640)
+        P.preprocess(rgb=self.rgb, patches=patches, B=B, H=H, W=W, pad_l=pl, pad_t=pt, Hp=self.Hp, Wp=self.Wp, Hn=Hn, Wn=Wn,
+                     ldp=640, is_u8=int(is_u8), normalize=int(normalize), mean=IMAGENET_DATASET_MEAN,
+                     inv_std=tuple(1.0 / s for s in IMAGENET_DATASET_STD))
+        # ---------------- encoder (dinov2.py:306-347; block.py:84-109; attention.py:51-62; mlp.py:35-41)
+        pos = model._pos_embed(h, wg).to(dev)                                # [N, D] fp32 (bicubic-resampled per grid)
+        cls_row = (w["host.cls_token"] + pos[0].cpu()).to(dev)
+        x = z(B * Np, D, dtype=f32)
+        M = B * Np
+        P.gemm(A=patches, W=w["patch.w"], bias=w["patch.b"], out=x, add=pos, M=B * hw, N=D, K=640, lda=640, ldw=640, ldc=D,
+               ldadd=D, epi=UD_EPI_F32, rows_in=hw, rows_out=Np, row_off=1, add_row_off=1)
+        P.fill_rows(x, cls_row, B, Np, 0, D, D)
+        xn = z(M, D)
+        qk = z(M, 2 * D)
+        vt = z(B, heads, 64, Nkp)
+        ao = z(M, D)
+        hid = z(M, 4 * D)
+        featn = [z(B * hwp, D) for _ in range(4)]
+        clsn = [z(_rup(B, 8), D) for _ in range(4)]
+        self.enc_first = len(P)
+        lvl = 0
+        for i in range(a["depth"]):
+            P.layernorm(x=x, y=xn, rows=M, D=D, ldx=D, ldy=D, eps=1e-6, rows_per_img=M, in_rows_per_img=M, out_rows_per_img=M)
+            P.gemm(A=xn, W=w[f"enc.{i}.qkv.w"], bias=w[f"enc.{i}.qkv.b"], out=qk, out2=vt, M=M, N=3 * D, K=D, lda=D, ldw=D,
+                   ldc=2 * D, epi=UD_EPI_QKV, vsplit=2 * D, tok_per_img=Np, kv_ld=Nkp, heads_v=heads)
+            P.attention(Q=qk, K=qk.data_ptr() + D * 2, Vt=vt, O=ao, B=B, H=heads, Nq=N, Nk=N, ldq=2 * D, ldk=2 * D, ldo=D,
+                        kv_ld=Nkp, q_rows_per_img=Np, k_rows_per_img=Np, scale=(D // heads) ** -0.5)
+            P.gemm(A=ao, W=w[f"enc.{i}.proj.w"], bias=w[f"enc.{i}.proj.b"], out=x, M=M, N=D, K=D, lda=D, ldw=D, ldc=D,
+                   epi=UD_EPI_F32, accumulate=1)
+            P.layernorm(x=x, y=xn, rows=M, D=D, ldx=D, ldy=D, eps=1e-6, rows_per_img=M, in_rows_per_img=M, out_rows_per_img=M)
+            P.gemm(A=xn, W=w[f"enc.{i}.fc1.w"], bias=w[f"enc.{i}.fc1.b"], out=hid, M=M, N=4 * D, K=D, lda=D, ldw=D, ldc=4 * D,
+                   epi=UD_EPI_F16, act=UD_ACT_GELU)
+            P.gemm(A=hid, W=w[f"enc.{i}.fc2.w"], bias=w[f"enc.{i}.fc2.b"], out=x, M=M, N=D, K=4 * D, lda=4 * D, ldw=4 * D, ldc=D,
+                   epi=UD_EPI_F32, accumulate=1)
+            if (i + 1) in a["output_idx"]:
+                # final LayerNorm (eps 1e-5, dinov2.py:254) only on the 4 consumed outputs; patch rows and cls row separately
+                P.layernorm(x=x, y=featn[lvl], rows=B * hw, D=D, ldx=D, ldy=D, eps=1e-5, rows_per_img=hw, in_rows_per_img=Np,
+                            in_row_off=1, out_rows_per_img=hwp, out_row_off=0)
+                P.layernorm(x=x, y=clsn[lvl], rows=B, D=D, ldx=D, ldy=D, eps=1e-5, rows_per_img=1, in_rows_per_img=Np, in_row_off=0,
+                            out_rows_per_img=1, out_row_off=0)
+                lvl += 1
+        self.enc_last = len(P)
+        self.x, self.featn, self.clsn = x, featn, clsn
+
+        # ---------------- decoder: adapters (decoder.py:418,434-435)
+        Md = B * hwp
+        feat = [z(Md, C, dtype=f32) for _ in range(4)]
+        ct = z(B * 4, C, dtype=f32)
+        for j in range(4):
+            P.gemm(A=featn[j], W=w[f"dec.adapter.{j}.w"], bias=w[f"dec.adapter.{j}.b"], out=feat[j], M=Md, N=C, K=D, lda=D, ldw=D,
+                   ldc=C, epi=UD_EPI_F32)
+            P.gemm(A=clsn[j], W=w[f"dec.camadapter.{j}.w"], bias=w[f"dec.camadapter.{j}.b"], out=ct.data_ptr() + j * C * 4, M=B, N=C,
+                   K=D, lda=D, ldw=D, ldc=4 * C, epi=UD_EPI_F32)
+        # ---------------- camera head (decoder.py:48-114) on the 4 camera tokens per image
+        Mc = B * 4
+        Mcp = _rup(Mc, 8)
+        cn = z(Mcp, C); ch = z(Mcp, 4 * C); cq = z(Mcp, Hd * 64); ck = z(Mcp, Hd * 64); cvt = z(B, Hd, 64, 64); cao = z(Mcp, Hd * 64)
+        t = z(Mcp, C, dtype=f32)
+        raw = z(Mcp, 4, dtype=f32)
+        scale_d = meta["hd"] ** -0.5
+
+        def ln(src, dst, rows, dim=C):
+            P.layernorm(x=src, y=dst, rows=rows, D=dim, ldx=dim, ldy=dim, eps=1e-5, rows_per_img=rows, in_rows_per_img=rows,
+                        out_rows_per_img=rows)
+
+        def mlp(pre, stream, rows, nrm, hidbuf, out=None, accumulate=1, out2=None, act2=UD_ACT_NONE, n_out=C, ldc=C):
+            ln(stream, nrm, rows)
+            nh = w[pre + "fc1.w"].shape[0]
+            P.gemm(A=nrm, W=w[pre + "fc1.w"], bias=w[pre + "fc1.b"], out=hidbuf, M=rows, N=nh, K=C, lda=C, ldw=C, ldc=nh,
+                   epi=UD_EPI_F16, act=UD_ACT_GELU)
+            kw = dict(out2=out2, ldc2=C, act2=act2) if out2 is not None else {}
+            P.gemm(A=hidbuf, W=w[pre + "fc2.w"], bias=w[pre + "fc2.b"], out=stream if out is None else out, M=rows, N=n_out, K=nh,
+                   lda=nh, ldw=nh, ldc=ldc, epi=UD_EPI_F32, accumulate=accumulate, **kw)
+
+        mlp("cam.project.", ct, Mc, cn, ch, out=t, accumulate=0)
+        for blk in ("cam.agg1.", "cam.agg2."):
+            ln(t, cn, Mc)                                                     # norm_attnx and norm_attnctx share statistics
+            P.gemm(A=cn, W=w[blk + "q.w"], bias=w[blk + "q.b"], out=cq, add=w["cam.pos"], M=Mc, N=Hd * 64, K=C, lda=C, ldw=C,
+                   ldc=Hd * 64, ldadd=Hd * 64, epi=UD_EPI_F16, rows_in=4, rows_out=4)
+            P.gemm(A=cn, W=w[blk + "kv.w"], bias=w[blk + "kv.b"], out=ck, out2=cvt, M=Mc, N=2 * Hd * 64, K=C, lda=C, ldw=C,
+                   ldc=Hd * 64, epi=UD_EPI_QKV, vsplit=Hd * 64, tok_per_img=4, kv_ld=64, heads_v=Hd)
+            P.attention(Q=cq, K=ck, Vt=cvt, O=cao, B=B, H=Hd, Nq=4, Nk=4, ldq=Hd * 64, ldk=Hd * 64, ldo=Hd * 64, kv_ld=64,
+                        q_rows_per_img=4, k_rows_per_img=4, scale=scale_d)
+            P.gemm(A=cao, W=w[blk + "out.w"], out=t, M=Mc, N=C, K=Hd * 64, lda=Hd * 64, ldw=Hd * 64, ldc=C, epi=UD_EPI_F32, accumulate=1)
+            mlp(blk, t, Mc, cn, ch)
+        mlp("cam.out.", t, Mc, cn, ch, out=raw, accumulate=0, n_out=4, ldc=4)
+        self.intr4 = z(B, 4, dtype=f32); self.K33 = z(B, 9, dtype=f32); kinv = z(B, 9, dtype=f32); self.Kpost = z(B, 9, dtype=f32)
+        P.camera_intrinsics(raw, 4, self.intr4, self.K33, kinv, self.Kpost, B, Hn, Wn, float(self.rf), pl, pt)
+        # ---------------- rays (decoder.py:361-403 / GT camera: unidepthv2.py:299-303,361-362)
+        self.rays = z(nb, 3, Hn, Wn, dtype=f32)
+        if cam_nb:
+            self.kinv_gt = z(nb, 9, dtype=f32)
+            P.rays(self.kinv_gt, self.rays, nb, Hn, Wn, 1)
+        else:
+            P.rays(kinv, self.rays, nb, Hn, Wn, 0)
+        # ---------------- ray embedding + 4 camera-prompt cross-attention blocks (decoder.py:234-260)
+        nbands = C // 2
+        scales = (2.0 ** torch.linspace(0.0, math.log2(max(h, wg) // 2), steps=nbands)).to(dev)
+        emb = z(nb * hwp, C)
+        P.ray_embed(rays=self.rays, scales=scales, xhat=emb, nb=nb, Hn=Hn, Wn=Wn, h=h, w=wg, C=C, ldy=C, rows_per_img=hwp, eps=1e-5)
+        fn = z(Md, C); qd = z(Md, Hd * 64); kd = z(nb * hwp, Hd * 64); vtd = z(nb, Hd, 64, hwkp); aod = z(Md, Hd * 64); hidd = z(Md, 4 * C)
+        c16 = [z(Md, C) for _ in range(4)]
+        for j in range(4):
+            pre = f"dh.{j}."
+            ln(feat[j], fn, Md)
+            P.gemm(A=fn, W=w[pre + "q.w"], bias=w[pre + "q.b"], out=qd, M=Md, N=Hd * 64, K=C, lda=C, ldw=C, ldc=Hd * 64, epi=UD_EPI_F16)
+            P.gemm(A=emb, W=w[pre + "kv.w"], bias=w[pre + "kv.b"], out=kd, out2=vtd, M=nb * hwp, N=2 * Hd * 64, K=C, lda=C, ldw=C,
+                   ldc=Hd * 64, epi=UD_EPI_QKV, vsplit=Hd * 64, tok_per_img=hwp, kv_ld=hwkp, heads_v=Hd)
+            P.attention(Q=qd, K=kd, Vt=vtd, O=aod, B=B, H=Hd, Nq=hw, Nk=hw, ldq=Hd * 64, ldk=Hd * 64, ldo=Hd * 64, kv_ld=hwkp,
+                        q_rows_per_img=hwp, k_rows_per_img=hwp, scale=scale_d, kv_broadcast=int(nb == 1 and B > 1))
+            P.gemm(A=aod, W=w[pre + "out.w"], out=feat[j], M=Md, N=C, K=Hd * 64, lda=Hd * 64, ldw=Hd * 64, ldc=C, epi=UD_EPI_F32, accumulate=1)
+            mlp(pre, feat[j], Md, fn, hidd, out2=c16[j])
+        # ---------------- latents + 3 x (ConvT inject, 2 RCU, 1x1 + x2 up) (decoder.py:262-282; upsample.py:137-223)
+        lat = z(Md, C, dtype=f32)
+        P.gemm(A=c16[0], W=w["dh.to_latents.w"], bias=w["dh.to_latents.b"], out=lat, M=Md, N=C, K=C, lda=C, ldw=C, ldc=C, epi=UD_EPI_F32)
+        self.depth_features = z(B, C, h, wg, dtype=f32)
+        P.nhwc_to_nchw(lat, self.depth_features, B, hw, C, C, hwp)
+        gh, gw, rows_img = h, wg, hwp
+        xh = None
+        for i in range(3):
+            cur, outd = meta["chans"][i]
+            k = max(1, 2 * i)
+            Ms = B * rows_img
+            l16 = z(Ms, cur); t16 = z(Ms, cur)
+            P.gemm(A=c16[i + 1], W=w[f"dh.convt.{i}.w"], bias=w[f"dh.convt.{i}.b"], out=lat, out2=l16, M=Md, N=k * k * cur, K=C, lda=C,
+                   ldw=C, ldc=cur, ldc2=cur, epi=UD_EPI_D2S, act2=UD_ACT_LRELU, d2s_k=k, d2s_Co=cur, d2s_Hin=h, d2s_Win=wg,
+                   d2s_rows_in_img=hwp, d2s_out_img_pix=rows_img)
+            kp = w[f"dh.ups.{i}.0.conv1.w"].shape[1]
+            conv = dict(zeros=zeros, M=Ms, N=cur, K=kp, ldw=kp, amode=UD_A_CONV3_ZERO, Himg=gh, Wimg=gw, Cin=cur, cstride=cur, coff=0,
+                        rows_img=rows_img, img_stride=rows_img * cur)
+            for c in range(2):
+                P.gemm(A=l16, W=w[f"dh.ups.{i}.{c}.conv1.w"], bias=w[f"dh.ups.{i}.{c}.conv1.b"], out=t16, ldc=cur, epi=UD_EPI_F16,
+                       act=UD_ACT_LRELU, **conv)
+                P.gemm(A=t16, W=w[f"dh.ups.{i}.{c}.conv2.w"], bias=w[f"dh.ups.{i}.{c}.conv2.b"], out=lat, out2=l16, ldc=cur, ldc2=cur,
+                       epi=UD_EPI_F32, accumulate=1, act2=UD_ACT_LRELU if c == 0 else UD_ACT_NONE, **conv)
+            u = z(Ms, outd, dtype=f32)
+            P.gemm(A=l16, W=w[f"dh.ups.{i}.up.w"], bias=w[f"dh.ups.{i}.up.b"], out=u, M=Ms, N=outd, K=_rup(cur, 64), lda=cur,
+                   ldw=_rup(cur, 64), ldc=outd, epi=UD_EPI_F32)
+            if i < 2:
+                nlat = z(B * 4 * gh * gw, outd, dtype=f32)
+                P.upsample2x(in_=u, out=nlat, B=B, H=gh, W=gw, C=outd, ldin=outd, ldy=outd, mode=0, in_img_rows=rows_img)
+                lat = nlat
+            else:
+                ldx = _rup(outd, 64)
+                xh = z(B * 4 * gh * gw, ldx)
+                P.upsample2x(in_=u, out=xh, B=B, H=gh, W=gw, C=outd, ldin=outd, ldy=ldx, mode=1, eps=1e-5, in_img_rows=rows_img)
+            gh, gw = 2 * gh, 2 * gw
+            rows_img = gh * gw
+        # ---------------- heads (decoder.py:284-318): LN+Linear (both branches), 3x3 reflect, AC resize, 3x3 reflect + 1x1 + exp
+        nd, od = meta["nd"], meta["od"]
+        Mh = B * gh * gw
+        ldx = _rup(nd, 64)
+        dm = z(Mh, 2 * od)
+        P.gemm(A=xh, W=w["dh.mlp.w"], bias=w["dh.mlp.b"], out=dm, M=Mh, N=2 * od, K=ldx, lda=ldx, ldw=ldx, ldc=2 * od, epi=UD_EPI_F16)
+        o2 = od // 2
+        lr = z(2, Mh, o2)
+        kp = w["dh.lr.w"].shape[2]
+        P.gemm(A=dm, W=w["dh.lr.w"], bias=w["dh.lr.b"], out=lr, zeros=zeros, M=Mh, N=o2, K=kp, ldw=kp, ldc=o2, amode=UD_A_CONV3_REFLECT,
+               epi=UD_EPI_F16, Himg=gh, Wimg=gw, Cin=od, cstride=2 * od, coff=0, rows_img=gh * gw, img_stride=gh * gw * 2 * od,
+               groups=2, gA=od, gW=o2 * kp, gBias=o2, gOut=Mh * o2)
+        hr = z(2, B * Hn * Wn, o2)
+        P.resize_ac(in_=lr, out=hr, G=2, B=B, Hin=gh, Win=gw, Hout=Hn, Wout=Wn, C=o2)
+        self.net = z(2, B, Hn, Wn, dtype=f32)              # [0] radius, [1] confidence at network resolution
+        kp = w["dh.hr.w"].shape[2]
+        b2 = w["dh.hr.b2"]
+        P.gemm(A=hr, W=w["dh.hr.w"], bias=w["dh.hr.b1"], w2=w["dh.hr.w2"], out=self.net, zeros=zeros, M=B * Hn * Wn, N=32, K=kp, ldw=kp,
+               amode=UD_A_CONV3_REFLECT, epi=UD_EPI_HEAD, Himg=Hn, Wimg=Wn, Cin=o2, cstride=o2, coff=0, rows_img=Hn * Wn,
+               img_stride=Hn * Wn * o2, b2=b2[0], post_add=2.0, b2_g1=b2[1], post_add_g1=0.0, groups=2, gA=B * Hn * Wn * o2,
+               gW=32 * kp, gBias=32, gOut=B * Hn * Wn, gW2=32)
+        self.nb = nb
+        self.Ho, self.Wo = self.Hp - pt - pb, self.Wp - pl - pr
+        self.graph = None
+
+    def finalize(self, out: dict):
+        import ctypes as C
+        pl, _, pt, _ = self.paddings
+        d = ops.mk(ops.UdFinalize, radius_net=self.net[0], conf_net=self.net[1], rays_net=self.rays, confidence=out["confidence"],
+                   radius=out["radius"], depth=out["depth"], points=out["points"], rays=out["rays"], B=self.B, nb_rays=self.nb,
+                   Hn=self.Hn, Wn=self.Wn, Hp=self.Hp, Wp=self.Wp, pad_l=pl, pad_t=pt, Ho=self.Ho, Wo=self.Wo)
+        ops.check(ops.lib.ud_finalize_outputs(C.byref(d), ops.cur_stream()), "ud_finalize_outputs")
+
+
+class UniDepthV2:
+    """Drop-in for the reference class (unidepthv2.py:111): from_pretrained / to / eval / infer, attributes
+    `resolution_level`, `interpolation_mode`, `shape_constraints`, `device`."""
+
+    def __init__(self, config: dict, eps: float = 1e-6, **kwargs):
+        self.config = config
+        self._arch = arch_of(config)
+        self.shape_constraints = config["data"]["augmentations"]["shape_constraints"]   # unidepthv2.py:459
+        self.interpolation_mode = "bilinear"                                            # unidepthv2.py:460
+        self._sd = None
+        self._w = None
+        self._device = torch.device("cpu")
+        self._plans: dict = {}
+        self._pos_cache: dict = {}
+        self.use_graph = False
+        self.training = False
+
+    # ---- checkpoint I/O (HF mixin layout: config.json + model.safetensors / pytorch_model.bin) ----
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, **kwargs):
+        path = str(pretrained_model_name_or_path)
+        if not os.path.isdir(path):
+            from huggingface_hub import snapshot_download     # e.g. "lpiccinelli/unidepth-v2-vitl14" (needs network / cache)
+            path = snapshot_download(path, allow_patterns=["config.json", "model.safetensors", "pytorch_model.bin"])
+        with open(os.path.join(path, "config.json")) as f:
+            config = json.load(f)
+        model = cls(config)
+        st = os.path.join(path, "model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        else:
+            sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu", weights_only=True)
+        model.load_state_dict(sd)
+        return model
+
+    def save_pretrained(self, path: str):
+        from safetensors.torch import save_file
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump(self.config, f)
+        save_file({k: v.contiguous() for k, v in self._sd.items()}, os.path.join(path, "model.safetensors"))
+
+    def load_state_dict(self, state_dict: dict, strict: bool = False):
+        if "model" in state_dict and not torch.is_tensor(state_dict["model"]):
+            state_dict = state_dict["model"]                                            # unidepthv2.py:386-388
+        self._sd = {k.replace("module.", ""): v.detach().float().cpu() for k, v in state_dict.items()}
+        self._w = None
+        self._plans.clear()
+        return self
+
+    def state_dict(self):
+        return dict(self._sd)
+
+    def load_pretrained(self, model_file):
+        return self.load_state_dict(torch.load(model_file, map_location="cpu", weights_only=False))
+
+    # ---- nn.Module-like plumbing ----
+    @property
+    def device(self):
+        return self._device
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if device != self._device:
+            self._device = device
+            self._w = None
+            self._plans.clear()
+        return self
+
+    def cuda(self):
+        return self.to("cuda")
+
+    def eval(self):
+        return self
+
+    def _ensure_packed(self):
+        if self._device.type != "cuda":
+            raise RuntimeError("UniDepthV2 (MI355X engine) runs on a ROCm GPU only: call .to('cuda') first; there is no CPU path")
+        if self._sd is None:
+            raise RuntimeError("no weights loaded (use from_pretrained or load_state_dict)")
+        if self._w is None:
+            with torch.cuda.device(self._device):
+                self._w = pack(self.config, self._sd, self._device)
+
+    def _pos_embed(self, h, w):
+        """Absolute position embedding for an (h, w) patch grid; bicubic resample of the 37x37 table in fp32 when the grid
+        differs (dinov2.py:267-304; computed once per grid on the host, it is a constant of the weights)."""
+        key = (h, w)
+        if key not in self._pos_cache:
+            pe = self._w["host.pos_embed"]
+            n = pe.shape[1] - 1
+            m = int(math.sqrt(n))
+            if h * w == n and h == w:
+                out = pe[0]
+            else:
+                grid = pe[:, 1:].reshape(1, m, m, -1).permute(0, 3, 1, 2)
+                grid = torch.nn.functional.interpolate(grid, size=(h, w), mode="bicubic", antialias=False)
+                out = torch.cat([pe[0, :1], grid.permute(0, 2, 3, 1).reshape(h * w, -1)], 0)
+            self._pos_cache[key] = out.contiguous()
+        return self._pos_cache[key]
+
+    def _pixels_bounds(self):
+        lo, hi = self.shape_constraints["pixels_min"], self.shape_constraints["pixels_max"]
+        if hasattr(self, "resolution_level"):
+            assert 0 <= self.resolution_level < 10, "resolution_level should be in [0, 10)"
+            step = (hi - lo) / 10
+            return (self.resolution_level * step + lo, (self.resolution_level + 1) * step + lo)
+        warnings.warn("!! self.resolution_level not set, using default bounds !!")
+        return (lo, hi)
+
+    def _plan(self, B, H, W, cam_nb, is_u8, normalize) -> _Plan:
+        bounds = self._pixels_bounds()
+        key = (B, H, W, cam_nb, is_u8, normalize, bounds)
+        plan = self._plans.get(key)
+        if plan is None:
+            with torch.cuda.device(self._device):
+                plan = _Plan(self, B, H, W, cam_nb, is_u8, normalize, bounds)
+            self._plans[key] = plan
+        return plan
+
+    # ---- the hot path ----
+    @torch.no_grad()
+    def infer(self, rgb: torch.Tensor, camera=None, normalize: bool = True):
+        """Same contract as the reference infer() (unidepthv2.py:239-339)."""
+        if self.interpolation_mode != "bilinear":
+            raise NotImplementedError("only interpolation_mode='bilinear' (the reference default) is implemented")
+        self._ensure_packed()
+        if rgb.ndim == 3:
+            rgb = rgb.unsqueeze(0)
+        B, _, H, W = rgb.shape
+        Kc = None
+        if camera is not None:
+            Kc = camera if isinstance(camera, torch.Tensor) else getattr(camera, "K", None)
+            if Kc is None:
+                raise NotImplementedError("only pinhole cameras given as [...,3,3] K tensors (or objects with .K) are implemented")
+            assert Kc.shape[-1] == 3 and Kc.shape[-2] == 3, "camera tensor should be of shape (..., 3, 3): assume pinhole"
+            Kc = Kc.detach().reshape(-1, 3, 3).float().cpu()
+        is_u8 = rgb.dtype == torch.uint8
+        with torch.cuda.device(self._device):
+            plan = self._plan(B, H, W, 0 if Kc is None else Kc.shape[0], is_u8, bool(normalize))
+            plan.rgb.copy_(rgb if is_u8 else rgb.float(), non_blocking=True)
+            if Kc is not None:
+                pl, _, pt, _ = plan.paddings
+                Kn = Kc.clone()                                    # camera.crop(-pad) then .resize(rf): utils/camera.py:78-81,115-120
+                Kn[:, 0, 2] += pl
+                Kn[:, 1, 2] += pt
+                Kn[:, :2, :] *= plan.rf
+                plan.kinv_gt.copy_(torch.inverse(Kn).reshape(-1, 9))
+            plan.prog.run()
+            dev, f32 = self._device, torch.float32
+            out = {
+                "confidence": torch.empty(B, 1, plan.Ho, plan.Wo, dtype=f32, device=dev),
+                "radius": torch.empty(B, 1, plan.Ho, plan.Wo, dtype=f32, device=dev),
+                "depth": torch.empty(B, 1, plan.Ho, plan.Wo, dtype=f32, device=dev),
+                "points": torch.empty(B, 3, plan.Ho, plan.Wo, dtype=f32, device=dev),
+                "rays": torch.empty(plan.nb, 3, plan.Ho, plan.Wo, dtype=f32, device=dev),
+            }
+            plan.finalize(out)
+            out["intrinsics"] = plan.Kpost.view(B, 3, 3).clone()
+            out["depth_features"] = plan.depth_features.clone()
+        return {k: out[k] for k in ("confidence", "intrinsics", "radius", "depth", "points", "rays", "depth_features")}
+
+    __call__ = infer
+
+    # ---- module seams for A/B bisection against the oracle ----
+    @torch.no_grad()
+    def debug_taps(self, plan: Optional[_Plan] = None):
+        """Tensors of the last infer() in reference layout: final-normed features/cls tokens, network-res maps."""
+        plan = plan or next(reversed(self._plans.values()))
+        hw = plan.h * plan.w
+        hwp = _rup(hw, 8)
+        D = self._arch["D"]
+        feats = [f.view(plan.B, hwp, D)[:, :hw].float().view(plan.B, plan.h, plan.w, D) for f in plan.featn]
+        cls = [c[: plan.B].float().view(plan.B, 1, D) for c in plan.clsn]
+        return dict(features=feats, tokens=cls, radius_net=plan.net[0], confidence_net=plan.net[1], rays_net=plan.rays,
+                    intrinsics_net=plan.K33.view(-1, 3, 3), intr4=plan.intr4)

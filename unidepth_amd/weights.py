@@ -1,0 +1,180 @@
+"""Load-time weight repacking for the HIP engine (reference state_dict -> fp16 GEMM operands).
+
+Input: the reference's state_dict layout (unidepthv2.py:418-460, decoder.py:468-524).
+Everything here is exact algebra done once in fp32 on the host, then rounded to fp16:
+  * LayerNorm affines are folded into the consuming Linear:  W' = W diag(gamma),  b' = b + W beta
+    (so the device LayerNorm kernel only normalises and its output can be shared by several consumers);
+  * LayerScale / RCU gammas are folded into the producing Linear/Conv:  W' = diag(g) W,  b' = g * b;
+  * decoder attention heads (C/8 wide: 32/48/64) are zero-padded to 64 so one attention kernel serves all;
+  * 3x3 conv filters become [Cout, (tap, cin)] rows, ConvTranspose2d(k=s) filters [(a, c, cout), cin] rows;
+  * K is zero-padded to a multiple of 64 (MFMA K-tile).
+"""
+from __future__ import annotations
+
+import torch
+
+ARCH = {  # backbones/dinov2.py:388-427, encoder.py:139-193
+    "dinov2_vits14": (384, 12, 6, [3, 6, 9, 12]),
+    "dinov2_vitb14": (768, 12, 12, [3, 6, 9, 12]),
+    "dinov2_vitl14": (1024, 24, 16, [5, 12, 18, 24]),
+}
+
+
+def arch_of(config: dict) -> dict:
+    enc = config["model"]["pixel_encoder"]
+    if enc["name"] not in ARCH:
+        raise NotImplementedError(f"pixel_encoder {enc['name']!r}: only the DINOv2 ViT-S/B/L backbones of UniDepthV2 are implemented")
+    D, depth, heads, out_idx = ARCH[enc["name"]]
+    dec = config["model"]["pixel_decoder"]
+    if dec.get("kernel_size", 7) != 3 or list(dec["depths"]) != [2, 2, 2]:
+        raise NotImplementedError("pixel_decoder: only kernel_size=3, depths=[2,2,2] (all released V2 configs) is implemented")
+    return dict(D=D, depth=depth, heads=heads, output_idx=list(enc.get("output_idx", out_idx)), C=dec["hidden_dim"],
+                dec_heads=config["model"]["num_heads"], expansion=config["model"]["expansion"], out_dim=dec["out_dim"])
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+def _padk(w: torch.Tensor) -> torch.Tensor:
+    n, k = w.shape
+    kp = _rup(k, 64)
+    if kp == k:
+        return w
+    out = w.new_zeros(n, kp)
+    out[:, :k] = w
+    return out
+
+
+def _fold_ln(w, b, gamma, beta):
+    b0 = b if b is not None else w.new_zeros(w.shape[0])
+    return w * gamma[None, :], b0 + w @ beta
+
+
+def _pad_head_rows(w, heads, hd):           # [heads*hd, K] -> [heads*64, K]
+    out = w.new_zeros(heads, 64, w.shape[1])
+    out[:, :hd] = w.view(heads, hd, -1)
+    return out.reshape(heads * 64, -1)
+
+
+def _pad_head_vec(v, heads, hd):
+    out = v.new_zeros(heads, 64)
+    out[:, :hd] = v.view(heads, hd)
+    return out.reshape(-1)
+
+
+def _pad_head_cols(w, heads, hd):           # [N, heads*hd] -> [N, heads*64]
+    out = w.new_zeros(w.shape[0], heads, 64)
+    out[:, :, :hd] = w.view(w.shape[0], heads, hd)
+    return out.reshape(w.shape[0], heads * 64)
+
+
+def _conv3_rows(w):                          # [Cout, Cin, 3, 3] -> [Cout, 9*Cin], k = (ky*3 + kx)*Cin + ci
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+
+
+def pack(config: dict, sd: dict, device) -> dict:
+    a = arch_of(config)
+    D, C, H = a["D"], a["C"], a["dec_heads"]
+    hd = C // H
+    f = {k: v.detach().to(torch.float32).cpu() for k, v in sd.items()}
+    out: dict = {}
+
+    def put16(name, w):
+        out[name] = _padk(w).to(torch.float16).contiguous().to(device)
+
+    def put32(name, v):
+        out[name] = v.to(torch.float32).contiguous().to(device)
+
+    pe = "pixel_encoder."
+    put16("patch.w", f[pe + "patch_embed.proj.weight"].reshape(D, -1))
+    put32("patch.b", f[pe + "patch_embed.proj.bias"])
+    for i in range(a["depth"]):
+        b = f"{pe}blocks.{i}."
+        w, bb = _fold_ln(f[b + "attn.qkv.weight"], f[b + "attn.qkv.bias"], f[b + "norm1.weight"], f[b + "norm1.bias"])
+        put16(f"enc.{i}.qkv.w", w); put32(f"enc.{i}.qkv.b", bb)
+        g1 = f[b + "ls1.gamma"]
+        put16(f"enc.{i}.proj.w", f[b + "attn.proj.weight"] * g1[:, None]); put32(f"enc.{i}.proj.b", f[b + "attn.proj.bias"] * g1)
+        w, bb = _fold_ln(f[b + "mlp.fc1.weight"], f[b + "mlp.fc1.bias"], f[b + "norm2.weight"], f[b + "norm2.bias"])
+        put16(f"enc.{i}.fc1.w", w); put32(f"enc.{i}.fc1.b", bb)
+        g2 = f[b + "ls2.gamma"]
+        put16(f"enc.{i}.fc2.w", f[b + "mlp.fc2.weight"] * g2[:, None]); put32(f"enc.{i}.fc2.b", f[b + "mlp.fc2.bias"] * g2)
+    gn, bn = f[pe + "norm.weight"], f[pe + "norm.bias"]
+
+    pd = "pixel_decoder."
+    for j in range(4):
+        for src, dst in (("input_adapter", "adapter"), ("camera_token_adapter", "camadapter")):
+            w, bb = _fold_ln(f[f"{pd}{src}.input_adapters.{j}.weight"], f[f"{pd}{src}.input_adapters.{j}.bias"], gn, bn)
+            put16(f"dec.{dst}.{j}.w", w); put32(f"dec.{dst}.{j}.b", bb)
+
+    def mlp(src, dst, ls=None, pad_out_to=None):
+        w, bb = _fold_ln(f[src + "proj1.weight"], f[src + "proj1.bias"], f[src + "norm.weight"], f[src + "norm.bias"])
+        put16(dst + "fc1.w", w); put32(dst + "fc1.b", bb)
+        w2, b2 = f[src + "proj2.weight"], f[src + "proj2.bias"]
+        if ls is not None:
+            w2, b2 = w2 * ls[:, None], b2 * ls
+        if pad_out_to is not None and w2.shape[0] < pad_out_to:
+            wz = w2.new_zeros(pad_out_to, w2.shape[1]); wz[: w2.shape[0]] = w2
+            bz = b2.new_zeros(pad_out_to); bz[: b2.shape[0]] = b2
+            w2, b2 = wz, bz
+        put16(dst + "fc2.w", w2); put32(dst + "fc2.b", b2)
+
+    def attn_block(src, dst, layer_scale):
+        wq, bq = _fold_ln(f[src + "q.weight"], None, f[src + "norm_attnx.weight"], f[src + "norm_attnx.bias"])
+        put16(dst + "q.w", _pad_head_rows(wq, H, hd)); put32(dst + "q.b", _pad_head_vec(bq, H, hd))
+        wkv, bkv = _fold_ln(f[src + "kv.weight"], None, f[src + "norm_attnctx.weight"], f[src + "norm_attnctx.bias"])
+        wk, wv, bk, bv = wkv[:C], wkv[C:], bkv[:C], bkv[C:]                     # rows [K | V], heads-major (attention.py:119-121)
+        put16(dst + "kv.w", torch.cat([_pad_head_rows(wk, H, hd), _pad_head_rows(wv, H, hd)], 0))
+        put32(dst + "kv.b", torch.cat([_pad_head_vec(bk, H, hd), _pad_head_vec(bv, H, hd)], 0))
+        wo = _pad_head_cols(f[src + "out.weight"], H, hd)
+        ls1 = f[src + "ls1.gamma"] if layer_scale else None
+        if ls1 is not None:
+            wo = wo * ls1[:, None]
+        put16(dst + "out.w", wo)
+        mlp(src + "mlp.", dst, ls=f[src + "ls2.gamma"] if layer_scale else None)
+
+    cl = pd + "camera_layer."
+    mlp(cl + "project.", "cam.project.")
+    attn_block(cl + "aggregate1.", "cam.agg1.", True)
+    attn_block(cl + "aggregate2.", "cam.agg2.", True)
+    mlp(cl + "out_pinhole.", "cam.out.", pad_out_to=4)
+    put32("cam.pos", _pad_head_cols(f[cl + "latents_pos"].reshape(4, C), H, hd))
+
+    dl = pd + "depth_layer."
+    for j in range(4):
+        attn_block(f"{dl}prompt_camera.{j}.layers.0.", f"dh.{j}.", False)
+    put16("dh.to_latents.w", f[dl + "to_latents.weight"]); put32("dh.to_latents.b", f[dl + "to_latents.bias"])
+    chans = []
+    for i in range(3):
+        cur = min(C, 2 * C // 2 ** i)
+        nxt = 2 * C // 2 ** (i + 1)
+        outd = max(nxt, a["out_dim"])
+        chans.append((cur, outd))
+        k = max(1, 2 * i)
+        wt = f[f"{dl}process_features.{i}.weight"]                                # [Cin, Cout, k, k]
+        put16(f"dh.convt.{i}.w", wt.permute(2, 3, 1, 0).reshape(k * k * cur, C)) # n = (a*k + c)*Cout + o
+        put32(f"dh.convt.{i}.b", f[f"{dl}process_features.{i}.bias"])
+        for c in range(2):
+            p = f"{dl}ups.{i}.convs.{c}."
+            g = f[p + "gamma"].reshape(-1)
+            put16(f"dh.ups.{i}.{c}.conv1.w", _conv3_rows(f[p + "conv1.weight"])); put32(f"dh.ups.{i}.{c}.conv1.b", f[p + "conv1.bias"])
+            put16(f"dh.ups.{i}.{c}.conv2.w", _conv3_rows(f[p + "conv2.weight"]) * g[:, None]); put32(f"dh.ups.{i}.{c}.conv2.b", f[p + "conv2.bias"] * g)
+        put16(f"dh.ups.{i}.up.w", f[f"{dl}ups.{i}.up.0.weight"].reshape(outd, cur)); put32(f"dh.ups.{i}.up.b", f[f"{dl}ups.{i}.up.0.bias"])
+    nd = 2 * C // 8            # channels of the x8 feature map
+    od = max(nd, a["out_dim"])
+    wd, bd = _fold_ln(f[f"{dl}depth_mlp.2.1.weight"], f[f"{dl}depth_mlp.2.1.bias"], f[f"{dl}depth_mlp.2.0.weight"], f[f"{dl}depth_mlp.2.0.bias"])
+    wc, bc = _fold_ln(f[dl + "confidence_mlp.1.weight"], f[dl + "confidence_mlp.1.bias"], f[dl + "confidence_mlp.0.weight"], f[dl + "confidence_mlp.0.bias"])
+    put16("dh.mlp.w", torch.cat([wd, wc], 0)); put32("dh.mlp.b", torch.cat([bd, bc], 0))
+    lr_w = torch.stack([_padk(_conv3_rows(f[f"{dl}to_{br}_lr.weight"])) for br in ("depth", "confidence")], 0)
+    out["dh.lr.w"] = lr_w.to(torch.float16).contiguous().to(device)
+    put32("dh.lr.b", torch.stack([f[f"{dl}to_{br}_lr.bias"] for br in ("depth", "confidence")], 0))
+    hr_w = torch.stack([_padk(_conv3_rows(f[f"{dl}to_{br}_hr.0.weight"])) for br in ("depth", "confidence")], 0)
+    out["dh.hr.w"] = hr_w.to(torch.float16).contiguous().to(device)
+    put32("dh.hr.b1", torch.stack([f[f"{dl}to_{br}_hr.0.bias"] for br in ("depth", "confidence")], 0))
+    put32("dh.hr.w2", torch.stack([f[f"{dl}to_{br}_hr.2.weight"].reshape(32) for br in ("depth", "confidence")], 0))
+    out["dh.hr.b2"] = [float(f[f"{dl}to_{br}_hr.2.bias"].reshape(())) for br in ("depth", "confidence")]
+    out["meta"] = dict(chans=chans, nd=nd, od=od, hd=hd)
+    # host copies needed per input shape
+    out["host.pos_embed"] = f[pe + "pos_embed"]
+    out["host.cls_token"] = f[pe + "cls_token"].reshape(-1)
+    return out
