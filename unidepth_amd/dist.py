@@ -1,0 +1,59 @@
+"""Batch data-parallel infer() across the GPUs of one node: one process per GPU, images are independent (no
+cross-sample op anywhere on the path), weights replicated, ONE exchange step -- an all-gather of the requested outputs
+over RCCL/xGMI (`backend="nccl"` is RCCL on ROCm).  The reference has no distributed inference path; its own helper for
+variable-length gathers (unidepth/utils/distributed.py:153-176: size all-gather -> pad -> gather -> trim) is the pattern
+followed for uneven shards."""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_images: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous split, ceil(n/world) per rank, trailing ranks may be short or empty."""
+    per = -(-n_images // world)
+    return [(min(r * per, n_images), min((r + 1) * per, n_images)) for r in range(world)]
+
+
+def all_gather_batch(t: torch.Tensor, counts: List[int], group=None) -> torch.Tensor:
+    """All-gather tensors whose dim 0 differs per rank (counts[r] rows on rank r): pad to max, one all_gather_into_tensor,
+    trim.  Works on any backend (RCCL on GPUs, gloo on CPU for the tests)."""
+    world = dist.get_world_size(group)
+    mx = max(counts)
+    pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[: t.shape[0]] = t
+    buf = torch.empty((world * mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(buf, pad, group=group)
+    if all(c == mx for c in counts):
+        return buf
+    return torch.cat([buf[r * mx: r * mx + counts[r]] for r in range(world)], dim=0)
+
+
+def infer_data_parallel(model, rgb: torch.Tensor, camera=None, keys: Optional[Iterable[str]] = ("depth", "confidence", "intrinsics"),
+                        group=None, **kw) -> Dict[str, torch.Tensor]:
+    """Every rank passes the SAME global batch `rgb` [B,3,H,W] (any device); rank r runs infer() on its contiguous shard and
+    all ranks return the gathered global outputs for `keys` (None = all seven).  A single camera broadcasts; a per-image
+    camera batch is sharded like the images."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    B = rgb.shape[0]
+    bounds = shard_bounds(B, world)
+    lo, hi = bounds[rank]
+    counts = [b - a for a, b in bounds]
+    cam = camera
+    if isinstance(camera, torch.Tensor) and camera.ndim == 3 and camera.shape[0] == B and B > 1:
+        cam = camera[lo:hi]
+    if hi > lo:
+        out = model.infer(rgb[lo:hi], cam, **kw)
+    else:                                  # empty shard: run one image to learn shapes, contribute zero rows
+        out = {k: v[:0] for k, v in model.infer(rgb[:1], camera if cam is camera else camera[:1], **kw).items()}
+    keys = list(out.keys()) if keys is None else list(keys)
+    res = {}
+    for k in keys:
+        t = out[k]
+        if k == "rays" and t.shape[0] == 1 and B > 1 and counts[rank] != 1:
+            res[k] = t                     # single GT camera: identical on every rank, nothing to exchange
+            continue
+        res[k] = all_gather_batch(t.contiguous(), counts, group)
+    return res

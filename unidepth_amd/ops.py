@@ -58,6 +58,7 @@ class Program:
         if not self.h:
             raise MemoryError("ud_program_create")
         self.keep = []          # keep tensors referenced by raw pointers alive
+        self.meta = []          # per op: (kernel class, tag, algorithmic flops, algorithmic bytes) for bench / profiling
 
     def __del__(self):
         try:
@@ -70,48 +71,59 @@ class Program:
     def __len__(self):
         return lib.ud_program_size(self.h)
 
-    def _k(self, kw):
+    def _k(self, kw, cls="misc", flops=0.0, nbytes=0.0):
         self.keep.extend(v for v in kw.values() if isinstance(v, torch.Tensor))
+        self.meta.append((cls, kw.pop("tag", cls), float(kw.pop("flops", flops)), float(nbytes)))
 
     def gemm(self, **kw):
-        self._k(kw); return check(lib.ud_program_add_gemm(self.h, C.byref(mk(UdGemm, **kw))))
+        g = max(1, kw.get("groups", 0))
+        n = kw["N"]
+        cls = "gemm%s_bn%d" % ({0: "", 1: "_conv", 2: "_conv"}[kw.get("amode", 0)], 128 if n > 64 else (64 if n > 32 else 32))
+        self._k(kw, cls, 2.0 * kw["M"] * n * kw["K"] * g)
+        return check(lib.ud_program_add_gemm(self.h, C.byref(mk(UdGemm, **kw))))
 
     def layernorm(self, **kw):
-        self._k(kw); return check(lib.ud_program_add_layernorm(self.h, C.byref(mk(UdLayerNorm, **kw))))
+        self._k(kw, "layernorm", 0.0, 6.0 * kw["rows"] * kw["D"])
+        return check(lib.ud_program_add_layernorm(self.h, C.byref(mk(UdLayerNorm, **kw))))
 
     def attention(self, **kw):
-        self._k(kw); return check(lib.ud_program_add_attention(self.h, C.byref(mk(UdAttention, **kw))))
+        self._k(kw, "attention", 4.0 * kw["B"] * kw["H"] * kw["Nq"] * kw["Nk"] * 64)
+        return check(lib.ud_program_add_attention(self.h, C.byref(mk(UdAttention, **kw))))
 
     def preprocess(self, **kw):
-        self._k(kw); return check(lib.ud_program_add_preprocess(self.h, C.byref(mk(UdPreprocess, **kw))))
+        self._k(kw, "preprocess"); return check(lib.ud_program_add_preprocess(self.h, C.byref(mk(UdPreprocess, **kw))))
 
     def fill_rows(self, dst, src, n_img, rows_per_img, row_off, D, ld):
         self.keep += [dst, src]
+        self.meta.append(("misc", "fill_rows", 0.0, 0.0))
         return check(lib.ud_program_add_fill_rows(self.h, ptr(dst), ptr(src), n_img, rows_per_img, row_off, D, ld))
 
     def camera_intrinsics(self, raw, raw_stride, intr4, K33, Kinv33, Kpost33, B, Hn, Wn, rf, pad_l, pad_t):
         self.keep += [raw, intr4, K33, Kinv33, Kpost33]
+        self.meta.append(("misc", "camera_intrinsics", 0.0, 0.0))
         return check(lib.ud_program_add_camera_intrinsics(self.h, ptr(raw), raw_stride, ptr(intr4), ptr(K33), ptr(Kinv33),
                                                           ptr(Kpost33), B, Hn, Wn, rf, pad_l, pad_t))
 
     def rays(self, Kinv33, rays, nb, Hn, Wn, gt_mode):
         self.keep += [Kinv33, rays]
+        self.meta.append(("misc", "rays", 0.0, 12.0 * nb * Hn * Wn))
         return check(lib.ud_program_add_rays(self.h, ptr(Kinv33), ptr(rays), nb, Hn, Wn, gt_mode))
 
     def ray_embed(self, **kw):
-        self._k(kw); return check(lib.ud_program_add_ray_embed(self.h, C.byref(mk(UdRayEmbed, **kw))))
+        self._k(kw, "ray_embed"); return check(lib.ud_program_add_ray_embed(self.h, C.byref(mk(UdRayEmbed, **kw))))
 
     def upsample2x(self, **kw):
-        self._k(kw); return check(lib.ud_program_add_upsample2x(self.h, C.byref(mk(UdUpsample2x, **kw))))
+        self._k(kw, "upsample2x", 0.0, kw["B"] * kw["H"] * kw["W"] * kw["C"] * (4.0 + 4 * (4.0 if kw.get("mode", 0) == 0 else 2.0))); return check(lib.ud_program_add_upsample2x(self.h, C.byref(mk(UdUpsample2x, **kw))))
 
     def resize_ac(self, **kw):
-        self._k(kw); return check(lib.ud_program_add_resize_ac(self.h, C.byref(mk(UdResizeAC, **kw))))
+        self._k(kw, "resize_ac", 0.0, 2.0 * kw["G"] * kw["B"] * kw["C"] * (kw["Hin"] * kw["Win"] + kw["Hout"] * kw["Wout"])); return check(lib.ud_program_add_resize_ac(self.h, C.byref(mk(UdResizeAC, **kw))))
 
     def finalize(self, **kw):
-        self._k(kw); return check(lib.ud_program_add_finalize(self.h, C.byref(mk(UdFinalize, **kw))))
+        self._k(kw, "finalize"); return check(lib.ud_program_add_finalize(self.h, C.byref(mk(UdFinalize, **kw))))
 
     def nhwc_to_nchw(self, src, dst, B, hw, Cc, ld, rows_per_img):
         self.keep += [src, dst]
+        self.meta.append(("misc", "nhwc_to_nchw", 0.0, 8.0 * B * hw * Cc))
         return check(lib.ud_program_add_nhwc_to_nchw(self.h, ptr(src), ptr(dst), B, hw, Cc, ld, rows_per_img))
 
     def run(self, first=0, last=None, stream=None):

@@ -117,16 +117,17 @@ class _Plan:
         for i in range(a["depth"]):
             P.layernorm(x=x, y=xn, rows=M, D=D, ldx=D, ldy=D, eps=1e-6, rows_per_img=M, in_rows_per_img=M, out_rows_per_img=M)
             P.gemm(A=xn, W=w[f"enc.{i}.qkv.w"], bias=w[f"enc.{i}.qkv.b"], out=qk, out2=vt, M=M, N=3 * D, K=D, lda=D, ldw=D,
-                   ldc=2 * D, epi=UD_EPI_QKV, vsplit=2 * D, tok_per_img=Np, kv_ld=Nkp, heads_v=heads)
+                   ldc=2 * D, epi=UD_EPI_QKV, vsplit=2 * D, tok_per_img=Np, kv_ld=Nkp, heads_v=heads, tag="enc.qkv",
+                   flops=2.0 * B * N * 3 * D * D)
             P.attention(Q=qk, K=qk.data_ptr() + D * 2, Vt=vt, O=ao, B=B, H=heads, Nq=N, Nk=N, ldq=2 * D, ldk=2 * D, ldo=D,
-                        kv_ld=Nkp, q_rows_per_img=Np, k_rows_per_img=Np, scale=(D // heads) ** -0.5)
+                        kv_ld=Nkp, q_rows_per_img=Np, k_rows_per_img=Np, scale=(D // heads) ** -0.5, tag="enc.attn")
             P.gemm(A=ao, W=w[f"enc.{i}.proj.w"], bias=w[f"enc.{i}.proj.b"], out=x, M=M, N=D, K=D, lda=D, ldw=D, ldc=D,
-                   epi=UD_EPI_F32, accumulate=1)
+                   epi=UD_EPI_F32, accumulate=1, tag="enc.proj", flops=2.0 * B * N * D * D)
             P.layernorm(x=x, y=xn, rows=M, D=D, ldx=D, ldy=D, eps=1e-6, rows_per_img=M, in_rows_per_img=M, out_rows_per_img=M)
             P.gemm(A=xn, W=w[f"enc.{i}.fc1.w"], bias=w[f"enc.{i}.fc1.b"], out=hid, M=M, N=4 * D, K=D, lda=D, ldw=D, ldc=4 * D,
-                   epi=UD_EPI_F16, act=UD_ACT_GELU)
+                   epi=UD_EPI_F16, act=UD_ACT_GELU, tag="enc.fc1", flops=8.0 * B * N * D * D)
             P.gemm(A=hid, W=w[f"enc.{i}.fc2.w"], bias=w[f"enc.{i}.fc2.b"], out=x, M=M, N=D, K=4 * D, lda=4 * D, ldw=4 * D, ldc=D,
-                   epi=UD_EPI_F32, accumulate=1)
+                   epi=UD_EPI_F32, accumulate=1, tag="enc.fc2", flops=8.0 * B * N * D * D)
             if (i + 1) in a["output_idx"]:
                 # final LayerNorm (eps 1e-5, dinov2.py:254) only on the 4 consumed outputs; patch rows and cls row separately
                 P.layernorm(x=x, y=featn[lvl], rows=B * hw, D=D, ldx=D, ldy=D, eps=1e-5, rows_per_img=hw, in_rows_per_img=Np,
