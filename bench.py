@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--gather", default="depth,confidence,intrinsics")
+    ap.add_argument("--dump-ops", default="", help="write per-launch timings (tsv) to this file")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -123,7 +124,7 @@ def main():
         fl = flops_per_image()
         result["model_tflops_per_s"] = round(value * fl["total"] / 1e12 / world, 2)
         if not args.no_kernel_timing:
-            result.update(kernel_timing(model, fl, B))
+            result.update(kernel_timing(model, fl, B, args.dump_ops))
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, sd, H, W)
         print(json.dumps(result))
@@ -132,7 +133,7 @@ def main():
         dist.destroy_process_group()
 
 
-def kernel_timing(model, fl, B):
+def kernel_timing(model, fl, B, dump=""):
     """Per-launch durations with HIP events on the launch stream (torch's current stream is the one every kernel of the
     program is enqueued on); aggregated per kernel class.  Returns the roofline object for the dominant kernel."""
     plan = next(reversed(model._plans.values()))
@@ -157,6 +158,12 @@ def kernel_timing(model, fl, B):
             if tag.startswith("enc."):
                 e = tot.setdefault(tag, {"ms": 0.0, "flops": 0.0, "launches": 0, "bytes": 0.0})
                 e["ms"] += evs[i].elapsed_time(evs[i + 1]); e["flops"] += flops; e["launches"] += 1
+    if dump:
+        with open(dump, "w") as f:
+            for i in range(n):
+                cls, tag, flops, nbytes = P.meta[i]
+                us = evs[i].elapsed_time(evs[i + 1]) * 1e3
+                f.write(f"{i}\t{cls}\t{tag}\t{us:.1f}\t{flops / us / 1e6 if flops else 0:.1f}\n")
     classes = {k: v for k, v in tot.items() if not k.startswith("enc.")}
     dom = max(classes, key=lambda k: classes[k]["ms"])
     d = classes[dom]

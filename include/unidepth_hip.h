@@ -71,6 +71,7 @@ typedef struct UdGemm {
   int groups;
   long long gA, gW, gBias, gOut, gOut2, gW2;
   float b2_g1, post_add_g1;    /* group 1 constants for UD_EPI_HEAD */
+  int tile_hint;               /* 0 = auto, 1 = force 128x128 tiles, 2 = force 256x256 tiles (dense A only) */
 } UdGemm;
 
 int ud_gemm_f16(const UdGemm* desc, void* stream);
@@ -86,8 +87,26 @@ typedef struct UdLayerNorm {
   int rows, D, ldx, ldy;
   float eps;
   int rows_per_img, in_rows_per_img, in_row_off, out_rows_per_img, out_row_off;
+  int out_f32;            /* 0: y is fp16 (MFMA operand); 1: y is fp32 (the fp32 camera head) */
 } UdLayerNorm;
 int ud_layernorm_f32_f16(const UdLayerNorm* desc, void* stream);
+
+/* ---- fp32 small-M linear layer (camera head only) ---------------------------------------------------------
+ * out[m, n] (+)= act(sum_k x[m,k] W[n,k] + bias[n] + add[m % add_mod, n]),  everything fp32, exact-erf GELU.
+ * The camera head (decoder.py:48-114) maps 4 tokens per image to the pinhole parameters that generate EVERY ray; its
+ * rounding error is amplified by the 2^k*pi ray-angle bands (decoder.py:246-252) into a common-mode depth error, so it is
+ * the one place where fp16 MFMA operands are not accurate enough (measured: K error 1e-3 -> depth ARel 1e-3) and, at
+ * M = 4*B rows, the one place where fp32 costs nothing.  Replaces nn.Linear in CameraHead / camera_token_adapter. */
+typedef struct UdLinearF32 {
+  const float* x; const float* W; const float* bias; const float* add; float* out;
+  int M, N, K, ldx, ldw, ldc, ldadd, add_mod;
+  int act, accumulate;
+} UdLinearF32;
+int ud_linear_f32(const UdLinearF32* desc, void* stream);
+
+/* fp32 attention over T <= 8 tokens per image (camera head, layers/attention.py:81-165 with 4 tokens):
+ * q [B*T, C], kv [B*T, 2C] = [K | V] heads-major, out [B*T, C]; H heads of width C/H. */
+int ud_attention_small_f32(const float* q, const float* kv, float* out, int B, int T, int H, int C, float scale, void* stream);
 
 /* ---- fused multi-head attention forward, head_dim 64 (padded), no mask, fp16 in/out, fp32 softmax ----
  * O = softmax(Q K^T * scale) V per (image, head).  Replaces F.scaled_dot_product_attention at
@@ -187,6 +206,8 @@ int ud_program_size(const UdProgram*);
 int ud_program_add_gemm(UdProgram*, const UdGemm*);
 int ud_program_add_layernorm(UdProgram*, const UdLayerNorm*);
 int ud_program_add_attention(UdProgram*, const UdAttention*);
+int ud_program_add_linear_f32(UdProgram*, const UdLinearF32*);
+int ud_program_add_attention_small_f32(UdProgram*, const float* q, const float* kv, float* out, int B, int T, int H, int C, float scale);
 int ud_program_add_preprocess(UdProgram*, const UdPreprocess*);
 int ud_program_add_fill_rows(UdProgram*, float* dst, const float* src, int n_img, int rows_per_img, int row_off, int D, int ld);
 int ud_program_add_camera_intrinsics(UdProgram*, const float* raw, int raw_stride, float* intr4, float* K33, float* Kinv33, float* Kpost33,

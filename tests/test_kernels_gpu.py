@@ -42,6 +42,58 @@ def test_gemm_f16_dense(ops, M, N, K, act):
     assert rel(out.float(), ref) < 1e-3
 
 
+@pytest.mark.parametrize("M,N,K,hint", [(1100, 512, 128, 2), (2048, 256, 64, 2), (3000, 1152, 384, 2), (2600, 1024, 4096, 2), (1100, 512, 128, 1)])
+def test_gemm_big_tiles_f16_f32(ops, M, N, K, hint):
+    """256x256 / 4-stage kernel (tile_hint=2) against the same fp32 statement; edge tiles in M and N, deep K ring."""
+    A = rnd(M, K, seed=1).half()
+    W = rnd(N, K, scale=K ** -0.5, seed=2).half()
+    bias = rnd(N, seed=3)
+    out = torch.zeros(M, N, dtype=torch.half, device="cuda")
+    ops.gemm(A=A, W=W, bias=bias, out=out, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, epi=ops.UD_EPI_F16, act=ops.UD_ACT_GELU, tile_hint=hint)
+    ref = A.float() @ W.float().t() + bias
+    torch.cuda.synchronize()
+    assert rel(out.float(), F.gelu(ref)) < 1e-3
+    x = rnd(M, N, seed=5)
+    x0 = x.clone()
+    x16 = torch.zeros(M, N, dtype=torch.half, device="cuda")
+    ops.gemm(A=A, W=W, bias=bias, out=x, out2=x16, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, ldc2=N, epi=ops.UD_EPI_F32, accumulate=1, tile_hint=hint)
+    torch.cuda.synchronize()
+    assert rel(x, x0 + ref) < 2e-5
+    assert rel(x16.float(), x0 + ref) < 1e-3
+
+
+def test_gemm_big_tiles_qkv_d2s(ops):
+    B, Npad, D, H = 2, 1376, 256, 4
+    M, N, K = B * Npad, 3 * D, D
+    kv_ld = 1408
+    A = rnd(M, K, seed=1).half()
+    W = rnd(N, K, scale=K ** -0.5, seed=2).half()
+    bias = rnd(N, seed=3)
+    qk = torch.zeros(M, 2 * D, dtype=torch.half, device="cuda")
+    vt = torch.zeros(B, H, 64, kv_ld, dtype=torch.half, device="cuda")
+    ops.gemm(A=A, W=W, bias=bias, out=qk, out2=vt, M=M, N=N, K=K, lda=K, ldw=K, ldc=2 * D, epi=ops.UD_EPI_QKV,
+             vsplit=2 * D, tok_per_img=Npad, kv_ld=kv_ld, heads_v=H, tile_hint=2)
+    ref = A.float() @ W.float().t() + bias
+    torch.cuda.synchronize()
+    assert rel(qk.float(), ref[:, :2 * D]) < 1e-3
+    assert rel(vt[..., :Npad].float(), ref[:, 2 * D:].view(B, Npad, H, 64).permute(0, 2, 3, 1)) < 1e-3
+    # ConvTranspose k=2 through the big kernel
+    k, Hin, Win, Cin, Co = 2, 37, 37, 128, 64
+    rows_in = 1376
+    x = rnd(B, rows_in, Cin, seed=1).half()
+    wt = rnd(Cin, Co, k, k, scale=Cin ** -0.5, seed=2)
+    b2 = rnd(Co, seed=3)
+    Wg = wt.permute(2, 3, 1, 0).reshape(k * k * Co, Cin).contiguous().half()
+    lat = rnd(B, Hin * k * Win * k, Co, seed=4)
+    lat0 = lat.clone()
+    ops.gemm(A=x, W=Wg, bias=b2, out=lat, M=B * rows_in, N=k * k * Co, K=Cin, lda=Cin, ldw=Cin, ldc=Co, epi=ops.UD_EPI_D2S,
+             d2s_k=k, d2s_Co=Co, d2s_Hin=Hin, d2s_Win=Win, d2s_rows_in_img=rows_in, d2s_out_img_pix=Hin * k * Win * k, tile_hint=2)
+    xin = x[:, :Hin * Win].float().view(B, Hin, Win, Cin).permute(0, 3, 1, 2)
+    refd = F.conv_transpose2d(xin, Wg.float().view(k, k, Co, Cin).permute(3, 2, 0, 1), b2, stride=k)
+    torch.cuda.synchronize()
+    assert rel(lat.view(B, Hin * k, Win * k, Co), lat0.view(B, Hin * k, Win * k, Co) + refd.permute(0, 2, 3, 1)) < 2e-4
+
+
 def test_gemm_f32_accumulate_remap_add(ops):
     # patch-embed style: rows_in=hw tokens/img -> rows_out=Npad with offset 1, + pos-embed add, then accumulate pass
     B, hw, Npad, K, N = 3, 50, 56, 128, 256
@@ -338,6 +390,33 @@ def test_resize_ac_and_finalize_and_transpose(ops):
     ops.check(ops.lib.ud_nhwc_to_nchw_f32(xin.data_ptr(), outT.data_ptr(), 2, 37, 70, 72, 40, ops.cur_stream()))
     torch.cuda.synchronize()
     assert torch.equal(outT, xin[:, :37, :70].permute(0, 2, 1))
+
+
+def test_camera_fp32_island(ops):
+    """fp32 linear (small M), 4-token fp32 attention and LayerNorm with fp32 output: agree with torch fp32 to round-off."""
+    import ctypes as C
+    B, T, H, Cc, K = 3, 4, 8, 384, 768
+    M = B * T
+    x = rnd(M, K, seed=1); W = rnd(Cc, K, scale=K ** -0.5, seed=2); bias = rnd(Cc, seed=3); pos = rnd(T, Cc, seed=4)
+    out = rnd(M, Cc, seed=5); out0 = out.clone()
+    d = ops.mk(ops.UdLinearF32, x=x, W=W, bias=bias, add=pos, out=out, M=M, N=Cc, K=K, ldx=K, ldw=K, ldc=Cc, ldadd=Cc, add_mod=T,
+               act=ops.UD_ACT_GELU, accumulate=1)
+    ops.check(ops.lib.ud_linear_f32(C.byref(d), ops.cur_stream()))
+    ref = out0 + F.gelu(x @ W.t() + bias + pos.repeat(B, 1))
+    torch.cuda.synchronize()
+    assert rel(out, ref) < 2e-6
+    q = rnd(M, Cc, seed=6); kv = rnd(M, 2 * Cc, seed=7); o = torch.zeros(M, Cc, device="cuda")
+    ops.check(ops.lib.ud_attention_small_f32(q.data_ptr(), kv.data_ptr(), o.data_ptr(), B, T, H, Cc, 0.2, ops.cur_stream()))
+    hd = Cc // H
+    qh = q.view(B, T, H, hd).transpose(1, 2); kh = kv[:, :Cc].reshape(B, T, H, hd).transpose(1, 2); vh = kv[:, Cc:].reshape(B, T, H, hd).transpose(1, 2)
+    refo = (torch.softmax(qh @ kh.transpose(-1, -2) * 0.2, -1) @ vh).transpose(1, 2).reshape(M, Cc)
+    torch.cuda.synchronize()
+    assert rel(o, refo) < 2e-6
+    y = torch.zeros(M, Cc, device="cuda")
+    xx = rnd(M, Cc, seed=8) * 2 + 0.3
+    ops.layernorm(x=xx, y=y, rows=M, D=Cc, ldx=Cc, ldy=Cc, eps=1e-5, rows_per_img=M, in_rows_per_img=M, out_rows_per_img=M, out_f32=1)
+    torch.cuda.synchronize()
+    assert rel(y, F.layer_norm(xx, (Cc,), eps=1e-5)) < 2e-6
 
 
 def test_program_replay_matches_eager(ops):

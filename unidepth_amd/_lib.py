@@ -30,14 +30,19 @@ class UdGemm(C.Structure):
         ("b2", f32), ("post_add", f32),
         ("groups", i32),
         ("gA", i64), ("gW", i64), ("gBias", i64), ("gOut", i64), ("gOut2", i64), ("gW2", i64),
-        ("b2_g1", f32), ("post_add_g1", f32),
+        ("b2_g1", f32), ("post_add_g1", f32), ("tile_hint", i32),
     ]
 
 
 class UdLayerNorm(C.Structure):
     _fields_ = [("x", fp), ("y", vp), ("rows", i32), ("D", i32), ("ldx", i32), ("ldy", i32), ("eps", f32),
                 ("rows_per_img", i32), ("in_rows_per_img", i32), ("in_row_off", i32), ("out_rows_per_img", i32),
-                ("out_row_off", i32)]
+                ("out_row_off", i32), ("out_f32", i32)]
+
+
+class UdLinearF32(C.Structure):
+    _fields_ = [("x", fp), ("W", fp), ("bias", fp), ("add", fp), ("out", fp), ("M", i32), ("N", i32), ("K", i32), ("ldx", i32),
+                ("ldw", i32), ("ldc", i32), ("ldadd", i32), ("add_mod", i32), ("act", i32), ("accumulate", i32)]
 
 
 class UdAttention(C.Structure):
@@ -84,6 +89,10 @@ def _load():
         "ud_gemm_f16": [P(UdGemm), vp],
         "ud_layernorm_f32_f16": [P(UdLayerNorm), vp],
         "ud_attention_f16": [P(UdAttention), vp],
+        "ud_linear_f32": [P(UdLinearF32), vp],
+        "ud_attention_small_f32": [vp, vp, vp, i32, i32, i32, i32, f32, vp],
+        "ud_program_add_linear_f32": [vp, P(UdLinearF32)],
+        "ud_program_add_attention_small_f32": [vp, vp, vp, vp, i32, i32, i32, i32, f32],
         "ud_preprocess_patches": [P(UdPreprocess), vp],
         "ud_fill_rows_f32": [vp, vp, i32, i32, i32, i32, i32, vp],
         "ud_camera_intrinsics": [vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp],
@@ -119,7 +128,7 @@ def _load():
     lib.ud_program_create.restype = vp
     lib.ud_last_error.argtypes = []
     lib.ud_last_error.restype = C.c_char_p
-    for i, st in enumerate([UdGemm, UdLayerNorm, UdAttention, UdPreprocess, UdRayEmbed, UdUpsample2x, UdResizeAC, UdFinalize]):
+    for i, st in enumerate([UdGemm, UdLayerNorm, UdAttention, UdPreprocess, UdRayEmbed, UdUpsample2x, UdResizeAC, UdFinalize, UdLinearF32]):
         if lib.ud_struct_size(i) != C.sizeof(st):
             raise ImportError(f"ctypes mirror of {st.__name__} is out of sync with include/unidepth_hip.h "
                               f"({C.sizeof(st)} vs {lib.ud_struct_size(i)} bytes)")

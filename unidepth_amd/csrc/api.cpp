@@ -23,6 +23,12 @@ extern "C" int ud_struct_size(int which) {
     case 5: return (int)sizeof(UdUpsample2x);
     case 6: return (int)sizeof(UdResizeAC);
     case 7: return (int)sizeof(UdFinalize);
+    case 8: return (int)sizeof(UdLinearF32);
     default: return -1;
   }
 }
+
+// numerics bisect switches (not part of the product surface; used by tools/ only)
+static int g_debug_flags = 0;
+int ud_debug_flags_host() { return g_debug_flags; }
+extern "C" void ud_set_debug_flags(int f) { g_debug_flags = f; }

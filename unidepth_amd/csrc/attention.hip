@@ -13,19 +13,20 @@
 //     -> the per-row rescale factor alpha is per lane, no shuffles in the main loop.
 // V arrives pre-transposed ([head][d][key], written by the QKV GEMM epilogue), so both LDS tiles are filled with
 // 16-byte row-contiguous loads.  LDS layouts: K [64][64] halves with the 16-byte chunk index XOR-swizzled by
-// (key >> 1) & 7 (conflict-free ds_read_b128); V^T [64 d][64 keys] with rows padded to 136 bytes
-// (conflict-free ds_read_b64 for 32 consecutive d).
+// (key >> 1) & 7 (conflict-free ds_read_b128); V^T [64 d][64 keys] with rows padded to 144 bytes and the 4-key groups of every
+// 16 keys stored as [0-3, 8-11, 4-7, 12-15], so the 8 keys a lane feeds to one MFMA are 16 contiguous bytes
+// (conflict-free ds_read_b128 for 32 consecutive d).
 #include "ud_common.h"
 
 namespace {
 
 constexpr int KT = 64;             // keys per tile
 constexpr int KS_BYTES = 64 * 128;
-constexpr int VS_STRIDE = 136;
+constexpr int VS_STRIDE = 144;      // 9 x 16 B: conflict-free ds_read_b128 for 32 consecutive d rows
 constexpr int VS_BYTES = 64 * VS_STRIDE;
 constexpr int STAGE = KS_BYTES + VS_BYTES;
 
-__global__ __launch_bounds__(256) void attention_kernel(const UdAttention p) {
+__global__ __launch_bounds__(256) void attention_kernel(const UdAttention p, const float defer_thr) {
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -78,9 +79,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const UdAttention p) {
         lo[e] = vreg[i][e];
         hi[e] = vreg[i][4 + e];
       }
-      char* vp = sb + KS_BYTES + row * VS_STRIDE + ch * 16;
+      // chunk ch holds keys 8ch..8ch+7; inside its 16-key group the 8-byte slots are ordered [k0-3, k8-11, k4-7, k12-15]
+      char* vp = sb + KS_BYTES + row * VS_STRIDE + (ch >> 1) * 32 + (ch & 1) * 8;
       *(half4*)vp = lo;
-      *(half4*)(vp + 8) = hi;
+      *(half4*)(vp + 16) = hi;
     }
   };
 
@@ -126,17 +128,25 @@ __global__ __launch_bounds__(256) void attention_kernel(const UdAttention p) {
           if (key >= p.Nk) s[kb][r] = -1.0e30f;
         }
     }
-    // ---- online softmax (lane-local + partner lane ^ 32)
+    // ---- online softmax (lane-local + partner lane ^ 32), max update deferred until it grows by > 2^8 (fp16 P has
+    //      constant relative precision, so P up to 256 costs no accuracy; accumulation is fp32)
     float mt = s[0][0];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[kb][r]);
+      for (int r = 0; r < 16; r += 2) mt = fmaxf(fmaxf(mt, s[kb][r]), s[kb][r + 1]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float m_new = fmaxf(m_i, mt);
-    const float alpha = __builtin_amdgcn_exp2f((m_i - m_new) * c);
-    m_i = m_new;
-    const float mc = m_new * c;
+    if (__any((mt - m_i) * c > defer_thr)) {
+      const float m_new = fmaxf(m_i, mt);
+      const float alpha = __builtin_amdgcn_exp2f((m_i - m_new) * c);
+      m_i = m_new;
+      l_i *= alpha;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    }
+    const float mc = m_i * c;
     float ls = 0.0f;
     half8 pf[2][2];
 #pragma unroll
@@ -144,37 +154,32 @@ __global__ __launch_bounds__(256) void attention_kernel(const UdAttention p) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float pv = __builtin_amdgcn_exp2f(s[kb][t * 8 + e] * c - mc);
-          ls += pv;
-          pf[kb][t][e] = (half_t)pv;
+        for (int e = 0; e < 8; e += 2) {
+          f32x2 pv;
+          pv[0] = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], c, -mc));
+          pv[1] = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e + 1], c, -mc));
+          ls += pv[0] + pv[1];
+          const half2v ph = __builtin_convertvector(pv, half2v);      // v_cvt_pk_f16_f32 (round to nearest even)
+          pf[kb][t][e] = ph[0];
+          pf[kb][t][e + 1] = ph[1];
         }
-    l_i = l_i * alpha + ls;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    l_i += ls;
 
     // ---- O^T += V^T P^T
     const char* vs = sb + KS_BYTES;
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
-      const char* vrow = vs + (db * 32 + ql) * VS_STRIDE + hh * 8;
+      const char* vrow = vs + (db * 32 + ql) * VS_STRIDE + hh * 16;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const half4 lo = *(const half4*)(vrow + (kb * 32 + t * 16) * 2);
-          const half4 hi = *(const half4*)(vrow + (kb * 32 + t * 16 + 8) * 2);
-          half8 vf;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            vf[e] = lo[e];
-            vf[4 + e] = hi[e];
-          }
+          const half8 vf = *(const half8*)(vrow + (kb * 2 + t) * 32);
           o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][t], o[db], 0, 0, 0);
         }
     }
+    __builtin_amdgcn_s_setprio(0);
 
     if (kt + 1 < nt) lstore((kt + 1) & 1);
     __syncthreads();
@@ -208,7 +213,7 @@ extern "C" int ud_attention_f16(const UdAttention* desc, void* stream) {
     return UD_ERR_BAD_ARG;
   }
   dim3 grid((d.Nq + 127) / 128, d.H, d.B);
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, (hipStream_t)stream, d);
+  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, (hipStream_t)stream, d, (ud_debug_flags_host() & 1) ? -1.0f : 8.0f);
   UD_CHECK_LAUNCH("ud_attention_f16 launch");
   return UD_OK;
 }

@@ -6,7 +6,7 @@ OUT=../libunidepth_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result"
 mkdir -p build
 pids=()
-for f in gemm.hip attention.hip layernorm.hip pointwise.hip; do
+for f in gemm.hip attention.hip layernorm.hip pointwise.hip camera_f32.hip; do
   ( hipcc $FLAGS "$@" -c $f -o build/${f%.hip}.o ) &
   pids+=($!)
 done

@@ -34,6 +34,187 @@ struct ConvLane {
   int valid;
 };
 
+// ---------------- epilogue (shared by all tile configurations) ----------------
+// acc[i][j] is the 16x16 MFMA accumulator of m-tile i / n-tile j of this wave's sub-tile whose origin is (mbase, nbase).
+// SWAP (default): lane owns m = mbase + 16i + (lane & 15), n = nbase + 16j + 4*(lane >> 4) + r.
+// !SWAP (V^T tiles): lane owns m = mbase + 16i + 4*(lane >> 4) + r, n = nbase + 16j + (lane & 15).
+template <int TM, int TN, int EPI, bool SWAP>
+__device__ __forceinline__ void gemm_epilogue(const UdGemm& p, f32x4 (&acc)[TM][TN], int mbase, int nbase, int lane, const float* bias,
+                                              char* out, char* out2, const float* w2, float b2, float post_add, char* stage) {
+  if constexpr (!SWAP) {
+    // V^T tiles of UD_EPI_QKV: lane owns tokens mb..mb+3 (one image: tok_per_img % 4 == 0) for column n.
+    static_assert(EPI == UD_EPI_QKV, "non-swapped orientation only for V^T");
+    half_t* vt = (half_t*)out2;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int mb = mbase + i * 16 + 4 * (lane >> 4);
+      if (mb >= p.M) continue;
+      const int img = mb / p.tok_per_img;
+      const int t = mb - img * p.tok_per_img;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = nbase + j * 16 + (lane & 15);
+        if (n >= p.N) continue;
+        const float bv = bias ? bias[n] : 0.0f;
+        const int nv = n - p.vsplit;
+        const int hd = nv >> 6, d = nv & 63;
+        half4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[i][j][r] + bv);
+        *(half4*)(vt + (((size_t)img * p.heads_v + hd) * 64 + d) * p.kv_ld + t) = h;
+      }
+    }
+    return;
+  } else {
+    // ---- fp16 outputs: stage the wave's sub-tile through LDS so that global stores are 16 B per lane and every
+    //      8 lanes write one full 128-byte row segment (direct MFMA-layout stores are 8 B per lane in 32-byte pieces)
+    if constexpr ((EPI == UD_EPI_F16 || EPI == UD_EPI_QKV) && TN == 4 && (TM % 4) == 0) {
+      if (stage != nullptr && (p.N & 7) == 0 && (p.ldc & 7) == 0 && !(p.ldc2 >> 30)) {
+#pragma unroll
+        for (int c = 0; c < TM / 4; ++c) {
+#pragma unroll
+          for (int il = 0; il < 4; ++il) {
+            const int i = c * 4 + il;
+            const int m = mbase + i * 16 + (lane & 15);
+            int arow = m;
+            if (p.rows_in > 0) arow = m - (m / p.rows_in) * p.rows_in + p.add_row_off;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int nb = nbase + j * 16 + 4 * (lane >> 4);
+              f32x4 v = acc[i][j];
+              if (nb < p.N) {
+                if (bias) v += *(const f32x4*)(bias + nb);
+                if (p.add && m < p.M) v += *(const f32x4*)(p.add + (size_t)arow * p.ldadd + nb);
+              }
+              half4 h;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) h[r] = (half_t)ud_act(v[r], p.act);
+              *(half4*)(stage + (il * 16 + (lane & 15)) * 144 + (j * 16 + 4 * (lane >> 4)) * 2) = h;
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int id = it * 64 + lane;
+            const int row = id >> 3, ch = id & 7;
+            const int m = mbase + c * 64 + row;
+            const int n = nbase + ch * 8;
+            if (m < p.M && n < p.N) {
+              int orow = m;
+              if (p.rows_in > 0) {
+                const int img = m / p.rows_in;
+                orow = img * p.rows_out + (m - img * p.rows_in) + p.row_off;
+              }
+              const half8 val = *(const half8*)(stage + row * 144 + ch * 16);
+              *(half8*)((half_t*)out + (size_t)orow * p.ldc + n) = val;
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        return;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = mbase + i * 16 + (lane & 15);
+      const bool mok = m < p.M;
+      // output row remap
+      int orow = m, arow = m;
+      if (p.rows_in > 0) {
+        const int img = m / p.rows_in;
+        const int pr = m - img * p.rows_in;
+        orow = img * p.rows_out + pr + p.row_off;
+        arow = pr + p.add_row_off;
+      }
+      if constexpr (EPI == UD_EPI_HEAD) {
+        float part = 0.0f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int nb = nbase + j * 16 + 4 * (lane >> 4);
+          if (nb < p.N) {
+            const f32x4 bv = *(const f32x4*)(bias + nb);
+            const f32x4 wv2 = *(const f32x4*)(w2 + nb);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part += ud_lrelu(acc[i][j][r] + bv[r]) * wv2[r];
+          }
+        }
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+        if (mok && (lane >> 4) == 0) {
+          float y = part + b2;
+          y = fminf(fmaxf(y, -8.0f), 8.0f);
+          ((float*)out)[orow] = __expf(y + post_add);
+        }
+        continue;
+      }
+      if constexpr (EPI == UD_EPI_D2S) {
+        // m -> (img, y, x) on the input grid
+        const int img = m / p.d2s_rows_in_img;
+        const int pp = m - img * p.d2s_rows_in_img;
+        const int y = pp / p.d2s_Win, x = pp - y * p.d2s_Win;
+        const bool ok = mok && pp < p.d2s_Hin * p.d2s_Win;
+        const int k = p.d2s_k;
+        const int Wout = p.d2s_Win * k;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int nb = nbase + j * 16 + 4 * (lane >> 4);
+          if (!ok || nb >= p.N) continue;
+          const int ac = nb / p.d2s_Co;
+          const int o = nb - ac * p.d2s_Co;
+          const int a = ac / k, c = ac - a * k;
+          const long long pix = (long long)img * p.d2s_out_img_pix + (long long)(y * k + a) * Wout + (x * k + c);
+          float* dst = (float*)out + pix * p.ldc + o;
+          f32x4 v = *(f32x4*)dst;
+          const f32x4 bv = *(const f32x4*)(bias + o);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += acc[i][j][r] + bv[r];
+          *(f32x4*)dst = v;
+          if (out2) {
+            half4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = (half_t)ud_act(v[r], p.act2);
+            *(half4*)((half_t*)out2 + pix * p.ldc2 + o) = h;
+          }
+        }
+        continue;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int nb = nbase + j * 16 + 4 * (lane >> 4);
+        if (!mok || nb >= p.N) continue;
+        f32x4 v = acc[i][j];
+        if (bias) {
+          const f32x4 bv = *(const f32x4*)(bias + nb);
+          v += bv;
+        }
+        if (p.add) {
+          const f32x4 av = *(const f32x4*)(p.add + (size_t)arow * p.ldadd + nb);
+          v += av;
+        }
+        if constexpr (EPI == UD_EPI_F16 || EPI == UD_EPI_QKV) {
+          half4 h;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[r] = (half_t)ud_act(v[r], p.act);
+          *(half4*)((half_t*)out + (size_t)orow * p.ldc + nb) = h;
+        } else if constexpr (EPI == UD_EPI_F32) {
+          float* dst = (float*)out + (size_t)orow * p.ldc + nb;
+          if (p.accumulate) {
+            const f32x4 old = *(const f32x4*)dst;
+            v += old;
+          }
+          *(f32x4*)dst = v;
+          if (out2) {
+            half4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = (half_t)ud_act(v[r], p.act2);
+            *(half4*)((half_t*)out2 + (size_t)orow * p.ldc2 + nb) = h;
+          }
+        }
+      }
+    }
+  }
+}
+
 template <class C, int EPI, int AMODE, bool SWAP>
 __device__ __forceinline__ void gemm_body(const UdGemm& p, char* smem, int m0, int n0, const half_t* A, const half_t* W,
                                           const float* bias, char* out, char* out2, const float* w2, float b2, float post_add) {
@@ -146,132 +327,12 @@ __device__ __forceinline__ void gemm_body(const UdGemm& p, char* smem, int m0, i
         }
     }
   }
-
-  // ---------------- epilogue ----------------
-  if constexpr (!SWAP) {
-    // V^T tiles of UD_EPI_QKV: lane owns tokens mb..mb+3 (one image: tok_per_img % 4 == 0) for column n.
-    static_assert(EPI == UD_EPI_QKV, "non-swapped orientation only for V^T");
-    half_t* vt = (half_t*)out2;
-#pragma unroll
-    for (int i = 0; i < C::TM; ++i) {
-      const int mb = m0 + wm * C::WM + i * 16 + 4 * (lane >> 4);
-      if (mb >= p.M) continue;
-      const int img = mb / p.tok_per_img;
-      const int t = mb - img * p.tok_per_img;
-#pragma unroll
-      for (int j = 0; j < C::TN; ++j) {
-        const int n = n0 + wn * C::WN + j * 16 + (lane & 15);
-        if (n >= p.N) continue;
-        const float bv = bias ? bias[n] : 0.0f;
-        const int nv = n - p.vsplit;
-        const int hd = nv >> 6, d = nv & 63;
-        half4 h;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[i][j][r] + bv);
-        *(half4*)(vt + (((size_t)img * p.heads_v + hd) * 64 + d) * p.kv_ld + t) = h;
-      }
-    }
-    return;
-  } else {
-#pragma unroll
-    for (int i = 0; i < C::TM; ++i) {
-      const int m = m0 + wm * C::WM + i * 16 + (lane & 15);
-      const bool mok = m < p.M;
-      // output row remap
-      int orow = m, arow = m;
-      if (p.rows_in > 0) {
-        const int img = m / p.rows_in;
-        const int pr = m - img * p.rows_in;
-        orow = img * p.rows_out + pr + p.row_off;
-        arow = pr + p.add_row_off;
-      }
-      if constexpr (EPI == UD_EPI_HEAD) {
-        float part = 0.0f;
-#pragma unroll
-        for (int j = 0; j < C::TN; ++j) {
-          const int nb = n0 + wn * C::WN + j * 16 + 4 * (lane >> 4);
-          if (nb < p.N) {
-            const f32x4 bv = *(const f32x4*)(bias + nb);
-            const f32x4 wv2 = *(const f32x4*)(w2 + nb);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) part += ud_lrelu(acc[i][j][r] + bv[r]) * wv2[r];
-          }
-        }
-        part += __shfl_xor(part, 16, 64);
-        part += __shfl_xor(part, 32, 64);
-        if (mok && (lane >> 4) == 0) {
-          float y = part + b2;
-          y = fminf(fmaxf(y, -8.0f), 8.0f);
-          ((float*)out)[orow] = __expf(y + post_add);
-        }
-        continue;
-      }
-      if constexpr (EPI == UD_EPI_D2S) {
-        // m -> (img, y, x) on the input grid
-        const int img = m / p.d2s_rows_in_img;
-        const int pp = m - img * p.d2s_rows_in_img;
-        const int y = pp / p.d2s_Win, x = pp - y * p.d2s_Win;
-        const bool ok = mok && pp < p.d2s_Hin * p.d2s_Win;
-        const int k = p.d2s_k;
-        const int Wout = p.d2s_Win * k;
-#pragma unroll
-        for (int j = 0; j < C::TN; ++j) {
-          const int nb = n0 + wn * C::WN + j * 16 + 4 * (lane >> 4);
-          if (!ok || nb >= p.N) continue;
-          const int ac = nb / p.d2s_Co;
-          const int o = nb - ac * p.d2s_Co;
-          const int a = ac / k, c = ac - a * k;
-          const long long pix = (long long)img * p.d2s_out_img_pix + (long long)(y * k + a) * Wout + (x * k + c);
-          float* dst = (float*)out + pix * p.ldc + o;
-          f32x4 v = *(f32x4*)dst;
-          const f32x4 bv = *(const f32x4*)(bias + o);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += acc[i][j][r] + bv[r];
-          *(f32x4*)dst = v;
-          if (out2) {
-            half4 h;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = (half_t)ud_act(v[r], p.act2);
-            *(half4*)((half_t*)out2 + pix * p.ldc2 + o) = h;
-          }
-        }
-        continue;
-      }
-#pragma unroll
-      for (int j = 0; j < C::TN; ++j) {
-        const int nb = n0 + wn * C::WN + j * 16 + 4 * (lane >> 4);
-        if (!mok || nb >= p.N) continue;
-        f32x4 v = acc[i][j];
-        if (bias) {
-          const f32x4 bv = *(const f32x4*)(bias + nb);
-          v += bv;
-        }
-        if (p.add) {
-          const f32x4 av = *(const f32x4*)(p.add + (size_t)arow * p.ldadd + nb);
-          v += av;
-        }
-        if constexpr (EPI == UD_EPI_F16 || EPI == UD_EPI_QKV) {
-          half4 h;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) h[r] = (half_t)ud_act(v[r], p.act);
-          *(half4*)((half_t*)out + (size_t)orow * p.ldc + nb) = h;
-        } else if constexpr (EPI == UD_EPI_F32) {
-          float* dst = (float*)out + (size_t)orow * p.ldc + nb;
-          if (p.accumulate) {
-            const f32x4 old = *(const f32x4*)dst;
-            v += old;
-          }
-          *(f32x4*)dst = v;
-          if (out2) {
-            half4 h;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = (half_t)ud_act(v[r], p.act2);
-            *(half4*)((half_t*)out2 + (size_t)orow * p.ldc2 + nb) = h;
-          }
-        }
-      }
-    }
+  char* stage = nullptr;
+  if constexpr ((EPI == UD_EPI_F16 || EPI == UD_EPI_QKV) && SWAP && C::TN == 4 && C::TM == 4) {
+    __syncthreads();                       // every wave is done reading operand tiles: LDS becomes the store staging area
+    stage = smem + wv * 9216;
   }
+  gemm_epilogue<C::TM, C::TN, EPI, SWAP>(p, acc, m0 + wm * C::WM, n0 + wn * C::WN, lane, bias, out, out2, w2, b2, post_add, stage);
 }
 
 template <class C, int EPI, int AMODE>
@@ -307,6 +368,188 @@ __global__ __launch_bounds__(256) void gemm_kernel(const UdGemm p) {
   gemm_body<C, EPI, AMODE, true>(p, smem, m0, n0, A, W, bias, out, out2, w2, b2, post_add);
 }
 
+// ================================================================================================================
+// Large-tile kernel: 256 x 256 output tile, 8 waves (2 along m x 4 along n, 128 x 64 per wave), K-tile = 64,
+// 2-stage LDS ring of 64 KB tiles (A [256][64] + B [256][64] halves, 128 KB, one workgroup per CU).
+//  * full 128-byte rows per DMA lane group (a 64-byte-row variant re-fetched every L2 line twice and was L2-bound);
+//  * the whole next K-tile is issued (8 x global_load_lds_dwordx4 per thread) at the top of the current one, i.e. three
+//    of the four 16-MFMA phases ahead of its first use; one vmcnt(0) + raw s_barrier per K-tile (64 MFMAs per wave);
+//  * the K-tile is walked as 2 k-steps x 2 m-halves; fragment reads run one phase ahead of their MFMAs in registers
+//    (A m-half sets alternate, B k-step sets alternate) -- 0.375 ds_read_b128 per MFMA;
+//  * same source-side XOR swizzle as the 128x128 kernel (chunk ^= (row >> 1) & 7): conflict-free ds_read_b128.
+// ================================================================================================================
+constexpr int BIG_STAGE = 65536;
+
+template <int EPI, bool SWAP>
+__device__ __forceinline__ void gemm256_body(const UdGemm& p, char* smem, int m0, int n0, const half_t* A, const half_t* W,
+                                             const float* bias, char* out, char* out2) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv >> 2, wn = wv & 3;
+  const int nk = p.K >> 6;
+
+  // loader: operand tile = 2048 chunks of 16 B; thread owns chunks tid + 512*i -> rows (tid >> 3) + 64*i, i = 0..3
+  const int lrow = tid >> 3;
+  const int csrc = (tid & 7) ^ ((lrow >> 1) & 7);
+  const half_t* pa[4];
+  const half_t* pb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + lrow + 64 * i;
+    m = m < p.M ? m : p.M - 1;
+    pa[i] = A + (size_t)m * p.lda + csrc * 8;
+    int n = n0 + lrow + 64 * i;
+    n = n < p.N ? n : p.N - 1;
+    pb[i] = W + (size_t)n * p.ldw + csrc * 8;
+  }
+  auto issue = [&](int kt) {
+    char* sb = smem + (kt & 1) * BIG_STAGE + wv * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ud_glds16(pa[i] + kt * 64, sb + i * 8192);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ud_glds16(pb[i] + kt * 64, sb + 32768 + i * 8192);
+  };
+
+  // fragment read offsets inside a stage: row-major [row][64 halves], chunk index swizzled by (row >> 1) & 7
+  const int frow = lane & 15;
+  const int fq = lane >> 4;
+  const int fswz = frow >> 1;
+  const int c0 = ((fq) ^ fswz) << 4;          // k-step 0
+  const int c1 = ((4 + fq) ^ fswz) << 4;      // k-step 1
+  const int a_off = (wm * 128 + frow) * 128;
+  const int b_off = 32768 + (wn * 64 + frow) * 128;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#define UD_MFMA16(ROW0, AF, BF)                                                                                  \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) {                \
+    if constexpr (SWAP) acc[ROW0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[j], AF[i], acc[ROW0 + i][j], 0, 0, 0); \
+    else acc[ROW0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AF[i], BF[j], acc[ROW0 + i][j], 0, 0, 0);   \
+  }
+
+  half8 a0[4], a1[4], b0[4], b1[4];
+  issue(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int t = 0; t < 4; ++t) a0[t] = *(const half8*)(smem + a_off + t * 2048 + c0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b0[j] = *(const half8*)(smem + b_off + j * 2048 + c0);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* sb = smem + (kt & 1) * BIG_STAGE;
+    const char* sbn = smem + ((kt + 1) & 1) * BIG_STAGE;
+    // ---- phase (k0, m-half 0): DMA of the whole next K-tile goes out first
+    if (kt + 1 < nk) issue(kt + 1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a1[t] = *(const half8*)(sb + a_off + (4 + t) * 2048 + c0);
+    __builtin_amdgcn_sched_barrier(0);     // keep the fragment prefetch ahead of the MFMAs (hipcc would sink it to first use)
+    UD_MFMA16(0, a0, b0)
+    // ---- phase (k0, m-half 1)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a0[t] = *(const half8*)(sb + a_off + t * 2048 + c1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b1[j] = *(const half8*)(sb + b_off + j * 2048 + c1);
+    __builtin_amdgcn_sched_barrier(0);
+    UD_MFMA16(4, a1, b0)
+    // ---- phase (k1, m-half 0)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a1[t] = *(const half8*)(sb + a_off + (4 + t) * 2048 + c1);
+    __builtin_amdgcn_sched_barrier(0);
+    UD_MFMA16(0, a0, b1)
+    // ---- phase (k1, m-half 1): next K-tile must have landed for every wave before anyone reads it
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a0[t] = *(const half8*)(sbn + a_off + t * 2048 + c0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b0[j] = *(const half8*)(sbn + b_off + j * 2048 + c0);
+    __builtin_amdgcn_sched_barrier(0);
+    UD_MFMA16(4, a1, b1)
+  }
+#undef UD_MFMA16
+  char* stage = nullptr;
+  if constexpr ((EPI == UD_EPI_F16 || EPI == UD_EPI_QKV) && SWAP) {
+    __syncthreads();
+    stage = smem + wv * 9216;
+  }
+  gemm_epilogue<8, 4, EPI, SWAP>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, bias, out, out2, nullptr, 0.f, 0.f, stage);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tiles_n = (p.N + 255) >> 8;
+  const int tiles_m = (p.M + 255) >> 8;
+  const int nblk = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {  // XCD-aware: contiguous range of the tile list per XCD
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  // group-M swizzle: walk 8 row-tiles x all column tiles at a time so concurrently running tiles share A and W panels in L2
+  constexpr int GM = 8;
+  const int gsz = GM * tiles_n;
+  const int grp = bid / gsz;
+  const int first_m = grp * GM;
+  const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+  const int rem = bid - grp * gsz;
+  const int tile_m = first_m + rem % gm;
+  const int tile_n = rem / gm;
+  const int m0 = tile_m << 8, n0 = tile_n << 8;
+  const half_t* A = (const half_t*)p.A;
+  const half_t* W = (const half_t*)p.W;
+  if constexpr (EPI == UD_EPI_QKV) {
+    if (n0 >= p.vsplit) {
+      gemm256_body<EPI, false>(p, smem, m0, n0, A, W, p.bias, (char*)p.out, (char*)p.out2);
+      return;
+    }
+  }
+  gemm256_body<EPI, true>(p, smem, m0, n0, A, W, p.bias, (char*)p.out, (char*)p.out2);
+}
+
+template <int EPI>
+int launch256(const UdGemm& d, hipStream_t s) {
+  const int tiles = ((d.N + 255) >> 8) * ((d.M + 255) >> 8);
+  const int lds = 2 * BIG_STAGE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      ud_set_error("ud_gemm_f16: cannot reserve 128 KB of LDS");
+      return UD_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(tiles), dim3(512), lds, s, d);
+  UD_CHECK_LAUNCH("ud_gemm_f16 (256x256) launch");
+  return UD_OK;
+}
+
+// Tile-shape choice for dense GEMMs: the 256x256 kernel has ~2x the per-CU rate of the 128x128 one but runs one
+// workgroup per CU, so it loses to wave quantisation when the tile count is small or just above a multiple of 256 CUs.
+inline bool use_big_tiles(const UdGemm& d) {
+  if (d.amode != UD_A_DENSE || d.groups > 1 || d.M < 1024 || d.N < 256 || (d.K & 63)) return false;
+  if (d.epi == UD_EPI_QKV && (d.vsplit & 255)) return false;
+  if (d.tile_hint == 1) return false;
+  if (d.tile_hint == 2) return true;
+  // cost model fitted on MI355X (tools/bench_gemm*.py): per-launch fixed cost + rounds x K-loop time per round;
+  // the 128x128 kernel runs two workgroups per CU, so its rounds quantise in halves
+  const double kk = (double)d.K / 1024.0;
+  const double big_tiles = (double)((d.N + 255) / 256) * ((d.M + 255) / 256);
+  const double small_tiles = (double)((d.N + 127) / 128) * ((d.M + 127) / 128);
+  const double t_big = 8.0 + ceil(big_tiles / 256.0) * 30.0 * kk;
+  const double t_small = 6.0 + ceil(small_tiles / 256.0) * 0.5 * 21.5 * kk;
+  return t_big < 0.93 * t_small;
+}
+
 template <class C, int EPI, int AMODE>
 int launch(const UdGemm& d, hipStream_t s) {
   const int tiles_n = (d.N + C::BN - 1) / C::BN;
@@ -333,7 +576,11 @@ int dispatch_bn(const UdGemm& d, hipStream_t s) {
 }  // namespace
 
 extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
-  const UdGemm& d = *desc;
+  UdGemm dcopy = *desc;
+  if ((ud_debug_flags_host() & 2) && dcopy.act == UD_ACT_GELU) dcopy.act = 3;          // bisect: erff GELU
+  if ((ud_debug_flags_host() & 4) && (dcopy.epi == UD_EPI_F16 || dcopy.epi == UD_EPI_QKV)) dcopy.ldc2 |= (1 << 30);
+  if (ud_debug_flags_host() & 8) dcopy.tile_hint = 1;                                  // bisect: 128x128 tiles only                               // bisect: no LDS-staged stores
+  const UdGemm& d = dcopy;
   hipStream_t s = (hipStream_t)stream;
   if (!d.A || !d.W || !d.out || d.M <= 0 || d.N <= 0 || d.K <= 0 || (d.K & 63) || (d.N & 3)) {
     ud_set_error("ud_gemm_f16: bad argument (need K % 64 == 0, N % 4 == 0)");
@@ -348,6 +595,7 @@ extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
       ud_set_error("ud_gemm_f16: bad QKV epilogue geometry");
       return UD_ERR_BAD_ARG;
     }
+    if (use_big_tiles(d)) return launch256<UD_EPI_QKV>(d, s);
     return launch<Cfg<128, 64, 64>, UD_EPI_QKV, UD_A_DENSE>(d, s);
   }
   if (d.epi == UD_EPI_D2S) {
@@ -355,6 +603,7 @@ extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
       ud_set_error("ud_gemm_f16: bad D2S epilogue geometry");
       return UD_ERR_BAD_ARG;
     }
+    if (use_big_tiles(d)) return launch256<UD_EPI_D2S>(d, s);
     return dispatch_bn<UD_EPI_D2S, UD_A_DENSE>(d, s);
   }
   if (d.epi == UD_EPI_HEAD) {
@@ -365,11 +614,13 @@ extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
     return launch<Cfg<32, 32, 32>, UD_EPI_HEAD, UD_A_CONV3_REFLECT>(d, s);
   }
   if (d.epi == UD_EPI_F16) {
+    if (use_big_tiles(d)) return launch256<UD_EPI_F16>(d, s);
     if (d.amode == UD_A_DENSE) return dispatch_bn<UD_EPI_F16, UD_A_DENSE>(d, s);
     if (d.amode == UD_A_CONV3_ZERO) return dispatch_bn<UD_EPI_F16, UD_A_CONV3_ZERO>(d, s);
     return dispatch_bn<UD_EPI_F16, UD_A_CONV3_REFLECT>(d, s);
   }
   if (d.epi == UD_EPI_F32) {
+    if (use_big_tiles(d)) return launch256<UD_EPI_F32>(d, s);
     if (d.amode == UD_A_DENSE) return dispatch_bn<UD_EPI_F32, UD_A_DENSE>(d, s);
     if (d.amode == UD_A_CONV3_ZERO) return dispatch_bn<UD_EPI_F32, UD_A_CONV3_ZERO>(d, s);
   }

@@ -5,7 +5,7 @@
 
 namespace {
 
-template <int NIT>  // D <= NIT * 256
+template <int NIT, bool F32OUT>  // D <= NIT * 256
 __global__ __launch_bounds__(256) void layernorm_kernel(const UdLayerNorm p) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -15,7 +15,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const UdLayerNorm p) {
   const size_t irow = (size_t)img * p.in_rows_per_img + pp + p.in_row_off;
   const size_t orow = (size_t)img * p.out_rows_per_img + pp + p.out_row_off;
   const float* x = p.x + irow * p.ldx;
-  half_t* y = (half_t*)p.y + orow * p.ldy;
+  half_t* y = (half_t*)p.y + (F32OUT ? 0 : orow * p.ldy);
+  float* yf = (float*)p.y + (F32OUT ? orow * p.ldy : 0);
   f32x4 v[NIT];
   float s = 0.0f;
 #pragma unroll
@@ -46,10 +47,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const UdLayerNorm p) {
   for (int it = 0; it < NIT; ++it) {
     const int c = it * 256 + lane * 4;
     if (c < p.D) {
-      half4 h;
+      if constexpr (F32OUT) {
+        f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) h[e] = (half_t)((v[it][e] - mean) * rstd);
-      *(half4*)(y + c) = h;
+        for (int e = 0; e < 4; ++e) o[e] = (v[it][e] - mean) * rstd;
+        *(f32x4*)(yf + c) = o;
+      } else {
+        half4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (half_t)((v[it][e] - mean) * rstd);
+        *(half4*)(y + c) = h;
+      }
     }
   }
 }
@@ -64,10 +72,16 @@ extern "C" int ud_layernorm_f32_f16(const UdLayerNorm* desc, void* stream) {
   }
   dim3 grid((d.rows + 3) / 4);
   hipStream_t s = (hipStream_t)stream;
-  if (d.D <= 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, d);
-  else if (d.D <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, d);
-  else if (d.D <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, s, d);
-  else hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, s, d);
+#define UD_LN_LAUNCH(NIT)                                                                                  \
+  do {                                                                                                    \
+    if (d.out_f32) hipLaunchKernelGGL((layernorm_kernel<NIT, true>), grid, dim3(256), 0, s, d);           \
+    else hipLaunchKernelGGL((layernorm_kernel<NIT, false>), grid, dim3(256), 0, s, d);                    \
+  } while (0)
+  if (d.D <= 256) UD_LN_LAUNCH(1);
+  else if (d.D <= 512) UD_LN_LAUNCH(2);
+  else if (d.D <= 1024) UD_LN_LAUNCH(4);
+  else UD_LN_LAUNCH(8);
+#undef UD_LN_LAUNCH
   UD_CHECK_LAUNCH("ud_layernorm_f32_f16 launch");
   return UD_OK;
 }

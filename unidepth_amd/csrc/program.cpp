@@ -9,16 +9,17 @@
 void ud_set_error(const char* msg);
 
 namespace {
-enum Kind { K_GEMM, K_LN, K_ATTN, K_PRE, K_FILL, K_CAM, K_RAYS, K_EMBED, K_UP2, K_RESIZE, K_FINAL, K_T };
+enum Kind { K_LIN32, K_ATTS, K_GEMM, K_LN, K_ATTN, K_PRE, K_FILL, K_CAM, K_RAYS, K_EMBED, K_UP2, K_RESIZE, K_FINAL, K_T };
 struct FillArgs { float* dst; const float* src; int n_img, rows_per_img, row_off, D, ld; };
 struct CamArgs { const float* raw; int raw_stride; float* intr4; float* K33; float* Kinv33; float* Kpost33; int B, Hn, Wn; float rf; int pad_l, pad_t; };
 struct RaysArgs { const float* Kinv33; float* rays; int nb, Hn, Wn, gt_mode; };
+struct AttSArgs { const float* q; const float* kv; float* out; int B, T, H, C; float scale; };
 struct TArgs { const float* in; float* out; int B, hw, C, ld, rows_per_img; };
 struct Op {
   Kind kind;
   union {
     UdGemm gemm; UdLayerNorm ln; UdAttention attn; UdPreprocess pre; FillArgs fill; CamArgs cam; RaysArgs rays;
-    UdRayEmbed embed; UdUpsample2x up2; UdResizeAC resize; UdFinalize fin; TArgs t;
+    UdRayEmbed embed; UdUpsample2x up2; UdResizeAC resize; UdFinalize fin; TArgs t; UdLinearF32 lin32; AttSArgs atts;
   };
   Op() {}
 };
@@ -39,6 +40,11 @@ int ud_program_add_gemm(UdProgram* p, const UdGemm* d) { ADD(K_GEMM, gemm, *d) }
 int ud_program_add_layernorm(UdProgram* p, const UdLayerNorm* d) { ADD(K_LN, ln, *d) }
 int ud_program_add_attention(UdProgram* p, const UdAttention* d) { ADD(K_ATTN, attn, *d) }
 int ud_program_add_preprocess(UdProgram* p, const UdPreprocess* d) { ADD(K_PRE, pre, *d) }
+int ud_program_add_linear_f32(UdProgram* p, const UdLinearF32* d) { ADD(K_LIN32, lin32, *d) }
+int ud_program_add_attention_small_f32(UdProgram* p, const float* q, const float* kv, float* out, int B, int T, int H, int C, float scale) {
+  AttSArgs a = {q, kv, out, B, T, H, C, scale};
+  ADD(K_ATTS, atts, a)
+}
 int ud_program_add_fill_rows(UdProgram* p, float* dst, const float* src, int n_img, int rows_per_img, int row_off, int D, int ld) {
   FillArgs a = {dst, src, n_img, rows_per_img, row_off, D, ld};
   ADD(K_FILL, fill, a)
@@ -68,6 +74,8 @@ int ud_program_run(const UdProgram* p, int first, int last, void* stream) {
     int rc = UD_OK;
     switch (op.kind) {
       case K_GEMM: rc = ud_gemm_f16(&op.gemm, stream); break;
+      case K_LIN32: rc = ud_linear_f32(&op.lin32, stream); break;
+      case K_ATTS: rc = ud_attention_small_f32(op.atts.q, op.atts.kv, op.atts.out, op.atts.B, op.atts.T, op.atts.H, op.atts.C, op.atts.scale, stream); break;
       case K_LN: rc = ud_layernorm_f32_f16(&op.ln, stream); break;
       case K_ATTN: rc = ud_attention_f16(&op.attn, stream); break;
       case K_PRE: rc = ud_preprocess_patches(&op.pre, stream); break;

@@ -8,6 +8,7 @@ typedef _Float16 half_t;
 typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
 typedef __attribute__((ext_vector_type(4))) _Float16 half4;
 typedef __attribute__((ext_vector_type(8))) _Float16 half8;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -20,9 +21,24 @@ __device__ __forceinline__ void ud_glds16(const void* gsrc, void* lds_wave_base)
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-__device__ __forceinline__ float ud_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU (nn.GELU default).  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32 round-off level and
+// three orders below the fp16 rounding of the stored result): 1 v_rcp + 1 v_exp + 7 FMAs instead of ~45 instructions of erff.
+__device__ __forceinline__ float ud_erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  poly *= t;
+  const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
+  const float r = fmaf(-poly, e, 1.0f);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float ud_gelu_erf(float x) { return 0.5f * x * (1.0f + ud_erf_fast(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float ud_lrelu(float x) { return x > 0.0f ? x : 0.01f * x; }
 __device__ __forceinline__ float ud_act(float x, int act) {
+  if (act == 3) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));   // bisect-only reference GELU
   return act == UD_ACT_GELU ? ud_gelu_erf(x) : (act == UD_ACT_LRELU ? ud_lrelu(x) : x);
 }
 
@@ -33,6 +49,7 @@ __device__ __forceinline__ float ud_wave_sum(float v) {
 }
 
 void ud_set_error(const char* msg);
+int ud_debug_flags_host();   // bisect switches (api.cpp): bit0 attention: no deferred max; bit1 GELU via erff; bit2 no LDS-staged stores
 #define UD_CHECK_LAUNCH(name)                          \
   do {                                                 \
     hipError_t e_ = hipGetLastError();                 \

@@ -9,7 +9,7 @@ import torch
 from . import _lib
 from ._lib import (UD_A_CONV3_REFLECT, UD_A_CONV3_ZERO, UD_A_DENSE, UD_ACT_GELU, UD_ACT_LRELU, UD_ACT_NONE,  # noqa: F401
                    UD_EPI_D2S, UD_EPI_F16, UD_EPI_F32, UD_EPI_HEAD, UD_EPI_QKV, UdAttention, UdFinalize, UdGemm,
-                   UdLayerNorm, UdPreprocess, UdRayEmbed, UdResizeAC, UdUpsample2x, check, lib)
+                   UdLayerNorm, UdLinearF32, UdPreprocess, UdRayEmbed, UdResizeAC, UdUpsample2x, check, lib)
 
 
 def ptr(t):
@@ -89,6 +89,15 @@ class Program:
     def attention(self, **kw):
         self._k(kw, "attention", 4.0 * kw["B"] * kw["H"] * kw["Nq"] * kw["Nk"] * 64)
         return check(lib.ud_program_add_attention(self.h, C.byref(mk(UdAttention, **kw))))
+
+    def linear_f32(self, **kw):
+        self._k(kw, "camera_f32", 2.0 * kw["M"] * kw["N"] * kw["K"], 4.0 * kw["N"] * kw["K"])
+        return check(lib.ud_program_add_linear_f32(self.h, C.byref(mk(UdLinearF32, **kw))))
+
+    def attention_small_f32(self, q, kv, out, B, T, H, Cc, scale):
+        self.keep += [q, kv, out]
+        self.meta.append(("camera_f32", "attention_small", 0.0, 0.0))
+        return check(lib.ud_program_add_attention_small_f32(self.h, ptr(q), ptr(kv), ptr(out), B, T, H, Cc, scale))
 
     def preprocess(self, **kw):
         self._k(kw, "preprocess"); return check(lib.ud_program_add_preprocess(self.h, C.byref(mk(UdPreprocess, **kw))))

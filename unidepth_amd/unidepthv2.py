@@ -90,6 +90,14 @@ class _Plan:
 
         P = ops.Program()
         self.prog = P
+        wname = {id(v): k for k, v in w.items() if torch.is_tensor(v)}
+        _gemm = P.gemm
+
+        def tagged_gemm(**kw):
+            if "tag" not in kw and id(kw.get("W")) in wname:
+                kw["tag"] = wname[id(kw["W"])]
+            return _gemm(**kw)
+        P.gemm = tagged_gemm
         zeros = z(256)
         # ---------------- inputs
         self.rgb = torch.zeros(B, 3, H, W, dtype=torch.uint8 if is_u8 else f32, device=dev)
@@ -111,7 +119,7 @@ class _Plan:
         ao = z(M, D)
         hid = z(M, 4 * D)
         featn = [z(B * hwp, D) for _ in range(4)]
-        clsn = [z(_rup(B, 8), D) for _ in range(4)]
+        clsn = [z(_rup(B, 8), D, dtype=f32) for _ in range(4)]       # final-LN'd cls tokens stay fp32: they feed the fp32 camera head
         self.enc_first = len(P)
         lvl = 0
         for i in range(a["depth"]):
@@ -133,7 +141,7 @@ class _Plan:
                 P.layernorm(x=x, y=featn[lvl], rows=B * hw, D=D, ldx=D, ldy=D, eps=1e-5, rows_per_img=hw, in_rows_per_img=Np,
                             in_row_off=1, out_rows_per_img=hwp, out_row_off=0)
                 P.layernorm(x=x, y=clsn[lvl], rows=B, D=D, ldx=D, ldy=D, eps=1e-5, rows_per_img=1, in_rows_per_img=Np, in_row_off=0,
-                            out_rows_per_img=1, out_row_off=0)
+                            out_rows_per_img=1, out_row_off=0, out_f32=1)
                 lvl += 1
         self.enc_last = len(P)
         self.x, self.featn, self.clsn = x, featn, clsn
@@ -145,19 +153,41 @@ class _Plan:
         for j in range(4):
             P.gemm(A=featn[j], W=w[f"dec.adapter.{j}.w"], bias=w[f"dec.adapter.{j}.b"], out=feat[j], M=Md, N=C, K=D, lda=D, ldw=D,
                    ldc=C, epi=UD_EPI_F32)
-            P.gemm(A=clsn[j], W=w[f"dec.camadapter.{j}.w"], bias=w[f"dec.camadapter.{j}.b"], out=ct.data_ptr() + j * C * 4, M=B, N=C,
-                   K=D, lda=D, ldw=D, ldc=4 * C, epi=UD_EPI_F32)
-        # ---------------- camera head (decoder.py:48-114) on the 4 camera tokens per image
+            P.linear_f32(x=clsn[j], W=w[f"dec.camadapter.{j}.w"], bias=w[f"dec.camadapter.{j}.b"], out=ct.data_ptr() + j * C * 4,
+                         M=B, N=C, K=D, ldx=D, ldw=D, ldc=4 * C, tag="cam.adapter")
+        # ---- camera head (decoder.py:48-114) on the 4 camera tokens per image: an fp32 island (UdLinearF32 explains why)
         Mc = B * 4
-        Mcp = _rup(Mc, 8)
-        cn = z(Mcp, C); ch = z(Mcp, 4 * C); cq = z(Mcp, Hd * 64); ck = z(Mcp, Hd * 64); cvt = z(B, Hd, 64, 64); cao = z(Mcp, Hd * 64)
-        t = z(Mcp, C, dtype=f32)
-        raw = z(Mcp, 4, dtype=f32)
+        cn = z(Mc, C, dtype=f32); ch = z(Mc, 4 * C, dtype=f32); cq = z(Mc, C, dtype=f32); ckv = z(Mc, 2 * C, dtype=f32)
+        cao = z(Mc, C, dtype=f32); t = z(Mc, C, dtype=f32); raw = z(Mc, 1, dtype=f32)
         scale_d = meta["hd"] ** -0.5
 
         def ln(src, dst, rows, dim=C):
             P.layernorm(x=src, y=dst, rows=rows, D=dim, ldx=dim, ldy=dim, eps=1e-5, rows_per_img=rows, in_rows_per_img=rows,
                         out_rows_per_img=rows)
+
+        def ln32(src, dst, rows):
+            P.layernorm(x=src, y=dst, rows=rows, D=C, ldx=C, ldy=C, eps=1e-5, rows_per_img=rows, in_rows_per_img=rows,
+                        out_rows_per_img=rows, out_f32=1)
+
+        def lin32(xb, pre, out, n, k, ldx, ldc, act=UD_ACT_NONE, accumulate=0, bias=True, **kw):
+            P.linear_f32(x=xb, W=w[pre + ".w"], out=out, M=Mc, N=n, K=k, ldx=ldx, ldw=k, ldc=ldc, act=act, accumulate=accumulate,
+                         tag="cam." + pre, **({"bias": w[pre + ".b"]} if bias else {}), **kw)
+
+        def mlp32(pre, stream, out, accumulate, n_out=C):
+            ln32(stream, cn, Mc)
+            nh = w[pre + "fc1.w"].shape[0]
+            lin32(cn, pre + "fc1", ch, nh, C, C, nh, act=UD_ACT_GELU)
+            lin32(ch, pre + "fc2", out, n_out, nh, nh, n_out if n_out == 1 else C, accumulate=accumulate)
+
+        mlp32("cam.project.", ct, t, 0)
+        for blk in ("cam.agg1.", "cam.agg2."):
+            ln32(t, cn, Mc)                                                   # norm_attnx and norm_attnctx share statistics
+            lin32(cn, blk + "q", cq, C, C, C, C, add=w["cam.pos"], ldadd=C, add_mod=4)
+            lin32(cn, blk + "kv", ckv, 2 * C, C, C, 2 * C)
+            P.attention_small_f32(cq, ckv, cao, B, 4, Hd, C, scale_d)
+            lin32(cao, blk + "out", t, C, C, C, C, accumulate=1, bias=False)
+            mlp32(blk, t, t, 1)
+        mlp32("cam.out.", t, raw, 0, n_out=1)
 
         def mlp(pre, stream, rows, nrm, hidbuf, out=None, accumulate=1, out2=None, act2=UD_ACT_NONE, n_out=C, ldc=C):
             ln(stream, nrm, rows)
@@ -168,20 +198,8 @@ class _Plan:
             P.gemm(A=hidbuf, W=w[pre + "fc2.w"], bias=w[pre + "fc2.b"], out=stream if out is None else out, M=rows, N=n_out, K=nh,
                    lda=nh, ldw=nh, ldc=ldc, epi=UD_EPI_F32, accumulate=accumulate, **kw)
 
-        mlp("cam.project.", ct, Mc, cn, ch, out=t, accumulate=0)
-        for blk in ("cam.agg1.", "cam.agg2."):
-            ln(t, cn, Mc)                                                     # norm_attnx and norm_attnctx share statistics
-            P.gemm(A=cn, W=w[blk + "q.w"], bias=w[blk + "q.b"], out=cq, add=w["cam.pos"], M=Mc, N=Hd * 64, K=C, lda=C, ldw=C,
-                   ldc=Hd * 64, ldadd=Hd * 64, epi=UD_EPI_F16, rows_in=4, rows_out=4)
-            P.gemm(A=cn, W=w[blk + "kv.w"], bias=w[blk + "kv.b"], out=ck, out2=cvt, M=Mc, N=2 * Hd * 64, K=C, lda=C, ldw=C,
-                   ldc=Hd * 64, epi=UD_EPI_QKV, vsplit=Hd * 64, tok_per_img=4, kv_ld=64, heads_v=Hd)
-            P.attention(Q=cq, K=ck, Vt=cvt, O=cao, B=B, H=Hd, Nq=4, Nk=4, ldq=Hd * 64, ldk=Hd * 64, ldo=Hd * 64, kv_ld=64,
-                        q_rows_per_img=4, k_rows_per_img=4, scale=scale_d)
-            P.gemm(A=cao, W=w[blk + "out.w"], out=t, M=Mc, N=C, K=Hd * 64, lda=Hd * 64, ldw=Hd * 64, ldc=C, epi=UD_EPI_F32, accumulate=1)
-            mlp(blk, t, Mc, cn, ch)
-        mlp("cam.out.", t, Mc, cn, ch, out=raw, accumulate=0, n_out=4, ldc=4)
         self.intr4 = z(B, 4, dtype=f32); self.K33 = z(B, 9, dtype=f32); kinv = z(B, 9, dtype=f32); self.Kpost = z(B, 9, dtype=f32)
-        P.camera_intrinsics(raw, 4, self.intr4, self.K33, kinv, self.Kpost, B, Hn, Wn, float(self.rf), pl, pt)
+        P.camera_intrinsics(raw, 1, self.intr4, self.K33, kinv, self.Kpost, B, Hn, Wn, float(self.rf), pl, pt)
         # ---------------- rays (decoder.py:361-403 / GT camera: unidepthv2.py:299-303,361-362)
         self.rays = z(nb, 3, Hn, Wn, dtype=f32)
         if cam_nb:

@@ -103,9 +103,11 @@ def pack(config: dict, sd: dict, device) -> dict:
 
     pd = "pixel_decoder."
     for j in range(4):
-        for src, dst in (("input_adapter", "adapter"), ("camera_token_adapter", "camadapter")):
-            w, bb = _fold_ln(f[f"{pd}{src}.input_adapters.{j}.weight"], f[f"{pd}{src}.input_adapters.{j}.bias"], gn, bn)
-            put16(f"dec.{dst}.{j}.w", w); put32(f"dec.{dst}.{j}.b", bb)
+        w, bb = _fold_ln(f[f"{pd}input_adapter.input_adapters.{j}.weight"], f[f"{pd}input_adapter.input_adapters.{j}.bias"], gn, bn)
+        put16(f"dec.adapter.{j}.w", w); put32(f"dec.adapter.{j}.b", bb)
+        # camera tokens feed the fp32 camera head (see UdLinearF32 in include/unidepth_hip.h): weights stay fp32
+        w, bb = _fold_ln(f[f"{pd}camera_token_adapter.input_adapters.{j}.weight"], f[f"{pd}camera_token_adapter.input_adapters.{j}.bias"], gn, bn)
+        put32(f"dec.camadapter.{j}.w", w); put32(f"dec.camadapter.{j}.b", bb)
 
     def mlp(src, dst, ls=None, pad_out_to=None):
         w, bb = _fold_ln(f[src + "proj1.weight"], f[src + "proj1.bias"], f[src + "norm.weight"], f[src + "norm.bias"])
@@ -133,12 +135,29 @@ def pack(config: dict, sd: dict, device) -> dict:
         put16(dst + "out.w", wo)
         mlp(src + "mlp.", dst, ls=f[src + "ls2.gamma"] if layer_scale else None)
 
+    # ---- camera head: fp32 weights, natural head width (no padding), same folds
+    def mlp32(src, dst, ls=None):
+        w, bb = _fold_ln(f[src + "proj1.weight"], f[src + "proj1.bias"], f[src + "norm.weight"], f[src + "norm.bias"])
+        put32(dst + "fc1.w", w); put32(dst + "fc1.b", bb)
+        w2, b2 = f[src + "proj2.weight"], f[src + "proj2.bias"]
+        if ls is not None:
+            w2, b2 = w2 * ls[:, None], b2 * ls
+        put32(dst + "fc2.w", w2); put32(dst + "fc2.b", b2)
+
+    def attn_block32(src, dst):
+        wq, bq = _fold_ln(f[src + "q.weight"], None, f[src + "norm_attnx.weight"], f[src + "norm_attnx.bias"])
+        put32(dst + "q.w", wq); put32(dst + "q.b", bq)
+        wkv, bkv = _fold_ln(f[src + "kv.weight"], None, f[src + "norm_attnctx.weight"], f[src + "norm_attnctx.bias"])
+        put32(dst + "kv.w", wkv); put32(dst + "kv.b", bkv)
+        put32(dst + "out.w", f[src + "out.weight"] * f[src + "ls1.gamma"][:, None])
+        mlp32(src + "mlp.", dst, ls=f[src + "ls2.gamma"])
+
     cl = pd + "camera_layer."
-    mlp(cl + "project.", "cam.project.")
-    attn_block(cl + "aggregate1.", "cam.agg1.", True)
-    attn_block(cl + "aggregate2.", "cam.agg2.", True)
-    mlp(cl + "out_pinhole.", "cam.out.", pad_out_to=4)
-    put32("cam.pos", _pad_head_cols(f[cl + "latents_pos"].reshape(4, C), H, hd))
+    mlp32(cl + "project.", "cam.project.")
+    attn_block32(cl + "aggregate1.", "cam.agg1.")
+    attn_block32(cl + "aggregate2.", "cam.agg2.")
+    mlp32(cl + "out_pinhole.", "cam.out.")
+    put32("cam.pos", f[cl + "latents_pos"].reshape(4, C))
 
     dl = pd + "depth_layer."
     for j in range(4):
