@@ -4,65 +4,84 @@
 
 namespace {
 
-// one wave per output column n, one lane per row m (<= 64 rows per grid.y slice): W[n, :] is wave-uniform (broadcast
-// loads), x[m, :] streams per lane from L1/L2 (the whole activation is <= 256 KB).
+// one wave per output column n; the 64 lanes split K (16 B per lane per step, coalesced, branch-free), every lane carries
+// partial sums for up to 32 rows; wave reductions at the end.  W is streamed exactly once, x (<= 256 KB) comes from L1/L2.
+// (Measured alternatives on MI355X -- K split over several waves per column, reduce-scatter shuffles -- were slower: every
+// extra wave re-reads the activation slice and the kernel is bound by that L2 traffic, not by the shuffles.)
 __global__ __launch_bounds__(256) void linear_f32_kernel(const UdLinearF32 p) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (n >= p.N) return;
-  const int m = blockIdx.y * 64 + lane;
-  const int mm = m < p.M ? m : p.M - 1;
-  const f32x4* xr = (const f32x4*)(p.x + (size_t)mm * p.ldx);
-  const f32x4* wr = (const f32x4*)(p.W + (size_t)n * p.ldw);
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  const int k4 = p.K >> 2;
-#pragma unroll 8
-  for (int k = 0; k < k4; ++k) {
-    const f32x4 xv = xr[k];
-    const f32x4 wv = wr[k];
-    a0 = fmaf(xv[0], wv[0], a0);
-    a1 = fmaf(xv[1], wv[1], a1);
-    a2 = fmaf(xv[2], wv[2], a2);
-    a3 = fmaf(xv[3], wv[3], a3);
+  const int m0 = blockIdx.y * 32;
+  const int rows = (p.M - m0) < 32 ? (p.M - m0) : 32;
+  float acc[32];
+#pragma unroll
+  for (int m = 0; m < 32; ++m) acc[m] = 0.f;
+  const float* wr = p.W + (size_t)n * p.ldw;
+  const float* xb = p.x + (size_t)m0 * p.ldx;
+  for (int k = lane * 4; k < p.K; k += 256) {
+    const f32x4 wv = *(const f32x4*)(wr + k);
+    f32x4 xv[32];
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {          // rows beyond the batch re-read the last valid row (results unused)
+      const int mr = m < rows ? m : rows - 1;
+      xv[m] = *(const f32x4*)(xb + (size_t)mr * p.ldx + k);
+    }
+#pragma unroll
+    for (int m = 0; m < 32; ++m)
+      acc[m] = fmaf(xv[m][0], wv[0], fmaf(xv[m][1], wv[1], fmaf(xv[m][2], wv[2], fmaf(xv[m][3], wv[3], acc[m]))));
   }
-  float y = (a0 + a1) + (a2 + a3);
-  if (p.bias) y += p.bias[n];
-  if (p.add) y += p.add[(size_t)(mm % p.add_mod) * p.ldadd + n];
-  if (p.act == UD_ACT_GELU) y = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
-  if (m < p.M) {
+  float mine = 0.f;   // lane m keeps the reduced value of row m
+#pragma unroll
+  for (int m = 0; m < 32; ++m) {
+    const float s = ud_wave_sum(acc[m]);
+    if (lane == m) mine = s;
+  }
+  if (lane < rows) {
+    const int m = m0 + lane;
+    float y = mine;
+    if (p.bias) y += p.bias[n];
+    if (p.add) y += p.add[(size_t)(m % p.add_mod) * p.ldadd + n];
+    if (p.act == UD_ACT_GELU) y = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
     float* o = p.out + (size_t)m * p.ldc + n;
     *o = p.accumulate ? *o + y : y;
   }
 }
 
-__global__ void attention_small_kernel(const float* q, const float* kv, float* out, int B, int T, int H, int C, float scale) {
-  const int idx = blockIdx.x * 64 + threadIdx.x;
-  if (idx >= B * H * T) return;
-  const int i = idx % T;
-  const int h = (idx / T) % H;
-  const int b = idx / (T * H);
+// one wave per (image, head): lane = channel d of the head (hd <= 64), T <= 8 tokens
+__global__ __launch_bounds__(64) void attention_small_kernel(const float* q, const float* kv, float* out, int B, int T, int H, int C, float scale) {
+  const int lane = threadIdx.x;
+  const int h = blockIdx.x % H;
+  const int b = blockIdx.x / H;
   const int hd = C / H;
-  const float* qi = q + (size_t)(b * T + i) * C + h * hd;
-  float s[8];
-  float mx = -1e30f;
-  for (int j = 0; j < T; ++j) {
-    const float* kj = kv + (size_t)(b * T + j) * 2 * C + h * hd;
-    float acc = 0.f;
-    for (int d = 0; d < hd; ++d) acc = fmaf(qi[d], kj[d], acc);
-    s[j] = acc * scale;
-    mx = fmaxf(mx, s[j]);
+  const bool on = lane < hd;
+  float qv[8], kk[8], vv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const bool ok = on && i < T;
+    const size_t row = (size_t)(b * T + (i < T ? i : 0));
+    qv[i] = ok ? q[row * C + h * hd + lane] : 0.f;
+    kk[i] = ok ? kv[row * 2 * C + h * hd + lane] : 0.f;
+    vv[i] = ok ? kv[row * 2 * C + C + h * hd + lane] : 0.f;
   }
-  float den = 0.f;
-  for (int j = 0; j < T; ++j) {
-    s[j] = expf(s[j] - mx);
-    den += s[j];
-  }
-  const float inv = 1.0f / den;
-  float* o = out + (size_t)(b * T + i) * C + h * hd;
-  for (int d = 0; d < hd; ++d) {
-    float acc = 0.f;
-    for (int j = 0; j < T; ++j) acc = fmaf(s[j], kv[(size_t)(b * T + j) * 2 * C + C + h * hd + d], acc);
-    o[d] = acc * inv;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i >= T) break;
+    float s[8];
+    float mx = -1e30f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      s[j] = j < T ? ud_wave_sum(qv[i] * kk[j]) * scale : -1e30f;
+      mx = fmaxf(mx, s[j]);
+    }
+    float den = 0.f, o = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float pj = j < T ? expf(s[j] - mx) : 0.f;
+      den += pj;
+      o = fmaf(pj, vv[j], o);
+    }
+    if (on) out[(size_t)(b * T + i) * C + h * hd + lane] = o / den;
   }
 }
 
@@ -74,17 +93,17 @@ extern "C" int ud_linear_f32(const UdLinearF32* desc, void* stream) {
     ud_set_error("ud_linear_f32: bad argument (K, ldx, ldw % 4 == 0)");
     return UD_ERR_BAD_ARG;
   }
-  hipLaunchKernelGGL(linear_f32_kernel, dim3((d.N + 3) / 4, (d.M + 63) / 64), dim3(256), 0, (hipStream_t)stream, d);
+  hipLaunchKernelGGL(linear_f32_kernel, dim3((d.N + 3) / 4, (d.M + 31) / 32), dim3(256), 0, (hipStream_t)stream, d);
   UD_CHECK_LAUNCH("ud_linear_f32 launch");
   return UD_OK;
 }
 
 extern "C" int ud_attention_small_f32(const float* q, const float* kv, float* out, int B, int T, int H, int C, float scale, void* stream) {
-  if (!q || !kv || !out || B <= 0 || T <= 0 || T > 8 || H <= 0 || C % H) {
+  if (!q || !kv || !out || B <= 0 || T <= 0 || T > 8 || H <= 0 || C % H || C / H > 64) {
     ud_set_error("ud_attention_small_f32: bad argument (T <= 8)");
     return UD_ERR_BAD_ARG;
   }
-  hipLaunchKernelGGL(attention_small_kernel, dim3((B * H * T + 63) / 64), dim3(64), 0, (hipStream_t)stream, q, kv, out, B, T, H, C, scale);
+  hipLaunchKernelGGL(attention_small_kernel, dim3(B * H), dim3(64), 0, (hipStream_t)stream, q, kv, out, B, T, H, C, scale);
   UD_CHECK_LAUNCH("ud_attention_small_f32 launch");
   return UD_OK;
 }

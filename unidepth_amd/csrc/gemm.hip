@@ -577,7 +577,6 @@ int dispatch_bn(const UdGemm& d, hipStream_t s) {
 
 extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
   UdGemm dcopy = *desc;
-  if ((ud_debug_flags_host() & 2) && dcopy.act == UD_ACT_GELU) dcopy.act = 3;          // bisect: erff GELU
   if ((ud_debug_flags_host() & 4) && (dcopy.epi == UD_EPI_F16 || dcopy.epi == UD_EPI_QKV)) dcopy.ldc2 |= (1 << 30);
   if (ud_debug_flags_host() & 8) dcopy.tile_hint = 1;                                  // bisect: 128x128 tiles only                               // bisect: no LDS-staged stores
   const UdGemm& d = dcopy;

@@ -38,7 +38,6 @@ __device__ __forceinline__ float ud_erf_fast(float x) {
 __device__ __forceinline__ float ud_gelu_erf(float x) { return 0.5f * x * (1.0f + ud_erf_fast(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float ud_lrelu(float x) { return x > 0.0f ? x : 0.01f * x; }
 __device__ __forceinline__ float ud_act(float x, int act) {
-  if (act == 3) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));   // bisect-only reference GELU
   return act == UD_ACT_GELU ? ud_gelu_erf(x) : (act == UD_ACT_LRELU ? ud_lrelu(x) : x);
 }
 
