@@ -42,7 +42,8 @@ def test_gemm_f16_dense(ops, M, N, K, act):
     assert rel(out.float(), ref) < 1e-3
 
 
-@pytest.mark.parametrize("M,N,K,hint", [(1100, 512, 128, 2), (2048, 256, 64, 2), (3000, 1152, 384, 2), (2600, 1024, 4096, 2), (1100, 512, 128, 1)])
+@pytest.mark.parametrize("M,N,K,hint", [(1100, 512, 128, 2), (2048, 256, 64, 2), (3000, 1152, 384, 2), (2600, 1024, 4096, 2), (1100, 512, 128, 1),
+                                           (1100, 512, 128, 3), (3000, 1152, 384, 3), (2600, 1024, 2048, 3)])
 def test_gemm_big_tiles_f16_f32(ops, M, N, K, hint):
     """256x256 / 4-stage kernel (tile_hint=2) against the same fp32 statement; edge tiles in M and N, deep K ring."""
     A = rnd(M, K, seed=1).half()

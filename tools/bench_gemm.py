@@ -14,7 +14,7 @@ for name, N, K, kind in shapes:
     W = (torch.randn(N, K, generator=g) * K ** -0.5).half().cuda()
     bias = torch.randn(N, generator=g).cuda()
     res = []
-    for hint in (1, 2):
+    for hint in (1, 2, 3):
         if kind == "qkv":
             out = torch.zeros(M, 2048, dtype=torch.half, device="cuda"); vt = torch.zeros(8, 16, 64, 1408, dtype=torch.half, device="cuda")
             kw = dict(out=out, out2=vt, ldc=2048, epi=ops.UD_EPI_QKV, vsplit=2048, tok_per_img=1376, kv_ld=1408, heads_v=16)
@@ -37,4 +37,4 @@ for name, N, K, kind in shapes:
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / reps * 1e3
         res.append((us, 2.0 * M * N * K / us / 1e6))
-    print(f"{name:8s} N={N:5d} K={K:5d}  128x128: {res[0][0]:7.1f} us {res[0][1]:7.1f} TF | 256x256: {res[1][0]:7.1f} us {res[1][1]:7.1f} TF")
+    print(f"{name:8s} N={N:5d} K={K:5d}  128x128: {res[0][0]:7.1f} us {res[0][1]:7.1f} TF | 256x256: {res[1][0]:7.1f} us {res[1][1]:7.1f} TF | 192x256: {res[2][0]:7.1f} us {res[2][1]:7.1f} TF")

@@ -6,10 +6,13 @@ OUT=../libunidepth_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result"
 mkdir -p build
 pids=()
-for f in gemm.hip attention.hip layernorm.hip pointwise.hip camera_f32.hip; do
+for f in gemm.hip layernorm.hip pointwise.hip camera_f32.hip; do
   ( hipcc $FLAGS "$@" -c $f -o build/${f%.hip}.o ) &
   pids+=($!)
 done
+# attention: keep the MFMA accumulators in VGPRs (the softmax VALU works on them every tile; the default AGPR form costs
+# ~160 v_accvgpr_read/write per 16 MFMAs)
+( hipcc $FLAGS -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -c attention.hip -o build/attention.o ) & pids+=($!)
 ( hipcc $FLAGS -x hip -c api.cpp -o build/api.o ) & pids+=($!)
 ( hipcc $FLAGS -x hip -c program.cpp -o build/program.o ) & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done

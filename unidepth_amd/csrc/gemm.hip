@@ -68,13 +68,14 @@ __device__ __forceinline__ void gemm_epilogue(const UdGemm& p, f32x4 (&acc)[TM][
   } else {
     // ---- fp16 outputs: stage the wave's sub-tile through LDS so that global stores are 16 B per lane and every
     //      8 lanes write one full 128-byte row segment (direct MFMA-layout stores are 8 B per lane in 32-byte pieces)
-    if constexpr ((EPI == UD_EPI_F16 || EPI == UD_EPI_QKV) && TN == 4 && (TM % 4) == 0) {
+    if constexpr ((EPI == UD_EPI_F16 || EPI == UD_EPI_QKV) && TN == 4 && (TM % 2) == 0) {
       if (stage != nullptr && (p.N & 7) == 0 && (p.ldc & 7) == 0 && !(p.ldc2 >> 30)) {
+        constexpr int CH = (TM % 4) == 0 ? 4 : 2;      // m-tiles staged per pass (64 or 32 rows x 64 columns)
 #pragma unroll
-        for (int c = 0; c < TM / 4; ++c) {
+        for (int c = 0; c < TM / CH; ++c) {
 #pragma unroll
-          for (int il = 0; il < 4; ++il) {
-            const int i = c * 4 + il;
+          for (int il = 0; il < CH; ++il) {
+            const int i = c * CH + il;
             const int m = mbase + i * 16 + (lane & 15);
             int arow = m;
             if (p.rows_in > 0) arow = m - (m / p.rows_in) * p.rows_in + p.add_row_off;
@@ -94,10 +95,10 @@ __device__ __forceinline__ void gemm_epilogue(const UdGemm& p, f32x4 (&acc)[TM][
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-          for (int it = 0; it < 8; ++it) {
+          for (int it = 0; it < 2 * CH; ++it) {
             const int id = it * 64 + lane;
             const int row = id >> 3, ch = id & 7;
-            const int m = mbase + c * 64 + row;
+            const int m = mbase + c * CH * 16 + row;
             const int n = nbase + ch * 8;
             if (m < p.M && n < p.N) {
               int orow = m;
@@ -378,37 +379,50 @@ __global__ __launch_bounds__(256) void gemm_kernel(const UdGemm p) {
 //    (A m-half sets alternate, B k-step sets alternate) -- 0.375 ds_read_b128 per MFMA;
 //  * same source-side XOR swizzle as the 128x128 kernel (chunk ^= (row >> 1) & 7): conflict-free ds_read_b128.
 // ================================================================================================================
-constexpr int BIG_STAGE = 65536;
+// MH = m-tiles (of 16 rows) per wave per m-half: 4 -> 256-row tiles, 3 -> 192-row tiles (tile-count quantisation on the
+// 256 CUs decides which one a GEMM gets: e.g. M = 11008, N = 1024 is 172 tiles of 256 rows (67 % of the CUs busy) but 232
+// tiles of 192 rows (91 %)).
+template <int MH>
+struct BigCfg {
+  static constexpr int BM = 64 * MH;                 // 2 waves along m x 2 halves x MH x 16
+  static constexpr int A_BYTES = BM * 128;
+  static constexpr int STAGE = A_BYTES + 32768;
+  static constexpr int A_LOADS = BM / 64;            // 16-byte chunks per thread per K-tile (512 threads)
+};
 
-template <int EPI, bool SWAP>
+template <int MH, int EPI, bool SWAP>
 __device__ __forceinline__ void gemm256_body(const UdGemm& p, char* smem, int m0, int n0, const half_t* A, const half_t* W,
                                              const float* bias, char* out, char* out2) {
+  using C = BigCfg<MH>;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wv >> 2, wn = wv & 3;
   const int nk = p.K >> 6;
 
-  // loader: operand tile = 2048 chunks of 16 B; thread owns chunks tid + 512*i -> rows (tid >> 3) + 64*i, i = 0..3
+  // loader: thread owns chunks tid + 512*i -> rows (tid >> 3) + 64*i
   const int lrow = tid >> 3;
   const int csrc = (tid & 7) ^ ((lrow >> 1) & 7);
-  const half_t* pa[4];
+  const half_t* pa[C::A_LOADS];
   const half_t* pb[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < C::A_LOADS; ++i) {
     int m = m0 + lrow + 64 * i;
     m = m < p.M ? m : p.M - 1;
     pa[i] = A + (size_t)m * p.lda + csrc * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
     int n = n0 + lrow + 64 * i;
     n = n < p.N ? n : p.N - 1;
     pb[i] = W + (size_t)n * p.ldw + csrc * 8;
   }
   auto issue = [&](int kt) {
-    char* sb = smem + (kt & 1) * BIG_STAGE + wv * 1024;
+    char* sb = smem + (kt & 1) * C::STAGE + wv * 1024;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ud_glds16(pa[i] + kt * 64, sb + i * 8192);
+    for (int i = 0; i < C::A_LOADS; ++i) ud_glds16(pa[i] + kt * 64, sb + i * 8192);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ud_glds16(pb[i] + kt * 64, sb + 32768 + i * 8192);
+    for (int i = 0; i < 4; ++i) ud_glds16(pb[i] + kt * 64, sb + C::A_BYTES + i * 8192);
   };
 
   // fragment read offsets inside a stage: row-major [row][64 halves], chunk index swizzled by (row >> 1) & 7
@@ -417,77 +431,78 @@ __device__ __forceinline__ void gemm256_body(const UdGemm& p, char* smem, int m0
   const int fswz = frow >> 1;
   const int c0 = ((fq) ^ fswz) << 4;          // k-step 0
   const int c1 = ((4 + fq) ^ fswz) << 4;      // k-step 1
-  const int a_off = (wm * 128 + frow) * 128;
-  const int b_off = 32768 + (wn * 64 + frow) * 128;
+  const int a_off = (wm * (C::BM / 2) + frow) * 128;
+  const int b_off = C::A_BYTES + (wn * 64 + frow) * 128;
 
-  f32x4 acc[8][4];
+  f32x4 acc[2 * MH][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 2 * MH; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-#define UD_MFMA16(ROW0, AF, BF)                                                                                  \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) {                \
+#define UD_MFMA_HALF(ROW0, AF, BF)                                                                               \
+  _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) {               \
     if constexpr (SWAP) acc[ROW0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[j], AF[i], acc[ROW0 + i][j], 0, 0, 0); \
     else acc[ROW0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AF[i], BF[j], acc[ROW0 + i][j], 0, 0, 0);   \
   }
 
-  half8 a0[4], a1[4], b0[4], b1[4];
+  half8 a0[MH], a1[MH], b0[4], b1[4];
   issue(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 #pragma unroll
-  for (int t = 0; t < 4; ++t) a0[t] = *(const half8*)(smem + a_off + t * 2048 + c0);
+  for (int t = 0; t < MH; ++t) a0[t] = *(const half8*)(smem + a_off + t * 2048 + c0);
 #pragma unroll
   for (int j = 0; j < 4; ++j) b0[j] = *(const half8*)(smem + b_off + j * 2048 + c0);
 
   for (int kt = 0; kt < nk; ++kt) {
-    const char* sb = smem + (kt & 1) * BIG_STAGE;
-    const char* sbn = smem + ((kt + 1) & 1) * BIG_STAGE;
+    const char* sb = smem + (kt & 1) * C::STAGE;
+    const char* sbn = smem + ((kt + 1) & 1) * C::STAGE;
     // ---- phase (k0, m-half 0): DMA of the whole next K-tile goes out first
     if (kt + 1 < nk) issue(kt + 1);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) a1[t] = *(const half8*)(sb + a_off + (4 + t) * 2048 + c0);
+    for (int t = 0; t < MH; ++t) a1[t] = *(const half8*)(sb + a_off + (MH + t) * 2048 + c0);
     __builtin_amdgcn_sched_barrier(0);     // keep the fragment prefetch ahead of the MFMAs (hipcc would sink it to first use)
-    UD_MFMA16(0, a0, b0)
+    UD_MFMA_HALF(0, a0, b0)
     // ---- phase (k0, m-half 1)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) a0[t] = *(const half8*)(sb + a_off + t * 2048 + c1);
+    for (int t = 0; t < MH; ++t) a0[t] = *(const half8*)(sb + a_off + t * 2048 + c1);
 #pragma unroll
     for (int j = 0; j < 4; ++j) b1[j] = *(const half8*)(sb + b_off + j * 2048 + c1);
     __builtin_amdgcn_sched_barrier(0);
-    UD_MFMA16(4, a1, b0)
+    UD_MFMA_HALF(MH, a1, b0)
     // ---- phase (k1, m-half 0)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) a1[t] = *(const half8*)(sb + a_off + (4 + t) * 2048 + c1);
+    for (int t = 0; t < MH; ++t) a1[t] = *(const half8*)(sb + a_off + (MH + t) * 2048 + c1);
     __builtin_amdgcn_sched_barrier(0);
-    UD_MFMA16(0, a0, b1)
+    UD_MFMA_HALF(0, a0, b1)
     // ---- phase (k1, m-half 1): next K-tile must have landed for every wave before anyone reads it
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int t = 0; t < 4; ++t) a0[t] = *(const half8*)(sbn + a_off + t * 2048 + c0);
+    for (int t = 0; t < MH; ++t) a0[t] = *(const half8*)(sbn + a_off + t * 2048 + c0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) b0[j] = *(const half8*)(sbn + b_off + j * 2048 + c0);
     __builtin_amdgcn_sched_barrier(0);
-    UD_MFMA16(4, a1, b1)
+    UD_MFMA_HALF(MH, a1, b1)
   }
-#undef UD_MFMA16
+#undef UD_MFMA_HALF
   char* stage = nullptr;
   if constexpr ((EPI == UD_EPI_F16 || EPI == UD_EPI_QKV) && SWAP) {
     __syncthreads();
     stage = smem + wv * 9216;
   }
-  gemm_epilogue<8, 4, EPI, SWAP>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, bias, out, out2, nullptr, 0.f, 0.f, stage);
+  gemm_epilogue<2 * MH, 4, EPI, SWAP>(p, acc, m0 + wm * (C::BM / 2), n0 + wn * 64, lane, bias, out, out2, nullptr, 0.f, 0.f, stage);
 }
 
-template <int EPI>
+template <int MH, int EPI>
 __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = BigCfg<MH>::BM;
   const int tiles_n = (p.N + 255) >> 8;
-  const int tiles_m = (p.M + 255) >> 8;
+  const int tiles_m = (p.M + BM - 1) / BM;
   const int nblk = tiles_m * tiles_n;
   int bid = blockIdx.x;
   {  // XCD-aware: contiguous range of the tile list per XCD
@@ -504,50 +519,60 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   const int rem = bid - grp * gsz;
   const int tile_m = first_m + rem % gm;
   const int tile_n = rem / gm;
-  const int m0 = tile_m << 8, n0 = tile_n << 8;
+  const int m0 = tile_m * BM, n0 = tile_n << 8;
   const half_t* A = (const half_t*)p.A;
   const half_t* W = (const half_t*)p.W;
   if constexpr (EPI == UD_EPI_QKV) {
     if (n0 >= p.vsplit) {
-      gemm256_body<EPI, false>(p, smem, m0, n0, A, W, p.bias, (char*)p.out, (char*)p.out2);
+      gemm256_body<MH, EPI, false>(p, smem, m0, n0, A, W, p.bias, (char*)p.out, (char*)p.out2);
       return;
     }
   }
-  gemm256_body<EPI, true>(p, smem, m0, n0, A, W, p.bias, (char*)p.out, (char*)p.out2);
+  gemm256_body<MH, EPI, true>(p, smem, m0, n0, A, W, p.bias, (char*)p.out, (char*)p.out2);
 }
 
-template <int EPI>
+template <int MH, int EPI>
 int launch256(const UdGemm& d, hipStream_t s) {
-  const int tiles = ((d.N + 255) >> 8) * ((d.M + 255) >> 8);
-  const int lds = 2 * BIG_STAGE;
+  constexpr int BM = BigCfg<MH>::BM;
+  const int tiles = ((d.N + 255) >> 8) * ((d.M + BM - 1) / BM);
+  const int lds = 2 * BigCfg<MH>::STAGE;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm256_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-      ud_set_error("ud_gemm_f16: cannot reserve 128 KB of LDS");
+    if (hipFuncSetAttribute((const void*)gemm256_kernel<MH, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      ud_set_error("ud_gemm_f16: cannot reserve the LDS ring of the large-tile kernel");
       return UD_ERR_LAUNCH;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm256_kernel<EPI>), dim3(tiles), dim3(512), lds, s, d);
-  UD_CHECK_LAUNCH("ud_gemm_f16 (256x256) launch");
+  hipLaunchKernelGGL((gemm256_kernel<MH, EPI>), dim3(tiles), dim3(512), lds, s, d);
+  UD_CHECK_LAUNCH("ud_gemm_f16 (large tile) launch");
   return UD_OK;
 }
 
-// Tile-shape choice for dense GEMMs: the 256x256 kernel has ~2x the per-CU rate of the 128x128 one but runs one
-// workgroup per CU, so it loses to wave quantisation when the tile count is small or just above a multiple of 256 CUs.
-inline bool use_big_tiles(const UdGemm& d) {
-  if (d.amode != UD_A_DENSE || d.groups > 1 || d.M < 1024 || d.N < 256 || (d.K & 63)) return false;
-  if (d.epi == UD_EPI_QKV && (d.vsplit & 255)) return false;
-  if (d.tile_hint == 1) return false;
-  if (d.tile_hint == 2) return true;
-  // cost model fitted on MI355X (tools/bench_gemm*.py): per-launch fixed cost + rounds x K-loop time per round;
-  // the 128x128 kernel runs two workgroups per CU, so its rounds quantise in halves
+// Tile-shape choice for dense GEMMs.  Cost model fitted on MI355X (tools/bench_gemm*.py): per-launch fixed cost + rounds x
+// K-loop time per round.  The large-tile kernel (one workgroup per CU) loses to wave quantisation when the tile count is
+// small or just above a multiple of 256 CUs; the 128x128 kernel runs two workgroups per CU, so its rounds quantise in halves.
+// Returns 0 (128x128), 3 (192x256) or 4 (256x256).
+inline int pick_tiles(const UdGemm& d) {
+  if (d.amode != UD_A_DENSE || d.groups > 1 || d.M < 1024 || d.N < 256 || (d.K & 63)) return 0;
+  if (d.epi == UD_EPI_QKV && (d.vsplit & 255)) return 0;
+  if (d.tile_hint == 1) return 0;
+  if (d.tile_hint == 2) return 4;
+  if (d.tile_hint == 3) return 3;
   const double kk = (double)d.K / 1024.0;
-  const double big_tiles = (double)((d.N + 255) / 256) * ((d.M + 255) / 256);
+  const double tn = (double)((d.N + 255) / 256);
+  const double t256 = 8.0 + ceil(tn * ((d.M + 255) / 256) / 256.0) * 30.0 * kk;
+  const double t192 = 8.0 + ceil(tn * ((d.M + 191) / 192) / 256.0) * 23.5 * kk;
   const double small_tiles = (double)((d.N + 127) / 128) * ((d.M + 127) / 128);
-  const double t_big = 8.0 + ceil(big_tiles / 256.0) * 30.0 * kk;
   const double t_small = 6.0 + ceil(small_tiles / 256.0) * 0.5 * 21.5 * kk;
-  return t_big < 0.93 * t_small;
+  const double t_big = t256 <= t192 ? t256 : t192;
+  if (t_big >= 0.93 * t_small) return 0;
+  return t256 <= t192 ? 4 : 3;
+}
+
+template <int EPI>
+int launch_big(const UdGemm& d, hipStream_t s, int which) {
+  return which == 3 ? launch256<3, EPI>(d, s) : launch256<4, EPI>(d, s);
 }
 
 template <class C, int EPI, int AMODE>
@@ -594,7 +619,7 @@ extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
       ud_set_error("ud_gemm_f16: bad QKV epilogue geometry");
       return UD_ERR_BAD_ARG;
     }
-    if (use_big_tiles(d)) return launch256<UD_EPI_QKV>(d, s);
+    if (const int bt = pick_tiles(d)) return launch_big<UD_EPI_QKV>(d, s, bt);
     return launch<Cfg<128, 64, 64>, UD_EPI_QKV, UD_A_DENSE>(d, s);
   }
   if (d.epi == UD_EPI_D2S) {
@@ -602,7 +627,7 @@ extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
       ud_set_error("ud_gemm_f16: bad D2S epilogue geometry");
       return UD_ERR_BAD_ARG;
     }
-    if (use_big_tiles(d)) return launch256<UD_EPI_D2S>(d, s);
+    if (const int bt = pick_tiles(d)) return launch_big<UD_EPI_D2S>(d, s, bt);
     return dispatch_bn<UD_EPI_D2S, UD_A_DENSE>(d, s);
   }
   if (d.epi == UD_EPI_HEAD) {
@@ -613,13 +638,13 @@ extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
     return launch<Cfg<32, 32, 32>, UD_EPI_HEAD, UD_A_CONV3_REFLECT>(d, s);
   }
   if (d.epi == UD_EPI_F16) {
-    if (use_big_tiles(d)) return launch256<UD_EPI_F16>(d, s);
+    if (const int bt = pick_tiles(d)) return launch_big<UD_EPI_F16>(d, s, bt);
     if (d.amode == UD_A_DENSE) return dispatch_bn<UD_EPI_F16, UD_A_DENSE>(d, s);
     if (d.amode == UD_A_CONV3_ZERO) return dispatch_bn<UD_EPI_F16, UD_A_CONV3_ZERO>(d, s);
     return dispatch_bn<UD_EPI_F16, UD_A_CONV3_REFLECT>(d, s);
   }
   if (d.epi == UD_EPI_F32) {
-    if (use_big_tiles(d)) return launch256<UD_EPI_F32>(d, s);
+    if (const int bt = pick_tiles(d)) return launch_big<UD_EPI_F32>(d, s, bt);
     if (d.amode == UD_A_DENSE) return dispatch_bn<UD_EPI_F32, UD_A_DENSE>(d, s);
     if (d.amode == UD_A_CONV3_ZERO) return dispatch_bn<UD_EPI_F32, UD_A_CONV3_ZERO>(d, s);
   }
