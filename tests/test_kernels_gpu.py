@@ -168,6 +168,33 @@ def test_gemm_conv3x3(ops, mode, Cin, Cout, H, W, rows_pad):
     assert rel(out.view(B, rows_img, Cout)[:, :H * W].float(), ref) < 1e-3
 
 
+@pytest.mark.parametrize("hint,Cin,Cout,H,W", [(2, 64, 256, 37, 37), (3, 128, 512, 30, 41), (2, 256, 256, 20, 20)])
+def test_gemm_conv3x3_big_tiles(ops, hint, Cin, Cout, H, W):
+    """implicit-GEMM 3x3 conv (zero padding) through the large-tile kernels, fp16 and fp32-accumulate epilogues."""
+    B = 2
+    rows_img = ((H * W + 7) // 8) * 8
+    x = rnd(B, rows_img, Cin, seed=1).half()
+    wt = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=2)
+    bias = rnd(Cout, seed=3)
+    Wg = wt.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().half()
+    zeros = torch.zeros(256, dtype=torch.half, device="cuda")
+    M = B * rows_img
+    conv = dict(A=x, W=Wg, bias=bias, zeros=zeros, M=M, N=Cout, K=9 * Cin, ldw=9 * Cin, amode=ops.UD_A_CONV3_ZERO, Himg=H, Wimg=W,
+                Cin=Cin, cstride=Cin, coff=0, rows_img=rows_img, img_stride=rows_img * Cin, tile_hint=hint)
+    out = torch.zeros(M, Cout, dtype=torch.half, device="cuda")
+    ops.gemm(out=out, ldc=Cout, epi=ops.UD_EPI_F16, act=ops.UD_ACT_LRELU, **conv)
+    xin = x[:, :H * W].float().view(B, H, W, Cin).permute(0, 3, 1, 2)
+    ref = F.conv2d(xin, Wg.float().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), bias, padding=1).permute(0, 2, 3, 1).reshape(B, H * W, Cout)
+    torch.cuda.synchronize()
+    assert rel(out.view(B, rows_img, Cout)[:, :H * W].float(), F.leaky_relu(ref, 0.01)) < 1e-3
+    lat = rnd(M, Cout, seed=5); lat0 = lat.clone(); l16 = torch.zeros(M, Cout, dtype=torch.half, device="cuda")
+    ops.gemm(out=lat, out2=l16, ldc=Cout, ldc2=Cout, epi=ops.UD_EPI_F32, accumulate=1, act2=ops.UD_ACT_LRELU, **conv)
+    torch.cuda.synchronize()
+    want = lat0.view(B, rows_img, Cout)[:, :H * W] + ref
+    assert rel(lat.view(B, rows_img, Cout)[:, :H * W], want) < 2e-4
+    assert rel(l16.view(B, rows_img, Cout)[:, :H * W].float(), F.leaky_relu(want, 0.01)) < 1e-3
+
+
 @pytest.mark.parametrize("k", [1, 2, 4])
 def test_gemm_d2s_convtranspose(ops, k):
     B, Hin, Win, Cin, Co = 2, 5, 7, 64, 64

@@ -390,7 +390,7 @@ struct BigCfg {
   static constexpr int A_LOADS = BM / 64;            // 16-byte chunks per thread per K-tile (512 threads)
 };
 
-template <int MH, int EPI, bool SWAP>
+template <int MH, int EPI, int AMODE, bool SWAP>
 __device__ __forceinline__ void gemm256_body(const UdGemm& p, char* smem, int m0, int n0, const half_t* A, const half_t* W,
                                              const float* bias, char* out, char* out2) {
   using C = BigCfg<MH>;
@@ -405,11 +405,23 @@ __device__ __forceinline__ void gemm256_body(const UdGemm& p, char* smem, int m0
   const int csrc = (tid & 7) ^ ((lrow >> 1) & 7);
   const half_t* pa[C::A_LOADS];
   const half_t* pb[4];
+  ConvLane cl[C::A_LOADS];
+  const float inv_cc = (AMODE != UD_A_DENSE) ? 1.0f / (float)(p.Cin >> 3) : 0.0f;
 #pragma unroll
   for (int i = 0; i < C::A_LOADS; ++i) {
     int m = m0 + lrow + 64 * i;
     m = m < p.M ? m : p.M - 1;
-    pa[i] = A + (size_t)m * p.lda + csrc * 8;
+    if constexpr (AMODE == UD_A_DENSE) {
+      pa[i] = A + (size_t)m * p.lda + csrc * 8;
+    } else {
+      const int img = m / p.rows_img;
+      const int pp = m - img * p.rows_img;
+      const int y = pp / p.Wimg;
+      cl[i].base = (long long)img * p.img_stride;
+      cl[i].y = y;
+      cl[i].x = pp - y * p.Wimg;
+      cl[i].valid = pp < p.Himg * p.Wimg;
+    }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -419,8 +431,30 @@ __device__ __forceinline__ void gemm256_body(const UdGemm& p, char* smem, int m0
   }
   auto issue = [&](int kt) {
     char* sb = smem + (kt & 1) * C::STAGE + wv * 1024;
+    if constexpr (AMODE == UD_A_DENSE) {
 #pragma unroll
-    for (int i = 0; i < C::A_LOADS; ++i) ud_glds16(pa[i] + kt * 64, sb + i * 8192);
+      for (int i = 0; i < C::A_LOADS; ++i) ud_glds16(pa[i] + kt * 64, sb + i * 8192);
+    } else {
+      // implicit-GEMM gather: this lane's 16-byte chunk = 8 channels of tap (kc / (Cin/8)); one tap decode per K-tile
+      const int kc = kt * 8 + csrc;
+      const int tap = (int)(((float)kc + 0.5f) * inv_cc);
+      const int cch = (kc - tap * (p.Cin >> 3)) << 3;
+      const int t3 = (tap * 11) >> 5;
+      const int dy = t3 - 1, dx = tap - t3 * 3 - 1;
+#pragma unroll
+      for (int i = 0; i < C::A_LOADS; ++i) {
+        int yy = cl[i].y + dy, xx = cl[i].x + dx;
+        bool ok = cl[i].valid && tap < 9;
+        if constexpr (AMODE == UD_A_CONV3_ZERO) {
+          ok = ok && (unsigned)yy < (unsigned)p.Himg && (unsigned)xx < (unsigned)p.Wimg;
+        } else {
+          yy = yy < 0 ? -yy : (yy >= p.Himg ? 2 * p.Himg - 2 - yy : yy);
+          xx = xx < 0 ? -xx : (xx >= p.Wimg ? 2 * p.Wimg - 2 - xx : xx);
+        }
+        const half_t* src = ok ? A + cl[i].base + ((long long)(yy * p.Wimg + xx)) * p.cstride + p.coff + cch : (const half_t*)p.zeros;
+        ud_glds16(src, sb + i * 8192);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) ud_glds16(pb[i] + kt * 64, sb + C::A_BYTES + i * 8192);
   };
@@ -497,7 +531,7 @@ __device__ __forceinline__ void gemm256_body(const UdGemm& p, char* smem, int m0
   gemm_epilogue<2 * MH, 4, EPI, SWAP>(p, acc, m0 + wm * (C::BM / 2), n0 + wn * 64, lane, bias, out, out2, nullptr, 0.f, 0.f, stage);
 }
 
-template <int MH, int EPI>
+template <int MH, int EPI, int AMODE>
 __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = BigCfg<MH>::BM;
@@ -524,27 +558,27 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   const half_t* W = (const half_t*)p.W;
   if constexpr (EPI == UD_EPI_QKV) {
     if (n0 >= p.vsplit) {
-      gemm256_body<MH, EPI, false>(p, smem, m0, n0, A, W, p.bias, (char*)p.out, (char*)p.out2);
+      gemm256_body<MH, EPI, AMODE, false>(p, smem, m0, n0, A, W, p.bias, (char*)p.out, (char*)p.out2);
       return;
     }
   }
-  gemm256_body<MH, EPI, true>(p, smem, m0, n0, A, W, p.bias, (char*)p.out, (char*)p.out2);
+  gemm256_body<MH, EPI, AMODE, true>(p, smem, m0, n0, A, W, p.bias, (char*)p.out, (char*)p.out2);
 }
 
-template <int MH, int EPI>
+template <int MH, int EPI, int AMODE>
 int launch256(const UdGemm& d, hipStream_t s) {
   constexpr int BM = BigCfg<MH>::BM;
   const int tiles = ((d.N + 255) >> 8) * ((d.M + BM - 1) / BM);
   const int lds = 2 * BigCfg<MH>::STAGE;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)gemm256_kernel<MH, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)gemm256_kernel<MH, EPI, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       ud_set_error("ud_gemm_f16: cannot reserve the LDS ring of the large-tile kernel");
       return UD_ERR_LAUNCH;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm256_kernel<MH, EPI>), dim3(tiles), dim3(512), lds, s, d);
+  hipLaunchKernelGGL((gemm256_kernel<MH, EPI, AMODE>), dim3(tiles), dim3(512), lds, s, d);
   UD_CHECK_LAUNCH("ud_gemm_f16 (large tile) launch");
   return UD_OK;
 }
@@ -554,7 +588,8 @@ int launch256(const UdGemm& d, hipStream_t s) {
 // small or just above a multiple of 256 CUs; the 128x128 kernel runs two workgroups per CU, so its rounds quantise in halves.
 // Returns 0 (128x128), 3 (192x256) or 4 (256x256).
 inline int pick_tiles(const UdGemm& d) {
-  if (d.amode != UD_A_DENSE || d.groups > 1 || d.M < 1024 || d.N < 256 || (d.K & 63)) return 0;
+  if (d.amode == UD_A_CONV3_REFLECT || d.groups > 1 || d.M < 1024 || d.N < 256 || (d.K & 63)) return 0;
+  if (d.amode == UD_A_CONV3_ZERO && d.epi != UD_EPI_F16 && d.epi != UD_EPI_F32) return 0;
   if (d.epi == UD_EPI_QKV && (d.vsplit & 255)) return 0;
   if (d.tile_hint == 1) return 0;
   if (d.tile_hint == 2) return 4;
@@ -570,9 +605,9 @@ inline int pick_tiles(const UdGemm& d) {
   return t256 <= t192 ? 4 : 3;
 }
 
-template <int EPI>
+template <int EPI, int AMODE = UD_A_DENSE>
 int launch_big(const UdGemm& d, hipStream_t s, int which) {
-  return which == 3 ? launch256<3, EPI>(d, s) : launch256<4, EPI>(d, s);
+  return which == 3 ? launch256<3, EPI, AMODE>(d, s) : launch256<4, EPI, AMODE>(d, s);
 }
 
 template <class C, int EPI, int AMODE>
@@ -638,13 +673,15 @@ extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
     return launch<Cfg<32, 32, 32>, UD_EPI_HEAD, UD_A_CONV3_REFLECT>(d, s);
   }
   if (d.epi == UD_EPI_F16) {
-    if (const int bt = pick_tiles(d)) return launch_big<UD_EPI_F16>(d, s, bt);
+    if (const int bt = pick_tiles(d))
+      return d.amode == UD_A_DENSE ? launch_big<UD_EPI_F16>(d, s, bt) : launch_big<UD_EPI_F16, UD_A_CONV3_ZERO>(d, s, bt);
     if (d.amode == UD_A_DENSE) return dispatch_bn<UD_EPI_F16, UD_A_DENSE>(d, s);
     if (d.amode == UD_A_CONV3_ZERO) return dispatch_bn<UD_EPI_F16, UD_A_CONV3_ZERO>(d, s);
     return dispatch_bn<UD_EPI_F16, UD_A_CONV3_REFLECT>(d, s);
   }
   if (d.epi == UD_EPI_F32) {
-    if (const int bt = pick_tiles(d)) return launch_big<UD_EPI_F32>(d, s, bt);
+    if (const int bt = pick_tiles(d))
+      return d.amode == UD_A_DENSE ? launch_big<UD_EPI_F32>(d, s, bt) : launch_big<UD_EPI_F32, UD_A_CONV3_ZERO>(d, s, bt);
     if (d.amode == UD_A_DENSE) return dispatch_bn<UD_EPI_F32, UD_A_DENSE>(d, s);
     if (d.amode == UD_A_CONV3_ZERO) return dispatch_bn<UD_EPI_F32, UD_A_CONV3_ZERO>(d, s);
   }
