@@ -55,7 +55,8 @@ typedef struct UdGemm {
   const float* w2;        /* UD_EPI_HEAD: [N] second-layer (1x1 conv) weights */
   int M, N, K;            /* K = padded reduction length (multiple of 64) */
   int lda, ldw, ldc, ldc2, ldadd;
-  int amode, epi, act, act2, accumulate;
+  int amode, epi, act, act2;
+  int accumulate;         /* UD_EPI_F32: 0 = overwrite, 1 = out += result, 2 = result = out + acc but only the fp16 copy out2 is written */
   int rows_in, rows_out, row_off, add_row_off;   /* output row = (m / rows_in) * rows_out + (m % rows_in) + row_off; rows_in = 0 -> identity */
   /* conv A-modes: row m -> image m / rows_img, pixel p = m % rows_img (valid if p < Himg*Wimg) */
   int Himg, Wimg, Cin, cstride, coff, rows_img;

@@ -168,6 +168,33 @@ def test_gemm_conv3x3(ops, mode, Cin, Cout, H, W, rows_pad):
     assert rel(out.view(B, rows_img, Cout)[:, :H * W].float(), ref) < 1e-3
 
 
+@pytest.mark.parametrize("mode,Cin,Cout,H,W,G", [(1, 128, 64, 37, 21, 1), (2, 128, 64, 40, 33, 2), (2, 64, 32, 16, 16, 2), (1, 64, 32, 50, 19, 1)])
+def test_conv3x3_halo_tile_kernel(ops, mode, Cin, Cout, H, W, G):
+    """narrow-output 3x3 conv (halo-tile kernel: input staged once per 16x16 tile) incl. groups, channel offsets, edges."""
+    B = 2
+    cstride = G * Cin
+    x = rnd(B, H * W, cstride, seed=1).half()
+    wt = rnd(G, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=2)
+    bias = rnd(G, Cout, seed=3)
+    Wg = wt.permute(0, 1, 3, 4, 2).reshape(G, Cout, 9 * Cin).contiguous().half()
+    zeros = torch.zeros(256, dtype=torch.half, device="cuda")
+    M = B * H * W
+    out = torch.zeros(G, M, Cout, dtype=torch.half, device="cuda")
+    ops.gemm(A=x, W=Wg, bias=bias, out=out, zeros=zeros, M=M, N=Cout, K=9 * Cin, ldw=9 * Cin, ldc=Cout, amode=mode, epi=ops.UD_EPI_F16,
+             act=ops.UD_ACT_LRELU, Himg=H, Wimg=W, Cin=Cin, cstride=cstride, coff=0, rows_img=H * W, img_stride=H * W * cstride,
+             groups=G, gA=Cin, gW=Cout * 9 * Cin, gBias=Cout, gOut=M * Cout)
+    torch.cuda.synchronize()
+    for g in range(G):
+        xin = x[:, :, g * Cin:(g + 1) * Cin].float().view(B, H, W, Cin).permute(0, 3, 1, 2)
+        wref = Wg[g].float().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+        if mode == 2:
+            ref = F.conv2d(F.pad(xin, (1, 1, 1, 1), mode="reflect"), wref, bias[g])
+        else:
+            ref = F.conv2d(xin, wref, bias[g], padding=1)
+        ref = F.leaky_relu(ref, 0.01).permute(0, 2, 3, 1).reshape(M, Cout)
+        assert rel(out[g].float(), ref) < 1e-3, g
+
+
 @pytest.mark.parametrize("hint,Cin,Cout,H,W", [(2, 64, 256, 37, 37), (3, 128, 512, 30, 41), (2, 256, 256, 20, 20)])
 def test_gemm_conv3x3_big_tiles(ops, hint, Cin, Cout, H, W):
     """implicit-GEMM 3x3 conv (zero padding) through the large-tile kernels, fp16 and fp32-accumulate epilogues."""

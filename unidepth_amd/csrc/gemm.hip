@@ -203,7 +203,7 @@ __device__ __forceinline__ void gemm_epilogue(const UdGemm& p, f32x4 (&acc)[TM][
             const f32x4 old = *(const f32x4*)dst;
             v += old;
           }
-          *(f32x4*)dst = v;
+          if (p.accumulate != 2) *(f32x4*)dst = v;     // accumulate == 2: the fp32 stream dies here, only the fp16 copy is consumed
           if (out2) {
             half4 h;
 #pragma unroll
@@ -610,6 +610,165 @@ int launch_big(const UdGemm& d, hipStream_t s, int which) {
   return which == 3 ? launch256<3, EPI, AMODE>(d, s) : launch256<4, EPI, AMODE>(d, s);
 }
 
+// ================================================================================================================
+// Halo-tile 3x3 convolution for narrow outputs (N <= 64: the two head convolutions, decoder.py:199-226).
+// The implicit-GEMM kernels above re-gather every input pixel once per tap (9x) through L2 -> LDS; with N <= 64 there is so
+// little MFMA work per gathered byte that they are bound by that traffic (measured 346 / 517 TFLOP/s).  Here a workgroup owns
+// a 16 x 16 output tile: the 18 x 18 x 64-channel input halo is DMA'd into LDS once per 64-channel chunk and the 9 taps
+// read it in place (shifted fragment addresses); only the per-tap [N][64] weight slab streams (double buffered).
+// 4 waves, wave w = output rows 4w..4w+3 (one 16-pixel MFMA m-tile per row), v_mfma_f32_16x16x32_f16, swapped operands.
+// ================================================================================================================
+constexpr int HALO_BYTES = 41 * 1024;          // 328 pixel slots x 128 B (324 used)
+
+template <int NT, int EPI, bool REFLECT>
+__global__ __launch_bounds__(256) void conv_tile_kernel(const UdGemm p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;
+  char* wbuf = smem + HALO_BYTES;
+  constexpr int WB = NT * 16 * 128;             // bytes per weight buffer
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_x = (p.Wimg + 15) >> 4;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int x0 = tx << 4, y0 = ty << 4;
+  const int b = blockIdx.y, g = blockIdx.z;
+  const half_t* in = (const half_t*)p.A + (long long)g * p.gA + (long long)b * p.img_stride + p.coff;
+  const half_t* W = (const half_t*)p.W + (long long)g * p.gW;
+  const float* bias = p.bias + (long long)g * p.gBias;
+
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto issue_halo = [&](int cc) {
+#pragma unroll
+    for (int j = 0; j < 11; ++j) {
+      const int i = wv + 4 * j;                  // wave-instruction index (uniform)
+      if (i < 41) {
+        const int idx = i * 64 + lane;
+        const int hp = idx >> 3, cpos = idx & 7;
+        const int hy = hp / 18, hx = hp - hy * 18;
+        int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        bool ok = hp < 324;
+        if constexpr (REFLECT) {
+          iy = iy < 0 ? -iy : (iy >= p.Himg ? 2 * p.Himg - 2 - iy : iy);
+          ix = ix < 0 ? -ix : (ix >= p.Wimg ? 2 * p.Wimg - 2 - ix : ix);
+          ok = ok && iy >= 0 && ix >= 0;         // tile overhang beyond the reflected border: unused outputs
+        } else {
+          ok = ok && (unsigned)iy < (unsigned)p.Himg && (unsigned)ix < (unsigned)p.Wimg;
+        }
+        const half_t* src = ok ? in + ((long long)iy * p.Wimg + ix) * p.cstride + cc * 64 + ((cpos ^ ((hp >> 1) & 7)) << 3)
+                               : (const half_t*)p.zeros;
+        ud_glds16(src, halo + i * 1024);
+      }
+    }
+  };
+  auto issue_w = [&](int tap, int cc, int buf) {
+#pragma unroll
+    for (int j = 0; j < NT / 2; ++j) {
+      const int i = wv * (NT / 2) + j;
+      const int idx = i * 64 + lane;
+      const int n = idx >> 3, cpos = idx & 7;
+      ud_glds16(W + (size_t)n * p.ldw + tap * p.Cin + cc * 64 + ((cpos ^ ((n >> 1) & 7)) << 3), wbuf + buf * WB + i * 1024);
+    }
+  };
+
+  const int px = lane & 15, fq = lane >> 4;
+  const int nchunks = p.Cin >> 6;
+  for (int cc = 0; cc < nchunks; ++cc) {
+    __syncthreads();                              // previous chunk fully consumed
+    issue_halo(cc);
+    issue_w(0, cc, 0);
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tap < 8) issue_w(tap + 1, cc, (tap + 1) & 1);
+      const int t3 = (tap * 11) >> 5;
+      const int dy = t3, dx = tap - t3 * 3;       // halo coordinates already include the -1 offset
+      const char* wb = wbuf + (tap & 1) * WB;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        half8 af[4], bf[NT];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int hp = (wv * 4 + i + dy) * 18 + px + dx;
+          af[i] = *(const half8*)(halo + hp * 128 + (((ks * 4 + fq) ^ ((hp >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int n = j * 16 + px;
+          bf[j] = *(const half8*)(wb + n * 128 + (((ks * 4 + fq) ^ ((n >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: lane owns pixel (y0 + 4*wv + i, x0 + px), channels j*16 + 4*fq .. +3
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int y = y0 + wv * 4 + i, x = x0 + px;
+    const bool ok = y < p.Himg && x < p.Wimg;
+    const size_t row = ((size_t)b * p.Himg + y) * p.Wimg + x;
+    if constexpr (EPI == UD_EPI_HEAD) {
+      const float* w2 = p.w2 + (long long)g * p.gW2;
+      float part = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int nb = j * 16 + 4 * fq;
+        const f32x4 bv = *(const f32x4*)(bias + nb);
+        const f32x4 wv2 = *(const f32x4*)(w2 + nb);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part += ud_lrelu(acc[i][j][r] + bv[r]) * wv2[r];
+      }
+      part += __shfl_xor(part, 16, 64);
+      part += __shfl_xor(part, 32, 64);
+      if (ok && fq == 0) {
+        float yv = part + (g == 0 ? p.b2 : p.b2_g1);
+        yv = fminf(fmaxf(yv, -8.0f), 8.0f);
+        ((float*)p.out)[(long long)g * p.gOut + row] = __expf(yv + (g == 0 ? p.post_add : p.post_add_g1));
+      }
+    } else {
+      if (ok) {
+        half_t* o = (half_t*)p.out + (long long)g * p.gOut + row * p.ldc;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int nb = j * 16 + 4 * fq;
+          const f32x4 bv = *(const f32x4*)(bias + nb);
+          half4 h;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[r] = (half_t)ud_act(acc[i][j][r] + bv[r], p.act);
+          *(half4*)(o + nb) = h;
+        }
+      }
+    }
+  }
+}
+
+template <int NT, int EPI, bool REFLECT>
+int launch_conv_tile(const UdGemm& d, hipStream_t s) {
+  const int lds = HALO_BYTES + 2 * NT * 16 * 128;
+  const int B = d.M / d.rows_img;
+  dim3 grid(((d.Wimg + 15) >> 4) * ((d.Himg + 15) >> 4), B, d.groups > 0 ? d.groups : 1);
+  hipLaunchKernelGGL((conv_tile_kernel<NT, EPI, REFLECT>), grid, dim3(256), lds, s, d);
+  UD_CHECK_LAUNCH("ud_gemm_f16 (halo-tile conv) launch");
+  return UD_OK;
+}
+
+// eligibility: dense images (rows_img == H*W), N in {32, 64}, Cin multiple of 64, weights laid out [N][tap*Cin + ci]
+inline bool conv_tile_ok(const UdGemm& d) {
+  return d.amode != UD_A_DENSE && (d.N == 32 || d.N == 64) && (d.Cin & 63) == 0 && d.rows_img == d.Himg * d.Wimg &&
+         d.M % d.rows_img == 0 && d.bias != nullptr && d.tile_hint != 1 && d.Himg >= 2 && d.Wimg >= 2 &&
+         (d.epi == UD_EPI_HEAD || (d.epi == UD_EPI_F16 && d.rows_in == 0 && d.add == nullptr && (d.ldc & 3) == 0));
+}
+
 template <class C, int EPI, int AMODE>
 int launch(const UdGemm& d, hipStream_t s) {
   const int tiles_n = (d.N + C::BN - 1) / C::BN;
@@ -670,9 +829,14 @@ extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
       ud_set_error("ud_gemm_f16: HEAD epilogue needs reflect conv, N == 32");
       return UD_ERR_BAD_ARG;
     }
+    if (conv_tile_ok(d)) return launch_conv_tile<2, UD_EPI_HEAD, true>(d, s);
     return launch<Cfg<32, 32, 32>, UD_EPI_HEAD, UD_A_CONV3_REFLECT>(d, s);
   }
   if (d.epi == UD_EPI_F16) {
+    if (conv_tile_ok(d)) {
+      if (d.amode == UD_A_CONV3_REFLECT) return d.N == 64 ? launch_conv_tile<4, UD_EPI_F16, true>(d, s) : launch_conv_tile<2, UD_EPI_F16, true>(d, s);
+      return d.N == 64 ? launch_conv_tile<4, UD_EPI_F16, false>(d, s) : launch_conv_tile<2, UD_EPI_F16, false>(d, s);
+    }
     if (const int bt = pick_tiles(d))
       return d.amode == UD_A_DENSE ? launch_big<UD_EPI_F16>(d, s, bt) : launch_big<UD_EPI_F16, UD_A_CONV3_ZERO>(d, s, bt);
     if (d.amode == UD_A_DENSE) return dispatch_bn<UD_EPI_F16, UD_A_DENSE>(d, s);

@@ -246,7 +246,7 @@ class _Plan:
                 P.gemm(A=l16, W=w[f"dh.ups.{i}.{c}.conv1.w"], bias=w[f"dh.ups.{i}.{c}.conv1.b"], out=t16, ldc=cur, epi=UD_EPI_F16,
                        act=UD_ACT_LRELU, **conv)
                 P.gemm(A=t16, W=w[f"dh.ups.{i}.{c}.conv2.w"], bias=w[f"dh.ups.{i}.{c}.conv2.b"], out=lat, out2=l16, ldc=cur, ldc2=cur,
-                       epi=UD_EPI_F32, accumulate=1, act2=UD_ACT_LRELU if c == 0 else UD_ACT_NONE, **conv)
+                       epi=UD_EPI_F32, accumulate=1 if c == 0 else 2, act2=UD_ACT_LRELU if c == 0 else UD_ACT_NONE, **conv)
             u = z(Ms, outd, dtype=f32)
             P.gemm(A=l16, W=w[f"dh.ups.{i}.up.w"], bias=w[f"dh.ups.{i}.up.b"], out=u, M=Ms, N=outd, K=_rup(cur, 64), lda=cur,
                    ldw=_rup(cur, 64), ldc=outd, epi=UD_EPI_F32)
