@@ -10,8 +10,9 @@ resident in HBM, seeded random-init ("sensitised") weights of the exact architec
 over RCCL; value = N * 8 images * K / max-over-ranks wall time.
 
 One JSON line on rank 0 with the driver contract fields plus
-  roofline     -- the dominant kernel (encoder MFMA GEMM, 128x128x64 tiles): algorithmic FLOP per launch / average launch
-                  duration measured live with HIP events on the launch stream, against the 2.5 PFLOP/s dense fp16 peak;
+  roofline     -- the dominant kernel class of the step (an MFMA GEMM instantiation, named as rocprofv3 prints it): algorithmic
+                  FLOP per launch / average launch duration measured live with HIP events on the launch stream, against the
+                  2.5 PFLOP/s dense fp16 peak; `traffic` = HBM bytes per launch from the committed PMC passes (profiles/);
   cpu_baseline -- the CPU oracle (fp32 restatement of the reference, oracle/restate.py) timed on this box's host cores on
                   a bounded sample (bs=2 of the same workload), rank 0 / N=1 only.
 """
@@ -174,12 +175,21 @@ def kernel_timing(model, fl, B, dump=""):
                      "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None,
                      "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
                  for k, v in sorted(tot.items(), key=lambda kv: -kv[1]["ms"])}
+    # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the json)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if os.path.exists(tpath):
+        short = dom.replace("Cfg<", "(anonymous namespace)::Cfg<")
+        for name, rec in json.load(open(tpath))["kernels"].items():
+            if short in name:
+                traffic = rec["hbm_total_bytes"]
     return {
-        "roofline": {"bound": "mfma", "kernel": dom + " (gemm_kernel<128x128x64>, v_mfma_f32_16x16x32_f16)",
+        "roofline": {"bound": "mfma", "kernel": dom + " (v_mfma_f32_16x16x32_f16)",
                      "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                      "flop_per_launch": round(d["flops"] / d["launches"], 1),
-                     "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 3)},
+                     "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 3),
+                     "algorithmic_bytes_per_launch": None},
         "roofline_enc_attention_mlp": {"achieved": round(enc_fl / (enc_ms * 1e-3) / 1e12, 2), "peak": MFMA_PEAK_TFLOPS,
                                        "unit": "TFLOP/s", "frac": round(enc_fl / (enc_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
                                        "ms_per_step": round(enc_ms, 4)},

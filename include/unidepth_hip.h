@@ -76,6 +76,8 @@ typedef struct UdGemm {
 } UdGemm;
 
 int ud_gemm_f16(const UdGemm* desc, void* stream);
+/* kernel the call above would pick (profiling labels): 0/1/2 = 128-row tiles with BN 128/64/32, 3 = 192x256, 4 = 256x256, 5 = halo-tile conv */
+int ud_gemm_pick(const UdGemm* desc);
 
 /* ---- LayerNorm (statistics only; the affine is folded into the consumer's weights at load time) ----
  * y(fp16)[orow, :] = (x[irow, :] - mean) * rsqrt(var + eps), biased variance (F.layer_norm).
@@ -113,7 +115,7 @@ int ud_attention_small_f32(const float* q, const float* kv, float* out, int B, i
  * O = softmax(Q K^T * scale) V per (image, head).  Replaces F.scaled_dot_product_attention at
  * metadinov2/attention.py:58 and layers/attention.py:136-138 (and xformers memory_efficient_attention :77).
  * Q [img*q_rows_per_img + i, h*64 + d] (ldq), K likewise (ldk), Vt = V^T [img][h][64][kv_ld], O like Q (ldo).
- * kv_img_stride_zero != 0: all images share image 0's K/V (single GT camera broadcast, decoder.py:400). */
+ * kv_broadcast != 0: groups of kv_group consecutive images share one K/V image (single GT camera, decoder.py:400). */
 typedef struct UdAttention {
   const void* Q; const void* K; const void* Vt; void* O;
   int B, H, Nq, Nk;
@@ -121,6 +123,7 @@ typedef struct UdAttention {
   int q_rows_per_img, k_rows_per_img;
   float scale;
   int kv_broadcast;
+  int kv_group;           /* with kv_broadcast: image i uses the K/V of image i / kv_group (0 -> all share image 0) */
 } UdAttention;
 int ud_attention_f16(const UdAttention* desc, void* stream);
 

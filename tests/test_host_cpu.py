@@ -74,16 +74,16 @@ def test_weight_folding_algebra_matches_oracle_blocks():
     orc = restate.OracleV2(cfg, sd)
     xq, ctx = torch.randn(2, 7, C), torch.randn(2, 5, C)
     want = orc._attn_block(xq, "pixel_decoder.depth_layer.prompt_camera.1.layers.0", context=ctx, layer_scale=False)
-    pre = "dh.1."
+    g = lambda name: w["dhg." + name][1]          # block 1 of the stacked (grouped-launch) weights
     hd = C // H
-    q = F.linear(F.layer_norm(xq, (C,), eps=1e-5), w[pre + "q.w"].float()[:, :C], w[pre + "q.b"]).view(2, 7, H, 64).transpose(1, 2)
-    kv = F.linear(F.layer_norm(ctx, (C,), eps=1e-5), w[pre + "kv.w"].float()[:, :C], w[pre + "kv.b"])
+    q = F.linear(F.layer_norm(xq, (C,), eps=1e-5), g("q.w").float()[:, :C], g("q.b")).view(2, 7, H, 64).transpose(1, 2)
+    kv = F.linear(F.layer_norm(ctx, (C,), eps=1e-5), g("kv.w").float()[:, :C], g("kv.b"))
     k = kv[..., : H * 64].view(2, 5, H, 64).transpose(1, 2)
     v = kv[..., H * 64:].view(2, 5, H, 64).transpose(1, 2)
     o = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v
-    y = xq + F.linear(o.transpose(1, 2).reshape(2, 7, H * 64), w[pre + "out.w"].float())
-    hmid = F.gelu(F.linear(F.layer_norm(y, (C,), eps=1e-5), w[pre + "fc1.w"].float(), w[pre + "fc1.b"]))
-    y = y + F.linear(hmid, w[pre + "fc2.w"].float(), w[pre + "fc2.b"])
+    y = xq + F.linear(o.transpose(1, 2).reshape(2, 7, H * 64), g("out.w").float())
+    hmid = F.gelu(F.linear(F.layer_norm(y, (C,), eps=1e-5), g("fc1.w").float(), g("fc1.b")))
+    y = y + F.linear(hmid, g("fc2.w").float(), g("fc2.b"))
     assert (y - want).norm() / want.norm() < 3e-3
 
 

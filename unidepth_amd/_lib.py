@@ -48,7 +48,7 @@ class UdLinearF32(C.Structure):
 class UdAttention(C.Structure):
     _fields_ = [("Q", vp), ("K", vp), ("Vt", vp), ("O", vp), ("B", i32), ("H", i32), ("Nq", i32), ("Nk", i32),
                 ("ldq", i32), ("ldk", i32), ("ldo", i32), ("kv_ld", i32), ("q_rows_per_img", i32),
-                ("k_rows_per_img", i32), ("scale", f32), ("kv_broadcast", i32)]
+                ("k_rows_per_img", i32), ("scale", f32), ("kv_broadcast", i32), ("kv_group", i32)]
 
 
 class UdPreprocess(C.Structure):
@@ -87,6 +87,7 @@ def _load():
     P = C.POINTER
     sig = {
         "ud_gemm_f16": [P(UdGemm), vp],
+        "ud_gemm_pick": [P(UdGemm)],
         "ud_layernorm_f32_f16": [P(UdLayerNorm), vp],
         "ud_attention_f16": [P(UdAttention), vp],
         "ud_linear_f32": [P(UdLinearF32), vp],

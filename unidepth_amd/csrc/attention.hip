@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const UdAttention p, con
   const int ql = lane & 31;
   const int head = blockIdx.y;
   const int img = blockIdx.z;
-  const int kimg = p.kv_broadcast ? 0 : img;
+  const int kimg = p.kv_broadcast ? (p.kv_group > 0 ? img / p.kv_group : 0) : img;
   const int q0 = blockIdx.x * 128 + wv * 32;
 
   const half_t* Q = (const half_t*)p.Q;

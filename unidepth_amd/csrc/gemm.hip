@@ -852,3 +852,15 @@ extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
   ud_set_error("ud_gemm_f16: unsupported epi/amode combination");
   return UD_ERR_UNSUPPORTED;
 }
+
+// Which kernel ud_gemm_f16 would launch for this descriptor (for profiling labels): 0/1/2 = 128-row kernels with BN 128/64/32,
+// 3 = 192x256 tiles, 4 = 256x256 tiles, 5 = halo-tile conv.
+extern "C" int ud_gemm_pick(const UdGemm* desc) {
+  const UdGemm& d = *desc;
+  if (conv_tile_ok(d) && (d.epi == UD_EPI_HEAD || d.epi == UD_EPI_F16)) return 5;
+  if (d.epi != UD_EPI_HEAD) {
+    const int bt = pick_tiles(d);
+    if (bt) return bt;
+  }
+  return d.N > 64 ? 0 : (d.N > 32 ? 1 : 2);
+}

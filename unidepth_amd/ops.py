@@ -78,9 +78,18 @@ class Program:
     def gemm(self, **kw):
         g = max(1, kw.get("groups", 0))
         n = kw["N"]
-        cls = "gemm%s_bn%d" % ({0: "", 1: "_conv", 2: "_conv"}[kw.get("amode", 0)], 128 if n > 64 else (64 if n > 32 else 32))
-        self._k(kw, cls, 2.0 * kw["M"] * n * kw["K"] * g)
-        return check(lib.ud_program_add_gemm(self.h, C.byref(mk(UdGemm, **kw))))
+        tag, flops = kw.pop("tag", None), kw.pop("flops", 2.0 * kw["M"] * n * kw["K"] * g)
+        d = mk(UdGemm, **kw)
+        pick, epi, amode = lib.ud_gemm_pick(C.byref(d)), kw.get("epi", 0), kw.get("amode", 0)
+        if pick <= 2:       # names as rocprofv3 prints them (template arguments), so profiles and bench lines can be joined
+            cls = "gemm_kernel<Cfg<%s>, %d, %d>" % (("128, 64, 64", "64, 64, 32", "32, 32, 32")[pick], epi, amode)
+        elif pick <= 4:
+            cls = "gemm256_kernel<%d, %d, %d>" % (pick, epi, amode)
+        else:
+            cls = "conv_tile_kernel<%d, %d, %s>" % (n // 16, epi, "true" if amode == 2 else "false")
+        self.keep.extend(v for v in kw.values() if isinstance(v, torch.Tensor))
+        self.meta.append((cls, tag or cls, float(flops), 0.0))
+        return check(lib.ud_program_add_gemm(self.h, C.byref(d)))
 
     def layernorm(self, **kw):
         self._k(kw, "layernorm", 0.0, 6.0 * kw["rows"] * kw["D"])

@@ -118,7 +118,8 @@ class _Plan:
         vt = z(B, heads, 64, Nkp)
         ao = z(M, D)
         hid = z(M, 4 * D)
-        featn = [z(B * hwp, D) for _ in range(4)]
+        featn_all = z(4, B * hwp, D)                                  # stacked: the 4 levels are processed by grouped launches
+        featn = [featn_all[j] for j in range(4)]
         clsn = [z(_rup(B, 8), D, dtype=f32) for _ in range(4)]       # final-LN'd cls tokens stay fp32: they feed the fp32 camera head
         self.enc_first = len(P)
         lvl = 0
@@ -148,11 +149,11 @@ class _Plan:
 
         # ---------------- decoder: adapters (decoder.py:418,434-435)
         Md = B * hwp
-        feat = [z(Md, C, dtype=f32) for _ in range(4)]
+        feat_all = z(4, Md, C, dtype=f32)
         ct = z(B * 4, C, dtype=f32)
+        P.gemm(A=featn_all, W=w["dec.adapterg.w"], bias=w["dec.adapterg.b"], out=feat_all, M=Md, N=C, K=D, lda=D, ldw=D, ldc=C,
+               epi=UD_EPI_F32, groups=4, gA=Md * D, gW=C * D, gBias=C, gOut=Md * C, tag="dec.adapters(x4)")
         for j in range(4):
-            P.gemm(A=featn[j], W=w[f"dec.adapter.{j}.w"], bias=w[f"dec.adapter.{j}.b"], out=feat[j], M=Md, N=C, K=D, lda=D, ldw=D,
-                   ldc=C, epi=UD_EPI_F32)
             P.linear_f32(x=clsn[j], W=w[f"dec.camadapter.{j}.w"], bias=w[f"dec.camadapter.{j}.b"], out=ct.data_ptr() + j * C * 4,
                          M=B, N=C, K=D, ldx=D, ldw=D, ldc=4 * C, tag="cam.adapter")
         # ---- camera head (decoder.py:48-114) on the 4 camera tokens per image: an fp32 island (UdLinearF32 explains why)
@@ -212,18 +213,30 @@ class _Plan:
         scales = (2.0 ** torch.linspace(0.0, math.log2(max(h, wg) // 2), steps=nbands)).to(dev)
         emb = z(nb * hwp, C)
         P.ray_embed(rays=self.rays, scales=scales, xhat=emb, nb=nb, Hn=Hn, Wn=Wn, h=h, w=wg, C=C, ldy=C, rows_per_img=hwp, eps=1e-5)
-        fn = z(Md, C); qd = z(Md, Hd * 64); kd = z(nb * hwp, Hd * 64); vtd = z(nb, Hd, 64, hwkp); aod = z(Md, Hd * 64); hidd = z(Md, 4 * C)
-        c16 = [z(Md, C) for _ in range(4)]
-        for j in range(4):
-            pre = f"dh.{j}."
-            ln(feat[j], fn, Md)
-            P.gemm(A=fn, W=w[pre + "q.w"], bias=w[pre + "q.b"], out=qd, M=Md, N=Hd * 64, K=C, lda=C, ldw=C, ldc=Hd * 64, epi=UD_EPI_F16)
-            P.gemm(A=emb, W=w[pre + "kv.w"], bias=w[pre + "kv.b"], out=kd, out2=vtd, M=nb * hwp, N=2 * Hd * 64, K=C, lda=C, ldw=C,
-                   ldc=Hd * 64, epi=UD_EPI_QKV, vsplit=Hd * 64, tok_per_img=hwp, kv_ld=hwkp, heads_v=Hd)
-            P.attention(Q=qd, K=kd, Vt=vtd, O=aod, B=B, H=Hd, Nq=hw, Nk=hw, ldq=Hd * 64, ldk=Hd * 64, ldo=Hd * 64, kv_ld=hwkp,
-                        q_rows_per_img=hwp, k_rows_per_img=hwp, scale=scale_d, kv_broadcast=int(nb == 1 and B > 1))
-            P.gemm(A=aod, W=w[pre + "out.w"], out=feat[j], M=Md, N=C, K=Hd * 64, lda=Hd * 64, ldw=Hd * 64, ldc=C, epi=UD_EPI_F32, accumulate=1)
-            mlp(pre, feat[j], Md, fn, hidd, out2=c16[j])
+        # the 4 blocks (one per encoder level) are independent: every step is ONE grouped launch (blockIdx.z = level)
+        HC = Hd * 64
+        Mk = nb * hwp
+        fn = z(4, Md, C); qd = z(4, Md, HC); kd = z(4, Mk, HC); vtd = z(4, nb, Hd, 64, hwkp); aod = z(4, Md, HC); hidd = z(4, Md, 4 * C)
+        c16_all = z(4, Md, C)
+        c16 = [c16_all[j] for j in range(4)]
+        G4 = dict(groups=4)
+        ln(feat_all, fn, 4 * Md)
+        P.gemm(A=fn, W=w["dhg.q.w"], bias=w["dhg.q.b"], out=qd, M=Md, N=HC, K=C, lda=C, ldw=C, ldc=HC, epi=UD_EPI_F16,
+               gA=Md * C, gW=HC * C, gBias=HC, gOut=Md * HC, tag="dh.q(x4)", **G4)
+        P.gemm(A=emb, W=w["dhg.kv.w"], bias=w["dhg.kv.b"], out=kd, out2=vtd, M=Mk, N=2 * HC, K=C, lda=C, ldw=C, ldc=HC, epi=UD_EPI_QKV,
+               vsplit=HC, tok_per_img=hwp, kv_ld=hwkp, heads_v=Hd, gA=0, gW=2 * HC * C, gBias=2 * HC, gOut=Mk * HC,
+               gOut2=nb * Hd * 64 * hwkp, tag="dh.kv(x4)", **G4)
+        bc = int(nb == 1 and B > 1)
+        P.attention(Q=qd, K=kd, Vt=vtd, O=aod, B=4 * B, H=Hd, Nq=hw, Nk=hw, ldq=HC, ldk=HC, ldo=HC, kv_ld=hwkp, q_rows_per_img=hwp,
+                    k_rows_per_img=hwp, scale=scale_d, kv_broadcast=bc, kv_group=B, tag="dh.attn(x4)")
+        P.gemm(A=aod, W=w["dhg.out.w"], out=feat_all, M=Md, N=C, K=HC, lda=HC, ldw=HC, ldc=C, epi=UD_EPI_F32, accumulate=1,
+               gA=Md * HC, gW=C * HC, gOut=Md * C, tag="dh.out(x4)", **G4)
+        ln(feat_all, fn, 4 * Md)
+        P.gemm(A=fn, W=w["dhg.fc1.w"], bias=w["dhg.fc1.b"], out=hidd, M=Md, N=4 * C, K=C, lda=C, ldw=C, ldc=4 * C, epi=UD_EPI_F16,
+               act=UD_ACT_GELU, gA=Md * C, gW=4 * C * C, gBias=4 * C, gOut=Md * 4 * C, tag="dh.fc1(x4)", **G4)
+        P.gemm(A=hidd, W=w["dhg.fc2.w"], bias=w["dhg.fc2.b"], out=feat_all, out2=c16_all, M=Md, N=C, K=4 * C, lda=4 * C, ldw=4 * C,
+               ldc=C, ldc2=C, epi=UD_EPI_F32, accumulate=1, gA=Md * 4 * C, gW=C * 4 * C, gBias=C, gOut=Md * C, gOut2=Md * C,
+               tag="dh.fc2(x4)", **G4)
         # ---------------- latents + 3 x (ConvT inject, 2 RCU, 1x1 + x2 up) (decoder.py:262-282; upsample.py:137-223)
         lat = z(Md, C, dtype=f32)
         P.gemm(A=c16[0], W=w["dh.to_latents.w"], bias=w["dh.to_latents.b"], out=lat, M=Md, N=C, K=C, lda=C, ldw=C, ldc=C, epi=UD_EPI_F32)

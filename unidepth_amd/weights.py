@@ -192,6 +192,11 @@ def pack(config: dict, sd: dict, device) -> dict:
     put32("dh.hr.b1", torch.stack([f[f"{dl}to_{br}_hr.0.bias"] for br in ("depth", "confidence")], 0))
     put32("dh.hr.w2", torch.stack([f[f"{dl}to_{br}_hr.2.weight"].reshape(32) for br in ("depth", "confidence")], 0))
     out["dh.hr.b2"] = [float(f[f"{dl}to_{br}_hr.2.bias"].reshape(())) for br in ("depth", "confidence")]
+    # the 4 camera-prompt blocks (and the 4 adapters) are independent -> stacked [4, N, K] copies for grouped launches
+    for name in ("q.w", "q.b", "kv.w", "kv.b", "out.w", "fc1.w", "fc1.b", "fc2.w", "fc2.b"):
+        out["dhg." + name] = torch.stack([out.pop(f"dh.{j}.{name}") for j in range(4)], 0).contiguous()
+    for name in ("w", "b"):
+        out["dec.adapterg." + name] = torch.stack([out.pop(f"dec.adapter.{j}.{name}") for j in range(4)], 0).contiguous()
     out["meta"] = dict(chans=chans, nd=nd, od=od, hd=hd)
     # host copies needed per input shape
     out["host.pos_embed"] = f[pe + "pos_embed"]
