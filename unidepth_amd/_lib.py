@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libunidepth_hip.so")
+LIB_PATH = os.environ.get("UNIDEPTH_HIP_LIB", os.path.join(_HERE, "libunidepth_hip.so"))   # env override: A/B two builds in one process tree
 
 UD_EPI_F16, UD_EPI_F32, UD_EPI_QKV, UD_EPI_D2S, UD_EPI_HEAD = 0, 1, 2, 3, 4
 UD_ACT_NONE, UD_ACT_GELU, UD_ACT_LRELU = 0, 1, 2

@@ -38,7 +38,28 @@ struct ConvLane {
 // acc[i][j] is the 16x16 MFMA accumulator of m-tile i / n-tile j of this wave's sub-tile whose origin is (mbase, nbase).
 // SWAP (default): lane owns m = mbase + 16i + (lane & 15), n = nbase + 16j + 4*(lane >> 4) + r.
 // !SWAP (V^T tiles): lane owns m = mbase + 16i + 4*(lane >> 4) + r, n = nbase + 16j + (lane & 15).
-template <int TM, int TN, int EPI, bool SWAP>
+// residual-as-accumulator-init: for `out += A W^T` epilogues the old fp32 values are loaded into the accumulators BEFORE the
+// K loop (overlapping the first operand DMA) instead of being re-read in the epilogue, where every tile of a one-round GEMM
+// would hit HBM at the same moment; the epilogue then only writes.
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_preload_acc(const UdGemm& p, f32x4 (&acc)[TM][TN], int mbase, int nbase, int lane, const char* out) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = mbase + i * 16 + (lane & 15);
+    int orow = m;
+    if (p.rows_in > 0) {
+      const int img = m / p.rows_in;
+      orow = img * p.rows_out + (m - img * p.rows_in) + p.row_off;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nb = nbase + j * 16 + 4 * (lane >> 4);
+      if (m < p.M && nb < p.N) acc[i][j] = *(const f32x4*)((const float*)out + (size_t)orow * p.ldc + nb);
+    }
+  }
+}
+
+template <int TM, int TN, int EPI, bool SWAP, bool PRELOADED = false>
 __device__ __forceinline__ void gemm_epilogue(const UdGemm& p, f32x4 (&acc)[TM][TN], int mbase, int nbase, int lane, const float* bias,
                                               char* out, char* out2, const float* w2, float b2, float post_add, char* stage) {
   if constexpr (!SWAP) {
@@ -199,9 +220,11 @@ __device__ __forceinline__ void gemm_epilogue(const UdGemm& p, f32x4 (&acc)[TM][
           *(half4*)((half_t*)out + (size_t)orow * p.ldc + nb) = h;
         } else if constexpr (EPI == UD_EPI_F32) {
           float* dst = (float*)out + (size_t)orow * p.ldc + nb;
-          if (p.accumulate) {
-            const f32x4 old = *(const f32x4*)dst;
-            v += old;
+          if constexpr (!PRELOADED) {
+            if (p.accumulate) {
+              const f32x4 old = *(const f32x4*)dst;
+              v += old;
+            }
           }
           if (p.accumulate != 2) *(f32x4*)dst = v;     // accumulate == 2: the fp32 stream dies here, only the fp16 copy is consumed
           if (out2) {
@@ -304,6 +327,10 @@ __device__ __forceinline__ void gemm_body(const UdGemm& p, char* smem, int m0, i
     for (int j = 0; j < C::TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   issue(0, 0);
+  constexpr bool PRE = (EPI == UD_EPI_F32) && SWAP;
+  if constexpr (PRE) {
+    if (p.accumulate) gemm_preload_acc<C::TM, C::TN>(p, acc, m0 + wm * C::WM, n0 + wn * C::WN, lane, out);
+  }
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -333,7 +360,7 @@ __device__ __forceinline__ void gemm_body(const UdGemm& p, char* smem, int m0, i
     __syncthreads();                       // every wave is done reading operand tiles: LDS becomes the store staging area
     stage = smem + wv * 9216;
   }
-  gemm_epilogue<C::TM, C::TN, EPI, SWAP>(p, acc, m0 + wm * C::WM, n0 + wn * C::WN, lane, bias, out, out2, w2, b2, post_add, stage);
+  gemm_epilogue<C::TM, C::TN, EPI, SWAP, PRE>(p, acc, m0 + wm * C::WM, n0 + wn * C::WN, lane, bias, out, out2, w2, b2, post_add, stage);
 }
 
 template <class C, int EPI, int AMODE>
@@ -482,6 +509,10 @@ __device__ __forceinline__ void gemm256_body(const UdGemm& p, char* smem, int m0
 
   half8 a0[MH], a1[MH], b0[4], b1[4];
   issue(0);
+  constexpr bool PRE = (EPI == UD_EPI_F32) && SWAP;
+  if constexpr (PRE) {
+    if (p.accumulate) gemm_preload_acc<2 * MH, 4>(p, acc, m0 + wm * (C::BM / 2), n0 + wn * 64, lane, out);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -528,7 +559,7 @@ __device__ __forceinline__ void gemm256_body(const UdGemm& p, char* smem, int m0
     __syncthreads();
     stage = smem + wv * 9216;
   }
-  gemm_epilogue<2 * MH, 4, EPI, SWAP>(p, acc, m0 + wm * (C::BM / 2), n0 + wn * 64, lane, bias, out, out2, nullptr, 0.f, 0.f, stage);
+  gemm_epilogue<2 * MH, 4, EPI, SWAP, PRE>(p, acc, m0 + wm * (C::BM / 2), n0 + wn * 64, lane, bias, out, out2, nullptr, 0.f, 0.f, stage);
 }
 
 template <int MH, int EPI, int AMODE>

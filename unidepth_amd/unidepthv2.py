@@ -277,14 +277,13 @@ class _Plan:
         nd, od = meta["nd"], meta["od"]
         Mh = B * gh * gw
         ldx = _rup(nd, 64)
-        dm = z(Mh, 2 * od)
-        P.gemm(A=xh, W=w["dh.mlp.w"], bias=w["dh.mlp.b"], out=dm, M=Mh, N=2 * od, K=ldx, lda=ldx, ldw=ldx, ldc=2 * od, epi=UD_EPI_F16)
         o2 = od // 2
         lr = z(2, Mh, o2)
         kp = w["dh.lr.w"].shape[2]
-        P.gemm(A=dm, W=w["dh.lr.w"], bias=w["dh.lr.b"], out=lr, zeros=zeros, M=Mh, N=o2, K=kp, ldw=kp, ldc=o2, amode=UD_A_CONV3_REFLECT,
-               epi=UD_EPI_F16, Himg=gh, Wimg=gw, Cin=od, cstride=2 * od, coff=0, rows_img=gh * gw, img_stride=gh * gw * 2 * od,
-               groups=2, gA=od, gW=o2 * kp, gBias=o2, gOut=Mh * o2)
+        # both branches read the same normalised map; their Linear layers live inside the composed conv filters (weights.py)
+        P.gemm(A=xh, W=w["dh.lr.w"], bias=w["dh.lr.b"], out=lr, zeros=zeros, M=Mh, N=o2, K=kp, ldw=kp, ldc=o2, amode=UD_A_CONV3_REFLECT,
+               epi=UD_EPI_F16, Himg=gh, Wimg=gw, Cin=nd, cstride=ldx, coff=0, rows_img=gh * gw, img_stride=gh * gw * ldx,
+               groups=2, gA=0, gW=o2 * kp, gBias=o2, gOut=Mh * o2, tag="dh.lr(mlp folded)", flops=2.0 * 2 * Mh * o2 * 9 * nd)
         hr = z(2, B * Hn * Wn, o2)
         P.resize_ac(in_=lr, out=hr, G=2, B=B, Hin=gh, Win=gw, Hout=Hn, Wout=Wn, C=o2)
         self.net = z(2, B, Hn, Wn, dtype=f32)              # [0] radius, [1] confidence at network resolution

@@ -181,12 +181,19 @@ def pack(config: dict, sd: dict, device) -> dict:
         put16(f"dh.ups.{i}.up.w", f[f"{dl}ups.{i}.up.0.weight"].reshape(outd, cur)); put32(f"dh.ups.{i}.up.b", f[f"{dl}ups.{i}.up.0.bias"])
     nd = 2 * C // 8            # channels of the x8 feature map
     od = max(nd, a["out_dim"])
-    wd, bd = _fold_ln(f[f"{dl}depth_mlp.2.1.weight"], f[f"{dl}depth_mlp.2.1.bias"], f[f"{dl}depth_mlp.2.0.weight"], f[f"{dl}depth_mlp.2.0.bias"])
-    wc, bc = _fold_ln(f[dl + "confidence_mlp.1.weight"], f[dl + "confidence_mlp.1.bias"], f[dl + "confidence_mlp.0.weight"], f[dl + "confidence_mlp.0.bias"])
-    put16("dh.mlp.w", torch.cat([wd, wc], 0)); put32("dh.mlp.b", torch.cat([bd, bc], 0))
-    lr_w = torch.stack([_padk(_conv3_rows(f[f"{dl}to_{br}_lr.weight"])) for br in ("depth", "confidence")], 0)
-    out["dh.lr.w"] = lr_w.to(torch.float16).contiguous().to(device)
-    put32("dh.lr.b", torch.stack([f[f"{dl}to_{br}_lr.bias"] for br in ("depth", "confidence")], 0))
+    # LN -> Linear -> 3x3 reflect conv has no non-linearity after the normalisation (decoder.py:186-188,199-212,297-298):
+    # the per-pixel Linear (with the LN affine folded in) is composed INTO the conv filter at load time,
+    #   W'[o, tap, ci] = sum_c Wconv[o, c, tap] Wlin[c, ci],   b'[o] = bconv[o] + sum_{c,tap} Wconv[o, c, tap] blin[c]
+    # (a constant bias map stays constant under reflect padding), so the device runs one conv on the normalised x8 map.
+    lr_w, lr_b = [], []
+    for br, mlp_pre in (("depth", f"{dl}depth_mlp.2"), ("confidence", f"{dl}confidence_mlp")):
+        wl, bl = _fold_ln(f[mlp_pre + ".1.weight"], f[mlp_pre + ".1.bias"], f[mlp_pre + ".0.weight"], f[mlp_pre + ".0.bias"])   # [od, nd]
+        wc, bc_ = f[f"{dl}to_{br}_lr.weight"].double(), f[f"{dl}to_{br}_lr.bias"].double()                                    # [o2, od, 3, 3]
+        wcomp = torch.einsum("ocyx,ci->oyxi", wc, wl.double()).reshape(wc.shape[0], -1)                                           # k = tap*nd + ci
+        bcomp = bc_ + torch.einsum("ocyx,c->o", wc, bl.double())
+        lr_w.append(_padk(wcomp.float())); lr_b.append(bcomp.float())
+    out["dh.lr.w"] = torch.stack(lr_w, 0).to(torch.float16).contiguous().to(device)
+    put32("dh.lr.b", torch.stack(lr_b, 0))
     hr_w = torch.stack([_padk(_conv3_rows(f[f"{dl}to_{br}_hr.0.weight"])) for br in ("depth", "confidence")], 0)
     out["dh.hr.w"] = hr_w.to(torch.float16).contiguous().to(device)
     put32("dh.hr.b1", torch.stack([f[f"{dl}to_{br}_hr.0.bias"] for br in ("depth", "confidence")], 0))
