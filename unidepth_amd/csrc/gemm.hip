@@ -59,9 +59,18 @@ __device__ __forceinline__ void gemm_preload_acc(const UdGemm& p, f32x4 (&acc)[T
   }
 }
 
-template <int TM, int TN, int EPI, bool SWAP, bool PRELOADED = false>
-__device__ __forceinline__ void gemm_epilogue(const UdGemm& p, f32x4 (&acc)[TM][TN], int mbase, int nbase, int lane, const float* bias,
-                                              char* out, char* out2, const float* w2, float b2, float post_add, char* stage) {
+template <int ACT>
+__device__ __forceinline__ float ud_act_t(float x) {
+  if constexpr (ACT == UD_ACT_GELU) return ud_gelu_erf(x);
+  else if constexpr (ACT == UD_ACT_LRELU) return ud_lrelu(x);
+  else return x;
+}
+
+// ACT = activation of the fp16 output (EPI_F16/QKV) or of the fp16 copy (EPI_F32/D2S), resolved ONCE per kernel by
+// gemm_epilogue below: a per-element switch on the runtime value compiled to ~700 scalar branches in the unrolled epilogue.
+template <int TM, int TN, int EPI, bool SWAP, bool PRELOADED, int ACT>
+__device__ __forceinline__ void gemm_epilogue_impl(const UdGemm& p, f32x4 (&acc)[TM][TN], int mbase, int nbase, int lane, const float* bias,
+                                                   char* out, char* out2, const float* w2, float b2, float post_add, char* stage) {
   if constexpr (!SWAP) {
     // V^T tiles of UD_EPI_QKV: lane owns tokens mb..mb+3 (one image: tok_per_img % 4 == 0) for column n.
     static_assert(EPI == UD_EPI_QKV, "non-swapped orientation only for V^T");
@@ -110,7 +119,7 @@ __device__ __forceinline__ void gemm_epilogue(const UdGemm& p, f32x4 (&acc)[TM][
               }
               half4 h;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) h[r] = (half_t)ud_act(v[r], p.act);
+              for (int r = 0; r < 4; ++r) h[r] = (half_t)ud_act_t<ACT>(v[r]);
               *(half4*)(stage + (il * 16 + (lane & 15)) * 144 + (j * 16 + 4 * (lane >> 4)) * 2) = h;
             }
           }
@@ -194,7 +203,7 @@ __device__ __forceinline__ void gemm_epilogue(const UdGemm& p, f32x4 (&acc)[TM][
           if (out2) {
             half4 h;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = (half_t)ud_act(v[r], p.act2);
+            for (int r = 0; r < 4; ++r) h[r] = (half_t)ud_act_t<ACT>(v[r]);
             *(half4*)((half_t*)out2 + pix * p.ldc2 + o) = h;
           }
         }
@@ -216,7 +225,7 @@ __device__ __forceinline__ void gemm_epilogue(const UdGemm& p, f32x4 (&acc)[TM][
         if constexpr (EPI == UD_EPI_F16 || EPI == UD_EPI_QKV) {
           half4 h;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) h[r] = (half_t)ud_act(v[r], p.act);
+          for (int r = 0; r < 4; ++r) h[r] = (half_t)ud_act_t<ACT>(v[r]);
           *(half4*)((half_t*)out + (size_t)orow * p.ldc + nb) = h;
         } else if constexpr (EPI == UD_EPI_F32) {
           float* dst = (float*)out + (size_t)orow * p.ldc + nb;
@@ -230,12 +239,28 @@ __device__ __forceinline__ void gemm_epilogue(const UdGemm& p, f32x4 (&acc)[TM][
           if (out2) {
             half4 h;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = (half_t)ud_act(v[r], p.act2);
+            for (int r = 0; r < 4; ++r) h[r] = (half_t)ud_act_t<ACT>(v[r]);
             *(half4*)((half_t*)out2 + (size_t)orow * p.ldc2 + nb) = h;
           }
         }
       }
     }
+  }
+}
+
+template <int TM, int TN, int EPI, bool SWAP, bool PRELOADED = false>
+__device__ __forceinline__ void gemm_epilogue(const UdGemm& p, f32x4 (&acc)[TM][TN], int mbase, int nbase, int lane, const float* bias,
+                                              char* out, char* out2, const float* w2, float b2, float post_add, char* stage) {
+  const int a = (EPI == UD_EPI_F16 || EPI == UD_EPI_QKV) ? p.act : p.act2;
+  if constexpr (EPI == UD_EPI_HEAD || EPI == UD_EPI_QKV) {
+    gemm_epilogue_impl<TM, TN, EPI, SWAP, PRELOADED, UD_ACT_NONE>(p, acc, mbase, nbase, lane, bias, out, out2, w2, b2, post_add, stage);
+  } else if constexpr (EPI == UD_EPI_F16) {
+    if (a == UD_ACT_GELU) gemm_epilogue_impl<TM, TN, EPI, SWAP, PRELOADED, UD_ACT_GELU>(p, acc, mbase, nbase, lane, bias, out, out2, w2, b2, post_add, stage);
+    else if (a == UD_ACT_LRELU) gemm_epilogue_impl<TM, TN, EPI, SWAP, PRELOADED, UD_ACT_LRELU>(p, acc, mbase, nbase, lane, bias, out, out2, w2, b2, post_add, stage);
+    else gemm_epilogue_impl<TM, TN, EPI, SWAP, PRELOADED, UD_ACT_NONE>(p, acc, mbase, nbase, lane, bias, out, out2, w2, b2, post_add, stage);
+  } else {
+    if (a == UD_ACT_LRELU) gemm_epilogue_impl<TM, TN, EPI, SWAP, PRELOADED, UD_ACT_LRELU>(p, acc, mbase, nbase, lane, bias, out, out2, w2, b2, post_add, stage);
+    else gemm_epilogue_impl<TM, TN, EPI, SWAP, PRELOADED, UD_ACT_NONE>(p, acc, mbase, nbase, lane, bias, out, out2, w2, b2, post_add, stage);
   }
 }
 
@@ -768,6 +793,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const UdGemm p) {
       }
     } else {
       if (ok) {
+        const bool lre = p.act == UD_ACT_LRELU;
         half_t* o = (half_t*)p.out + (long long)g * p.gOut + row * p.ldc;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -775,7 +801,10 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const UdGemm p) {
           const f32x4 bv = *(const f32x4*)(bias + nb);
           half4 h;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) h[r] = (half_t)ud_act(acc[i][j][r] + bv[r], p.act);
+          for (int r = 0; r < 4; ++r) {
+            const float t = acc[i][j][r] + bv[r];
+            h[r] = (half_t)(lre ? ud_lrelu(t) : t);       // branch-free: act is NONE or LeakyReLU here (conv_tile_ok)
+          }
           *(half4*)(o + nb) = h;
         }
       }
@@ -797,7 +826,7 @@ int launch_conv_tile(const UdGemm& d, hipStream_t s) {
 inline bool conv_tile_ok(const UdGemm& d) {
   return d.amode != UD_A_DENSE && (d.N == 32 || d.N == 64) && (d.Cin & 63) == 0 && d.rows_img == d.Himg * d.Wimg &&
          d.M % d.rows_img == 0 && d.bias != nullptr && d.tile_hint != 1 && d.Himg >= 2 && d.Wimg >= 2 &&
-         (d.epi == UD_EPI_HEAD || (d.epi == UD_EPI_F16 && d.rows_in == 0 && d.add == nullptr && (d.ldc & 3) == 0));
+         (d.epi == UD_EPI_HEAD || (d.epi == UD_EPI_F16 && d.act != UD_ACT_GELU && d.rows_in == 0 && d.add == nullptr && (d.ldc & 3) == 0));
 }
 
 template <class C, int EPI, int AMODE>
