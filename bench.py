@@ -80,10 +80,10 @@ def main():
     def step():
         out = model.infer(rgb)
         if world > 1:
-            for k in gather_keys:
-                t = out[k].contiguous()
-                buf = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=dev)
-                dist.all_gather_into_tensor(buf, t)
+            # one exchange step: requested outputs packed per image, ONE RCCL all-gather (xGMI is point-to-point: few, larger messages)
+            packed = torch.cat([out[k].reshape(B, -1) for k in gather_keys], dim=1)
+            gathered = torch.empty((world * B, packed.shape[1]), dtype=packed.dtype, device=dev)
+            dist.all_gather_into_tensor(gathered, packed)
         return out
 
     for _ in range(args.warmup):

@@ -594,31 +594,38 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   const int tiles_n = (p.N + 255) >> 8;
   const int tiles_m = (p.M + BM - 1) / BM;
   const int nblk = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {  // XCD-aware: contiguous range of the tile list per XCD
-    const int q = nblk >> 3, r = nblk & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  // group-M swizzle: walk 8 row-tiles x all column tiles at a time so concurrently running tiles share A and W panels in L2
-  constexpr int GM = 8;
-  const int gsz = GM * tiles_n;
-  const int grp = bid / gsz;
-  const int first_m = grp * GM;
-  const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
-  const int rem = bid - grp * gsz;
-  const int tile_m = first_m + rem % gm;
-  const int tile_n = rem / gm;
-  const int m0 = tile_m * BM, n0 = tile_n << 8;
-  const half_t* A = (const half_t*)p.A;
-  const half_t* W = (const half_t*)p.W;
-  if constexpr (EPI == UD_EPI_QKV) {
-    if (n0 >= p.vsplit) {
-      gemm256_body<MH, EPI, AMODE, false>(p, smem, m0, n0, A, W, p.bias, (char*)p.out, (char*)p.out2);
-      return;
+  // persistent workgroups: <= 256 resident (one per CU), each walks tiles t = blockIdx.x, blockIdx.x + gridDim.x, ...
+  // The epilogue's global stores are fire-and-forget: they drain into L2/HBM while the next tile's DMA and MFMAs run
+  // (as separate workgroups the store burst of every round sat on the critical path: ~9 us per round at bs=8).
+  for (int t = blockIdx.x; t < nblk; t += gridDim.x) {
+    int bid = t;
+    {  // XCD-aware: contiguous range of the tile list per XCD (gridDim.x is a multiple of 8 or == nblk, so t % 8 == blockIdx.x % 8)
+      const int q = nblk >> 3, r = nblk & 7;
+      const int xcd = bid & 7, idx = bid >> 3;
+      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    // group-M swizzle: walk 8 row-tiles x all column tiles at a time so concurrently running tiles share A and W panels in L2
+    constexpr int GM = 8;
+    const int gsz = GM * tiles_n;
+    const int grp = bid / gsz;
+    const int first_m = grp * GM;
+    const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int rem = bid - grp * gsz;
+    const int tile_m = first_m + rem % gm;
+    const int tile_n = rem / gm;
+    const int m0 = tile_m * BM, n0 = tile_n << 8;
+    const half_t* A = (const half_t*)p.A;
+    const half_t* W = (const half_t*)p.W;
+    bool done = false;
+    if constexpr (EPI == UD_EPI_QKV) {
+      if (n0 >= p.vsplit) {
+        gemm256_body<MH, EPI, AMODE, false>(p, smem, m0, n0, A, W, p.bias, (char*)p.out, (char*)p.out2);
+        done = true;
+      }
+    }
+    if (!done) gemm256_body<MH, EPI, AMODE, true>(p, smem, m0, n0, A, W, p.bias, (char*)p.out, (char*)p.out2);
+    __syncthreads();      // LDS (operand ring / store staging) is reused by the next tile
   }
-  gemm256_body<MH, EPI, AMODE, true>(p, smem, m0, n0, A, W, p.bias, (char*)p.out, (char*)p.out2);
 }
 
 template <int MH, int EPI, int AMODE>
@@ -634,7 +641,7 @@ int launch256(const UdGemm& d, hipStream_t s) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm256_kernel<MH, EPI, AMODE>), dim3(tiles), dim3(512), lds, s, d);
+  hipLaunchKernelGGL((gemm256_kernel<MH, EPI, AMODE>), dim3(tiles < 256 ? tiles : 256), dim3(512), lds, s, d);
   UD_CHECK_LAUNCH("ud_gemm_f16 (large tile) launch");
   return UD_OK;
 }

@@ -50,6 +50,17 @@ def infer_data_parallel(model, rgb: torch.Tensor, camera=None, keys: Optional[It
         out = {k: v[:0] for k, v in model.infer(rgb[:1], camera if cam is camera else camera[:1], **kw).items()}
     keys = list(out.keys()) if keys is None else list(keys)
     res = {}
+    packable = [k for k in keys if not (k == "rays" and out[k].shape[0] == 1 and B > 1 and counts[rank] != 1)]
+    if len(packable) > 1 and all(out[k].dtype == out[packable[0]].dtype for k in packable):
+        # ONE collective for all requested outputs: per-image rows are concatenated, gathered, and split again
+        widths = [int(torch.Size(out[k].shape[1:]).numel()) for k in packable]
+        packed = torch.cat([out[k].reshape(out[k].shape[0], wdt) for k, wdt in zip(packable, widths)], dim=1)
+        g = all_gather_batch(packed.contiguous(), counts, group)
+        off = 0
+        for k, wdt in zip(packable, widths):
+            res[k] = g[:, off:off + wdt].reshape((g.shape[0],) + tuple(out[k].shape[1:]))
+            off += wdt
+        keys = [k for k in keys if k not in packable]
     for k in keys:
         t = out[k]
         if k == "rays" and t.shape[0] == 1 and B > 1 and counts[rank] != 1:
