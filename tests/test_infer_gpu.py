@@ -117,3 +117,21 @@ def test_resolution_level_and_float_input(engine_cls):
     model.resolution_level = 11
     with pytest.raises(AssertionError):
         model.infer(rgb.cuda())
+
+
+@pytest.mark.parametrize("arch,H,W,B,normalize,ndim3", [("vits14", 240, 320, 1, True, True),      # up-resized input, [3,H,W] call form
+                                                      ("vits14", 462, 616, 2, False, False),    # caller-normalised float input
+                                                      ("vitl14", 644, 966, 1, True, False)])    # BASELINE configs[4] shape (3128 tokens)
+def test_infer_more_shapes_and_call_forms(engine_cls, arch, H, W, B, normalize, ndim3):
+    cfg = synth.load_config(arch)
+    sd = synth.make_synthetic_checkpoint(cfg, 31)
+    g = torch.Generator().manual_seed(17)
+    rgb = torch.randint(0, 256, (B, 3, H, W), dtype=torch.uint8, generator=g)
+    if not normalize:
+        rgb = (rgb.float() / 255.0 - 0.45) / 0.25
+    x = rgb[0] if ndim3 else rgb
+    ref = restate.OracleV2(cfg, sd).infer(x, None, normalize=normalize)
+    model = engine_cls(cfg).load_state_dict(sd).to("cuda").eval()
+    out = model.infer(x.cuda(), None, normalize=normalize)
+    torch.cuda.synchronize()
+    _check(out, ref, f"{arch}_{H}x{W}_b{B}_norm{int(normalize)}")
