@@ -63,6 +63,47 @@ def test_gemm_big_tiles_f16_f32(ops, M, N, K, hint):
     assert rel(x16.float(), x0 + ref) < 1e-3
 
 
+@pytest.mark.parametrize("hint", [2, 3])
+def test_gemm_big_tiles_persistent(ops, hint):
+    """More tiles than CUs: every workgroup walks several tiles (K-tile stream continuous across tiles, epilogue of tile t
+    beside the operand DMA of tile t+1), straight-line full-tile epilogues and the edge-tile path in one launch; fp16+GELU,
+    fp32 accumulate with the residual streamed in during the K loop (192-row tiles, K > 384), Q|K + V^T epilogue."""
+    B, Npad, D, H = 8, 1376, 512, 8
+    M, K = B * Npad, 512
+    A = rnd(M, K, seed=1).half()
+    for N in (2048, 1792):                      # 1792: last column tile partial
+        W = rnd(N, K, scale=K ** -0.5, seed=2).half()
+        bias = rnd(N, seed=3)
+        ref = A.float() @ W.float().t() + bias
+        out = torch.zeros(M, N, dtype=torch.half, device="cuda")
+        ops.gemm(A=A, W=W, bias=bias, out=out, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, epi=ops.UD_EPI_F16, act=ops.UD_ACT_GELU, tile_hint=hint)
+        torch.cuda.synchronize()
+        assert rel(out.float(), F.gelu(ref)) < 1e-3
+        assert (out.float() - F.gelu(ref)).abs().max() < 2e-2
+        x = rnd(M, N, seed=5); x0 = x.clone()
+        x16 = torch.zeros(M, N, dtype=torch.half, device="cuda")
+        ops.gemm(A=A, W=W, bias=bias, out=x, out2=x16, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, ldc2=N, epi=ops.UD_EPI_F32, accumulate=1,
+                 act2=ops.UD_ACT_LRELU, tile_hint=hint)
+        torch.cuda.synchronize()
+        assert rel(x, x0 + ref) < 2e-5
+        assert (x - (x0 + ref)).abs().max() < 1e-3
+        assert rel(x16.float(), F.leaky_relu(x0 + ref, 0.01)) < 1e-3
+    N, kv_ld = 3 * D, 1408
+    W = rnd(N, K, scale=K ** -0.5, seed=2).half()
+    bias = rnd(N, seed=3)
+    qk = torch.zeros(M, 2 * D, dtype=torch.half, device="cuda")
+    vt = torch.zeros(B, H, 64, kv_ld, dtype=torch.half, device="cuda")
+    ops.gemm(A=A, W=W, bias=bias, out=qk, out2=vt, M=M, N=N, K=K, lda=K, ldw=K, ldc=2 * D, epi=ops.UD_EPI_QKV,
+             vsplit=2 * D, tok_per_img=Npad, kv_ld=kv_ld, heads_v=H, tile_hint=hint)
+    ref = A.float() @ W.float().t() + bias
+    torch.cuda.synchronize()
+    assert rel(qk.float(), ref[:, :2 * D]) < 1e-3
+    want = ref[:, 2 * D:].view(B, Npad, H, 64).permute(0, 2, 3, 1)
+    assert rel(vt[..., :Npad].float(), want) < 1e-3
+    assert (vt[..., :Npad].float() - want).abs().max() < 2e-2
+    assert vt[..., Npad:].abs().max() == 0
+
+
 def test_gemm_big_tiles_qkv_d2s(ops):
     B, Npad, D, H = 2, 1376, 256, 4
     M, N, K = B * Npad, 3 * D, D

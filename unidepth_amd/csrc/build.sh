@@ -1,20 +1,22 @@
 #!/bin/bash
 # Build libunidepth_hip.so for gfx950 in-tree (cross-compiles without a GPU).  Usage: csrc/build.sh [extra hipcc flags]
+# UD_OUT / UD_BUILD_DIR override the output library / object directory (A/B and instrumented builds, tools/).
 set -e
 cd "$(dirname "$0")"
-OUT=../libunidepth_hip.so
+OUT=${UD_OUT:-../libunidepth_hip.so}
+BD=${UD_BUILD_DIR:-build}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result"
-mkdir -p build
+mkdir -p $BD
 pids=()
 for f in gemm.hip layernorm.hip pointwise.hip camera_f32.hip; do
-  ( hipcc $FLAGS "$@" -c $f -o build/${f%.hip}.o ) &
+  ( hipcc $FLAGS "$@" -c $f -o $BD/${f%.hip}.o ) &
   pids+=($!)
 done
 # attention: keep the MFMA accumulators in VGPRs (the softmax VALU works on them every tile; the default AGPR form costs
 # ~160 v_accvgpr_read/write per 16 MFMAs)
-( hipcc $FLAGS -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -c attention.hip -o build/attention.o ) & pids+=($!)
-( hipcc $FLAGS -x hip -c api.cpp -o build/api.o ) & pids+=($!)
-( hipcc $FLAGS -x hip -c program.cpp -o build/program.o ) & pids+=($!)
+( hipcc $FLAGS -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -c attention.hip -o $BD/attention.o ) & pids+=($!)
+( hipcc $FLAGS -x hip -c api.cpp -o $BD/api.o ) & pids+=($!)
+( hipcc $FLAGS -x hip -c program.cpp -o $BD/program.o ) & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC build/*.o -o $OUT
+hipcc --offload-arch=gfx950 -shared -fPIC $BD/*.o -o $OUT
 echo "built $(realpath $OUT)"

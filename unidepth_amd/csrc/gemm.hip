@@ -13,6 +13,18 @@
 //  * workgroup -> tile map is XCD-aware: the 8 XCDs get contiguous ranges of the tile list (private L2 reuse).
 #include "ud_common.h"
 
+#ifdef UD_TRACE
+// timeline instrumentation (tools/trace_gemm.py; never in the product build): per workgroup and tile, 100 MHz wall-clock stamps
+__device__ unsigned long long* ud_trace_ptr = nullptr;
+#define UD_STAMP(slot)                                                                           \
+  do {                                                                                           \
+    if (ud_trace_ptr && threadIdx.x == 0 && trace_tile < 8)                                      \
+      ud_trace_ptr[((size_t)blockIdx.x * 8 + trace_tile) * 8 + (slot)] = wall_clock64();         \
+  } while (0)
+#else
+#define UD_STAMP(slot)
+#endif
+
 namespace {
 
 template <int BN_, int WM_, int WN_>
@@ -422,14 +434,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const UdGemm p) {
 }
 
 // ================================================================================================================
-// Large-tile kernel: 256 x 256 output tile, 8 waves (2 along m x 4 along n, 128 x 64 per wave), K-tile = 64,
-// 2-stage LDS ring of 64 KB tiles (A [256][64] + B [256][64] halves, 128 KB, one workgroup per CU).
+// Large-tile kernel: 256 x 256 (MH = 4) or 192 x 256 (MH = 3) output tile, 8 waves (2 along m x 4 along n), K-tile = 64,
+// 2-stage LDS ring (A [BM][64] + B [256][64] halves per stage; one workgroup per CU), persistent over its tile list.
 //  * full 128-byte rows per DMA lane group (a 64-byte-row variant re-fetched every L2 line twice and was L2-bound);
-//  * the whole next K-tile is issued (8 x global_load_lds_dwordx4 per thread) at the top of the current one, i.e. three
-//    of the four 16-MFMA phases ahead of its first use; one vmcnt(0) + raw s_barrier per K-tile (64 MFMAs per wave);
+//  * the whole next K-tile is issued (global_load_lds_dwordx4) at the top of the current one, three of the four 16-MFMA
+//    phases ahead of its first use; one vmcnt(0) + raw s_barrier per K-tile (64 MFMAs per wave);
 //  * the K-tile is walked as 2 k-steps x 2 m-halves; fragment reads run one phase ahead of their MFMAs in registers
 //    (A m-half sets alternate, B k-step sets alternate) -- 0.375 ds_read_b128 per MFMA;
-//  * same source-side XOR swizzle as the 128x128 kernel (chunk ^= (row >> 1) & 7): conflict-free ds_read_b128.
+//  * same source-side XOR swizzle as the 128x128 kernel (chunk ^= (row >> 1) & 7): conflict-free ds_read_b128;
+//  * the K-tile stream is CONTINUOUS across the workgroup's tiles: the last K-tile of tile t issues K-tile 0 of tile t+1, so
+//    the epilogue of t (VALU + fire-and-forget stores, no LDS) runs while the next operands are already landing
+//    (measured with tools/trace_gemm.py: prologue 1.1 us + epilogue 7-10 us per 21-26 us K loop before);
+//  * fp16 outputs: v_permlane16_swap pairs neighbouring 16-column MFMA tiles so every lane stores 16 contiguous bytes
+//    (64-byte row segments) straight from registers -- no LDS staging pass, no lgkmcnt waits.
 // ================================================================================================================
 // MH = m-tiles (of 16 rows) per wave per m-half: 4 -> 256-row tiles, 3 -> 192-row tiles (tile-count quantisation on the
 // 256 CUs decides which one a GEMM gets: e.g. M = 11008, N = 1024 is 172 tiles of 256 rows (67 % of the CUs busy) but 232
@@ -442,52 +459,96 @@ struct BigCfg {
   static constexpr int A_LOADS = BM / 64;            // 16-byte chunks per thread per K-tile (512 threads)
 };
 
-template <int MH, int EPI, int AMODE, bool SWAP>
-__device__ __forceinline__ void gemm256_body(const UdGemm& p, char* smem, int m0, int n0, const half_t* A, const half_t* W,
-                                             const float* bias, char* out, char* out2) {
+template <bool B> struct BoolTag { static constexpr bool value = B; };
+template <int I> struct IntTag { static constexpr int value = I; };
+
+// two packed-fp16 dwords of column tiles j / j+1 -> 8 consecutive columns per lane (see the layout note in the kernel)
+__device__ __forceinline__ void ud_pair16(unsigned& a, unsigned& b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
+__device__ __forceinline__ unsigned ud_pack2(float x, float y) {
+  f32x2 v; v[0] = x; v[1] = y;
+  const half2v h = __builtin_convertvector(v, half2v);
+  return __builtin_bit_cast(unsigned, h);
+}
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+template <int MH, int EPI, int AMODE>
+__global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   using C = BigCfg<MH>;
+  constexpr int BM = C::BM;
+  constexpr int TM = 2 * MH;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wv >> 2, wn = wv & 3;
   const int nk = p.K >> 6;
+  const int tiles_n = (p.N + 255) >> 8;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int nblk = tiles_m * tiles_n;
+  const half_t* A = (const half_t*)p.A;
+  const half_t* W = (const half_t*)p.W;
 
-  // loader: thread owns chunks tid + 512*i -> rows (tid >> 3) + 64*i
+  // tile list entry -> (m0, n0): XCD-aware (contiguous range of the list per XCD; gridDim.x is a multiple of 8 or == nblk, so
+  // t % 8 == blockIdx.x % 8 == the XCD) + group-M walk (8 row-tiles x all column tiles at a time share A and W panels in L2)
+  auto decode = [&](int t, int& m0, int& n0) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = t & 7, idx = t >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    constexpr int GM = 8;
+    const int gsz = GM * tiles_n;
+    const int grp = bid / gsz;
+    const int first_m = grp * GM;
+    const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int rem = bid - grp * gsz;
+    m0 = (first_m + rem % gm) * BM;
+    n0 = (rem / gm) << 8;
+  };
+
+  // ---------------- loader: thread owns chunks tid + 512*i -> rows (tid >> 3) + 64*i.  Operands are addressed through buffer
+  // descriptors (buffer_load_dwordx4 ... lds): one 32-bit byte offset per chunk in a VGPR, the K-tile advance in an SGPR.
   const int lrow = tid >> 3;
   const int csrc = (tid & 7) ^ ((lrow >> 1) & 7);
-  const half_t* pa[C::A_LOADS];
-  const half_t* pb[4];
-  ConvLane cl[C::A_LOADS];
+  const ud_rsrc_t rA = ud_make_rsrc(A, 0x80000000u);
+  const ud_rsrc_t rW = ud_make_rsrc(W, 0x80000000u);
+  unsigned pa[C::A_LOADS];        // dense: byte offset of the lane's chunk in K-tile 0; conv: byte offset of the image
+  unsigned cyx[C::A_LOADS];       // conv: (y << 16) | x of the row's pixel (y = 0x4000 for rows past the image: always padding)
+  unsigned pb[4];
   const float inv_cc = (AMODE != UD_A_DENSE) ? 1.0f / (float)(p.Cin >> 3) : 0.0f;
+  auto setup = [&](int m0, int n0) {
 #pragma unroll
-  for (int i = 0; i < C::A_LOADS; ++i) {
-    int m = m0 + lrow + 64 * i;
-    m = m < p.M ? m : p.M - 1;
-    if constexpr (AMODE == UD_A_DENSE) {
-      pa[i] = A + (size_t)m * p.lda + csrc * 8;
-    } else {
-      const int img = m / p.rows_img;
-      const int pp = m - img * p.rows_img;
-      const int y = pp / p.Wimg;
-      cl[i].base = (long long)img * p.img_stride;
-      cl[i].y = y;
-      cl[i].x = pp - y * p.Wimg;
-      cl[i].valid = pp < p.Himg * p.Wimg;
+    for (int i = 0; i < C::A_LOADS; ++i) {
+      int m = m0 + lrow + 64 * i;
+      m = m < p.M ? m : p.M - 1;
+      if constexpr (AMODE == UD_A_DENSE) {
+        pa[i] = ((unsigned)m * (unsigned)p.lda + csrc * 8) * 2u;
+      } else {
+        const int img = m / p.rows_img;
+        const int pp = m - img * p.rows_img;
+        const int y = pp / p.Wimg;
+        pa[i] = (unsigned)((long long)img * p.img_stride) * 2u;
+        cyx[i] = pp < p.Himg * p.Wimg ? ((unsigned)y << 16) | (unsigned)(pp - y * p.Wimg) : 0x40000000u;
+      }
     }
-  }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int n = n0 + lrow + 64 * i;
-    n = n < p.N ? n : p.N - 1;
-    pb[i] = W + (size_t)n * p.ldw + csrc * 8;
-  }
-  auto issue = [&](int kt) {
-    char* sb = smem + (kt & 1) * C::STAGE + wv * 1024;
+    for (int i = 0; i < 4; ++i) {
+      int n = n0 + lrow + 64 * i;
+      n = n < p.N ? n : p.N - 1;
+      pb[i] = ((unsigned)n * (unsigned)p.ldw + csrc * 8) * 2u;
+    }
+  };
+  auto issue = [&](int kt, int stg) {
+    char* sb = smem + stg * C::STAGE + wv * 1024;
     if constexpr (AMODE == UD_A_DENSE) {
 #pragma unroll
-      for (int i = 0; i < C::A_LOADS; ++i) ud_glds16(pa[i] + kt * 64, sb + i * 8192);
+      for (int i = 0; i < C::A_LOADS; ++i) ud_bufl16(rA, pa[i], kt * 128, sb + i * 8192);
     } else {
-      // implicit-GEMM gather: this lane's 16-byte chunk = 8 channels of tap (kc / (Cin/8)); one tap decode per K-tile
+      // implicit-GEMM gather: this lane's 16-byte chunk = 8 channels of tap (kc / (Cin/8)); one tap decode per K-tile;
+      // padding taps use an offset beyond the descriptor's range and read as zeros
+      static_assert(AMODE != UD_A_CONV3_REFLECT, "large-tile kernel: zero-padded convolutions only");
       const int kc = kt * 8 + csrc;
       const int tap = (int)(((float)kc + 0.5f) * inv_cc);
       const int cch = (kc - tap * (p.Cin >> 3)) << 3;
@@ -495,136 +556,277 @@ __device__ __forceinline__ void gemm256_body(const UdGemm& p, char* smem, int m0
       const int dy = t3 - 1, dx = tap - t3 * 3 - 1;
 #pragma unroll
       for (int i = 0; i < C::A_LOADS; ++i) {
-        int yy = cl[i].y + dy, xx = cl[i].x + dx;
-        bool ok = cl[i].valid && tap < 9;
-        if constexpr (AMODE == UD_A_CONV3_ZERO) {
-          ok = ok && (unsigned)yy < (unsigned)p.Himg && (unsigned)xx < (unsigned)p.Wimg;
-        } else {
-          yy = yy < 0 ? -yy : (yy >= p.Himg ? 2 * p.Himg - 2 - yy : yy);
-          xx = xx < 0 ? -xx : (xx >= p.Wimg ? 2 * p.Wimg - 2 - xx : xx);
-        }
-        const half_t* src = ok ? A + cl[i].base + ((long long)(yy * p.Wimg + xx)) * p.cstride + p.coff + cch : (const half_t*)p.zeros;
-        ud_glds16(src, sb + i * 8192);
+        const int yy = (int)(cyx[i] >> 16) + dy, xx = (int)(cyx[i] & 0xffff) + dx;
+        const bool ok = tap < 9 && (unsigned)yy < (unsigned)p.Himg && (unsigned)xx < (unsigned)p.Wimg;
+        const unsigned off = ok ? pa[i] + (unsigned)((yy * p.Wimg + xx) * p.cstride + p.coff + cch) * 2u : 0xfffffff0u;
+        ud_bufl16(rA, off, 0, sb + i * 8192);
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ud_glds16(pb[i] + kt * 64, sb + C::A_BYTES + i * 8192);
+    for (int i = 0; i < 4; ++i) ud_bufl16(rW, pb[i], kt * 128, sb + C::A_BYTES + i * 8192);
   };
 
-  // fragment read offsets inside a stage: row-major [row][64 halves], chunk index swizzled by (row >> 1) & 7
-  const int frow = lane & 15;
-  const int fq = lane >> 4;
-  const int fswz = frow >> 1;
-  const int c0 = ((fq) ^ fswz) << 4;          // k-step 0
-  const int c1 = ((4 + fq) ^ fswz) << 4;      // k-step 1
-  const int a_off = (wm * (C::BM / 2) + frow) * 128;
-  const int b_off = C::A_BYTES + (wn * 64 + frow) * 128;
+  // ---------------- fragment read offsets inside a stage: row-major [row][64 halves], chunk index swizzled by (row >> 1) & 7
+  const int fswz = (lane & 15) >> 1;
+  const int c0 = ((lane >> 4) ^ fswz) << 4;          // k-step 0
+  const int c1 = ((4 + (lane >> 4)) ^ fswz) << 4;    // k-step 1
+  const int a_off = (wm * (BM / 2) + (lane & 15)) * 128;
+  const int b_off = C::A_BYTES + (wn * 64 + (lane & 15)) * 128;
 
-  f32x4 acc[2 * MH][4];
-#pragma unroll
-  for (int i = 0; i < 2 * MH; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[TM][4];
+  half8 a0[MH], a1[MH], b0[4], b1[4];
+  int stg = 0;                                 // ring stage holding the K-tile about to be multiplied
 
+  constexpr bool ACC_EPI = (EPI == UD_EPI_F32);        // `out (+)= ...`: old values are preloaded into the accumulators
+
+  int m0, n0;
+  int t = blockIdx.x;
+  decode(t, m0, n0);
+  setup(m0, n0);
+  issue(0, 0);
+
+  int trace_tile = 0;
+  bool first = true;
+  for (; t < nblk; t += gridDim.x, ++trace_tile) {
+    UD_STAMP(0);
+    const int tn = t + gridDim.x;
+    const bool has_next = tn < nblk;
+    int m0n = 0, n0n = 0;
+    if (has_next) decode(tn, m0n, n0n);
+    const int mbase = m0 + wm * (BM / 2), nbase = n0 + wn * 64;
+    const bool swap = !(EPI == UD_EPI_QKV && n0 >= p.vsplit);
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // `out += A W^T`: the old fp32 values become the accumulators' initial state (the summation order of every output element
+    // is then independent of where its row sits in the tile, i.e. of the image's position in the batch: infer() stays
+    // bit-for-bit batch-permutation equivariant; an in-loop variant that streamed them in during the first K-tiles hid the
+    // 7 us load burst but made the result depend on the batch position at the 2e-4 level after fp16 re-rounding).
+    // Issued before the wait for the first operand tile: both bursts are in flight together.
+    if constexpr (ACC_EPI) {
+      if (p.accumulate) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        gemm_preload_acc<TM, 4>(p, acc, mbase, nbase, ln, (const char*)p.out);
+      }
+    }
+    if (first) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      first = false;
+    }
+    {  // first fragments of this tile (its K-tile 0 landed before the barrier that ended the previous tile's K loop)
+      const char* sb0 = smem + stg * C::STAGE;
+#pragma unroll
+      for (int i = 0; i < MH; ++i) a0[i] = *(const half8*)(sb0 + a_off + i * 2048 + c0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b0[j] = *(const half8*)(sb0 + b_off + j * 2048 + c0);
+    }
+
+    // ---- one K-tile: SW = operand order, LAST = last K-tile of the output tile (prefetches the next tile's first K-tile
+    //      instead of this tile's next one)
+    auto ktile = [&](auto SW, auto LASTT, int kt) {
+      constexpr bool SWAP = decltype(SW)::value;
+      constexpr bool LAST = decltype(LASTT)::value;
+      const char* sb = smem + stg * C::STAGE;
+      const char* sbn = smem + (stg ^ 1) * C::STAGE;
 #define UD_MFMA_HALF(ROW0, AF, BF)                                                                               \
   _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) {               \
     if constexpr (SWAP) acc[ROW0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[j], AF[i], acc[ROW0 + i][j], 0, 0, 0); \
     else acc[ROW0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AF[i], BF[j], acc[ROW0 + i][j], 0, 0, 0);   \
   }
-
-  half8 a0[MH], a1[MH], b0[4], b1[4];
-  issue(0);
-  constexpr bool PRE = (EPI == UD_EPI_F32) && SWAP;
-  if constexpr (PRE) {
-    if (p.accumulate) gemm_preload_acc<2 * MH, 4>(p, acc, m0 + wm * (C::BM / 2), n0 + wn * 64, lane, out);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
+      // ---- phase (k0, m-half 0): DMA of the whole next K-tile goes out first
+      if constexpr (LAST) {
+        if (has_next) {
+          setup(m0n, n0n);
+          issue(0, stg ^ 1);
+        }
+      } else {
+        issue(kt + 1, stg ^ 1);
+      }
 #pragma unroll
-  for (int t = 0; t < MH; ++t) a0[t] = *(const half8*)(smem + a_off + t * 2048 + c0);
+      for (int i = 0; i < MH; ++i) a1[i] = *(const half8*)(sb + a_off + (MH + i) * 2048 + c0);
+      __builtin_amdgcn_sched_barrier(0);     // keep the fragment prefetch ahead of the MFMAs (hipcc would sink it to first use)
+      UD_MFMA_HALF(0, a0, b0)
+      // ---- phase (k0, m-half 1)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) b0[j] = *(const half8*)(smem + b_off + j * 2048 + c0);
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const char* sb = smem + (kt & 1) * C::STAGE;
-    const char* sbn = smem + ((kt + 1) & 1) * C::STAGE;
-    // ---- phase (k0, m-half 0): DMA of the whole next K-tile goes out first
-    if (kt + 1 < nk) issue(kt + 1);
+      for (int i = 0; i < MH; ++i) a0[i] = *(const half8*)(sb + a_off + i * 2048 + c1);
 #pragma unroll
-    for (int t = 0; t < MH; ++t) a1[t] = *(const half8*)(sb + a_off + (MH + t) * 2048 + c0);
-    __builtin_amdgcn_sched_barrier(0);     // keep the fragment prefetch ahead of the MFMAs (hipcc would sink it to first use)
-    UD_MFMA_HALF(0, a0, b0)
-    // ---- phase (k0, m-half 1)
+      for (int j = 0; j < 4; ++j) b1[j] = *(const half8*)(sb + b_off + j * 2048 + c1);
+      __builtin_amdgcn_sched_barrier(0);
+      UD_MFMA_HALF(MH, a1, b0)
+      // ---- phase (k1, m-half 0)
 #pragma unroll
-    for (int t = 0; t < MH; ++t) a0[t] = *(const half8*)(sb + a_off + t * 2048 + c1);
+      for (int i = 0; i < MH; ++i) a1[i] = *(const half8*)(sb + a_off + (MH + i) * 2048 + c1);
+      __builtin_amdgcn_sched_barrier(0);
+      UD_MFMA_HALF(0, a0, b1)
+      // ---- phase (k1, m-half 1): next K-tile must have landed for every wave before anyone reads it
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if constexpr (!LAST) {                   // (the next TILE's first fragments are read after the epilogue: 32 registers less there)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b1[j] = *(const half8*)(sb + b_off + j * 2048 + c1);
-    __builtin_amdgcn_sched_barrier(0);
-    UD_MFMA_HALF(MH, a1, b0)
-    // ---- phase (k1, m-half 0)
+        for (int i = 0; i < MH; ++i) a0[i] = *(const half8*)(sbn + a_off + i * 2048 + c0);
 #pragma unroll
-    for (int t = 0; t < MH; ++t) a1[t] = *(const half8*)(sb + a_off + (MH + t) * 2048 + c1);
-    __builtin_amdgcn_sched_barrier(0);
-    UD_MFMA_HALF(0, a0, b1)
-    // ---- phase (k1, m-half 1): next K-tile must have landed for every wave before anyone reads it
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int t = 0; t < MH; ++t) a0[t] = *(const half8*)(sbn + a_off + t * 2048 + c0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) b0[j] = *(const half8*)(sbn + b_off + j * 2048 + c0);
-    __builtin_amdgcn_sched_barrier(0);
-    UD_MFMA_HALF(MH, a1, b1)
-  }
+        for (int j = 0; j < 4; ++j) b0[j] = *(const half8*)(sbn + b_off + j * 2048 + c0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      UD_MFMA_HALF(MH, a1, b1)
 #undef UD_MFMA_HALF
-  char* stage = nullptr;
-  if constexpr ((EPI == UD_EPI_F16 || EPI == UD_EPI_QKV) && SWAP) {
-    __syncthreads();
-    stage = smem + wv * 9216;
-  }
-  gemm_epilogue<2 * MH, 4, EPI, SWAP, PRE>(p, acc, m0 + wm * (C::BM / 2), n0 + wn * 64, lane, bias, out, out2, nullptr, 0.f, 0.f, stage);
-}
+      stg ^= 1;
+    };
 
-template <int MH, int EPI, int AMODE>
-__global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BM = BigCfg<MH>::BM;
-  const int tiles_n = (p.N + 255) >> 8;
-  const int tiles_m = (p.M + BM - 1) / BM;
-  const int nblk = tiles_m * tiles_n;
-  // persistent workgroups: <= 256 resident (one per CU), each walks tiles t = blockIdx.x, blockIdx.x + gridDim.x, ...
-  // The epilogue's global stores are fire-and-forget: they drain into L2/HBM while the next tile's DMA and MFMAs run
-  // (as separate workgroups the store burst of every round sat on the critical path: ~9 us per round at bs=8).
-  for (int t = blockIdx.x; t < nblk; t += gridDim.x) {
-    int bid = t;
-    {  // XCD-aware: contiguous range of the tile list per XCD (gridDim.x is a multiple of 8 or == nblk, so t % 8 == blockIdx.x % 8)
-      const int q = nblk >> 3, r = nblk & 7;
-      const int xcd = bid & 7, idx = bid >> 3;
-      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    // group-M swizzle: walk 8 row-tiles x all column tiles at a time so concurrently running tiles share A and W panels in L2
-    constexpr int GM = 8;
-    const int gsz = GM * tiles_n;
-    const int grp = bid / gsz;
-    const int first_m = grp * GM;
-    const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
-    const int rem = bid - grp * gsz;
-    const int tile_m = first_m + rem % gm;
-    const int tile_n = rem / gm;
-    const int m0 = tile_m * BM, n0 = tile_n << 8;
-    const half_t* A = (const half_t*)p.A;
-    const half_t* W = (const half_t*)p.W;
-    bool done = false;
+    auto kloop = [&](auto SW) {
+      for (int kt = 0; kt < nk - 1; ++kt) ktile(SW, BoolTag<false>{}, kt);
+      ktile(SW, BoolTag<true>{}, nk - 1);
+    };
+    UD_STAMP(1);
     if constexpr (EPI == UD_EPI_QKV) {
-      if (n0 >= p.vsplit) {
-        gemm256_body<MH, EPI, AMODE, false>(p, smem, m0, n0, A, W, p.bias, (char*)p.out, (char*)p.out2);
-        done = true;
+      if (swap) kloop(BoolTag<true>{});
+      else kloop(BoolTag<false>{});
+    } else {
+      kloop(BoolTag<true>{});
+    }
+    UD_STAMP(2);
+
+    // =================================== epilogue ===================================
+    // Accumulator layout (SWAP): lane owns row mbase + 16 i + (lane & 15), columns nbase + 16 j + 4 q .. + 3, q = lane >> 4.
+    // v_permlane16_swap of the packed dwords of tiles j / j+1 leaves lane q with 8 consecutive columns starting at
+    // nbase + 16 (j + (q & 1)) + 8 (q >> 1): 16-byte stores, 64-byte row segments.  V^T tiles (!SWAP) own 4 consecutive rows
+    // (tokens) per lane; the same exchange between row tiles i / i+1 gives 8 consecutive tokens starting at
+    // mbase + 16 (i + (q & 1)) + 8 (q >> 1).
+    const bool full = (m0 + BM <= p.M) && (n0 + 256 <= p.N) && p.rows_in == 0 && p.add == nullptr && p.bias != nullptr;
+    bool fast = false;
+    int eln = lane;
+    asm volatile("" : "+v"(eln));              // epilogue addresses are derived here, per tile: nothing of them lives across the K loop
+    const int frow = eln & 15, fq = eln >> 4;
+    if constexpr (EPI == UD_EPI_F16 || EPI == UD_EPI_QKV) {
+      if (swap) {
+        fast = full && (p.ldc & 7) == 0;
+        if (fast) {
+          const int act = p.act;
+          f32x4 bv[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(p.bias + nbase + j * 16 + 4 * fq);
+          half_t* o = (half_t*)p.out + (size_t)(mbase + frow) * p.ldc + nbase + 16 * (fq & 1) + 8 * (fq >> 1);
+          auto body = [&](auto ACT) {
+            constexpr int AC = decltype(ACT)::value;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+              unsigned w[4][2];
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const f32x4 v = acc[i][j] + bv[j];
+                w[j][0] = ud_pack2(ud_act_t<AC>(v[0]), ud_act_t<AC>(v[1]));
+                w[j][1] = ud_pack2(ud_act_t<AC>(v[2]), ud_act_t<AC>(v[3]));
+              }
+#pragma unroll
+              for (int jp = 0; jp < 2; ++jp) {
+                ud_pair16(w[2 * jp][0], w[2 * jp + 1][0]);
+                ud_pair16(w[2 * jp][1], w[2 * jp + 1][1]);
+                u32x4 s;
+                s[0] = w[2 * jp][0]; s[1] = w[2 * jp][1]; s[2] = w[2 * jp + 1][0]; s[3] = w[2 * jp + 1][1];
+                *(u32x4*)(o + (size_t)(i * 16) * p.ldc + jp * 32) = s;
+              }
+            }
+          };
+          if (act == UD_ACT_GELU) body(IntTag<UD_ACT_GELU>{});
+          else if (act == UD_ACT_LRELU) body(IntTag<UD_ACT_LRELU>{});
+          else body(IntTag<UD_ACT_NONE>{});
+        }
+      } else {
+        if constexpr (EPI == UD_EPI_QKV) {
+          fast = full && (p.tok_per_img & 7) == 0 && (p.kv_ld & 7) == 0;
+          if (fast) {
+            half_t* vt = (half_t*)p.out2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int n = nbase + j * 16 + frow;
+              const float bvn = p.bias[n];
+              const int nv = n - p.vsplit;
+              half_t* vrow = vt + (size_t)((nv >> 6) * 64 + (nv & 63)) * p.kv_ld;
+#pragma unroll
+              for (int ip = 0; ip < MH; ++ip) {
+                unsigned w0[2], w1[2];
+                w0[0] = ud_pack2(acc[2 * ip][j][0] + bvn, acc[2 * ip][j][1] + bvn);
+                w0[1] = ud_pack2(acc[2 * ip][j][2] + bvn, acc[2 * ip][j][3] + bvn);
+                w1[0] = ud_pack2(acc[2 * ip + 1][j][0] + bvn, acc[2 * ip + 1][j][1] + bvn);
+                w1[1] = ud_pack2(acc[2 * ip + 1][j][2] + bvn, acc[2 * ip + 1][j][3] + bvn);
+                ud_pair16(w0[0], w1[0]);
+                ud_pair16(w0[1], w1[1]);
+                const int mb = mbase + 16 * (2 * ip + (fq & 1)) + 8 * (fq >> 1);
+                const int img = mb / p.tok_per_img;
+                const int tk = mb - img * p.tok_per_img;
+                u32x4 s;
+                s[0] = w0[0]; s[1] = w0[1]; s[2] = w1[0]; s[3] = w1[1];
+                *(u32x4*)(vrow + (size_t)img * p.heads_v * 64 * p.kv_ld + tk) = s;
+              }
+            }
+          }
+        }
+      }
+    } else if constexpr (EPI == UD_EPI_F32) {
+      fast = full && (p.ldc & 3) == 0 && (p.out2 == nullptr || (p.ldc2 & 7) == 0);
+      if (fast) {
+        f32x4 bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(p.bias + nbase + j * 16 + 4 * fq);
+        float* o = (float*)p.out + (size_t)(mbase + frow) * p.ldc + nbase + 4 * fq;
+        half_t* o2 = p.out2 ? (half_t*)p.out2 + (size_t)(mbase + frow) * p.ldc2 + nbase + 16 * (fq & 1) + 8 * (fq >> 1) : nullptr;
+        const bool wr32 = p.accumulate != 2;   // accumulate == 2: the fp32 stream dies here, only the fp16 copy is consumed
+        const bool lre = p.act2 == UD_ACT_LRELU;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          unsigned w[4][2];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 v = acc[i][j] + bv[j];
+            if (wr32) *(f32x4*)(o + (size_t)(i * 16) * p.ldc + j * 16) = v;
+            if (o2) {
+              f32x4 a = v;
+              if (lre) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[r] = ud_lrelu(v[r]);
+              }
+              w[j][0] = ud_pack2(a[0], a[1]);
+              w[j][1] = ud_pack2(a[2], a[3]);
+            }
+          }
+          if (o2) {
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+              ud_pair16(w[2 * jp][0], w[2 * jp + 1][0]);
+              ud_pair16(w[2 * jp][1], w[2 * jp + 1][1]);
+              u32x4 s;
+              s[0] = w[2 * jp][0]; s[1] = w[2 * jp][1]; s[2] = w[2 * jp + 1][0]; s[3] = w[2 * jp + 1][1];
+              *(u32x4*)(o2 + (size_t)(i * 16) * p.ldc2 + jp * 32) = s;
+            }
+          }
+        }
       }
     }
-    if (!done) gemm256_body<MH, EPI, AMODE, true>(p, smem, m0, n0, A, W, p.bias, (char*)p.out, (char*)p.out2);
-    __syncthreads();      // LDS (operand ring / store staging) is reused by the next tile
+    if (!fast) {
+      // generic path: edge tiles, row remaps, `add` operands, depth-to-space (8-byte fp16 stores, per-element bounds checks)
+      constexpr bool PRE = ACC_EPI;            // the residual is already inside the accumulators (in-loop or preloaded)
+      if constexpr (EPI == UD_EPI_QKV) {
+        if (swap) gemm_epilogue<TM, 4, EPI, true, PRE>(p, acc, mbase, nbase, eln, p.bias, (char*)p.out, (char*)p.out2, nullptr, 0.f, 0.f, nullptr);
+        else gemm_epilogue<TM, 4, EPI, false, PRE>(p, acc, mbase, nbase, eln, p.bias, (char*)p.out, (char*)p.out2, nullptr, 0.f, 0.f, nullptr);
+      } else {
+        gemm_epilogue<TM, 4, EPI, true, PRE>(p, acc, mbase, nbase, eln, p.bias, (char*)p.out, (char*)p.out2, nullptr, 0.f, 0.f, nullptr);
+      }
+    }
+    UD_STAMP(3);
+#ifdef UD_TRACE_DRAIN
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    UD_STAMP(4);
+#endif
+    UD_STAMP(5);
+    m0 = m0n;
+    n0 = n0n;
   }
 }
 
@@ -653,6 +855,10 @@ int launch256(const UdGemm& d, hipStream_t s) {
 inline int pick_tiles(const UdGemm& d) {
   if (d.amode == UD_A_CONV3_REFLECT || d.groups > 1 || d.M < 1024 || d.N < 256 || (d.K & 63)) return 0;
   if (d.amode == UD_A_CONV3_ZERO && d.epi != UD_EPI_F16 && d.epi != UD_EPI_F32) return 0;
+  {  // the large-tile loader addresses its operands with 32-bit byte offsets inside 2 GB buffer descriptors
+    const double a_bytes = d.amode == UD_A_DENSE ? 2.0 * d.M * d.lda : 2.0 * ((double)(d.M / d.rows_img) + 1.0) * (double)d.img_stride;
+    if (a_bytes >= 2147483648.0 || 2.0 * d.N * d.ldw >= 2147483648.0) return 0;
+  }
   if (d.epi == UD_EPI_QKV && (d.vsplit & 255)) return 0;
   if (d.tile_hint == 1) return 0;
   if (d.tile_hint == 2) return 4;
@@ -919,6 +1125,12 @@ extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
   ud_set_error("ud_gemm_f16: unsupported epi/amode combination");
   return UD_ERR_UNSUPPORTED;
 }
+
+#ifdef UD_TRACE
+extern "C" int ud_trace_set(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(ud_trace_ptr), &buf, sizeof(buf)) == hipSuccess ? UD_OK : UD_ERR_LAUNCH;
+}
+#endif
 
 // Which kernel ud_gemm_f16 would launch for this descriptor (for profiling labels): 0/1/2 = 128-row kernels with BN 128/64/32,
 // 3 = 192x256 tiles, 4 = 256x256 tiles, 5 = halo-tile conv.

@@ -21,21 +21,31 @@ __device__ __forceinline__ void ud_glds16(const void* gsrc, void* lds_wave_base)
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// exact-erf GELU (nn.GELU default).  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32 round-off level and
-// three orders below the fp16 rounding of the stored result): 1 v_rcp + 1 v_exp + 7 FMAs instead of ~45 instructions of erff.
-__device__ __forceinline__ float ud_erf_fast(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  poly *= t;
-  const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
-  const float r = fmaf(-poly, e, 1.0f);
-  return copysignf(r, x);
+// the same copy through a buffer descriptor: address = base(SGPR x4) + voff (one VGPR, bytes) + soff (SGPR, bytes); no 64-bit
+// per-lane pointer, no per-K-tile address VALU, and an offset >= num_records reads as zeros (conv padding for free).
+typedef __amdgpu_buffer_rsrc_t ud_rsrc_t;
+__device__ __forceinline__ ud_rsrc_t ud_make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
 }
-__device__ __forceinline__ float ud_gelu_erf(float x) { return 0.5f * x * (1.0f + ud_erf_fast(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ void ud_bufl16(ud_rsrc_t r, unsigned voff, int soff, void* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, soff, 0, 0);
+}
+
+// exact-erf GELU (nn.GELU default).  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32 round-off level and
+// three orders below the fp16 rounding of the stored result), written on |x| so that no sign fix-up is needed:
+//   gelu(x) = x Phi(x) = max(x, 0) - |x| q,   q = Phi(-|x|) = 0.5 poly(t) exp(-x^2 / 2),   t = 1 / (1 + p |x| / sqrt 2)
+// 1 v_rcp + 1 v_exp + 11 plain VALU (abs / neg are operand modifiers) -- erff() is ~45 instructions.
+__device__ __forceinline__ float ud_gelu_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+  float poly = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+  poly = fmaf(poly, t, 0.5f * 1.421413741f);
+  poly = fmaf(poly, t, 0.5f * -0.284496736f);
+  poly = fmaf(poly, t, 0.5f * 0.254829592f);
+  poly *= t;
+  const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.4426950408889634f));
+  return fmaf(-ax, poly * e, fmaxf(x, 0.0f));
+}
 __device__ __forceinline__ float ud_lrelu(float x) { return x > 0.0f ? x : 0.01f * x; }
 __device__ __forceinline__ float ud_act(float x, int act) {
   return act == UD_ACT_GELU ? ud_gelu_erf(x) : (act == UD_ACT_LRELU ? ud_lrelu(x) : x);
