@@ -27,7 +27,10 @@ extern "C" {
 /* ---- GEMM epilogues ------------------------------------------------------------------------------- */
 #define UD_EPI_F16 0   /* out(fp16)[row, n] = act(acc + bias[n] + add[.., n])                                      */
 #define UD_EPI_F32 1   /* out(fp32)[row, n] (+)= acc + bias[n] + add[.., n]; optional fp16 copy out2 = act2(result)  */
-#define UD_EPI_QKV 2   /* n <  vsplit: out(fp16) row-major;  n >= vsplit: out2(fp16) = V^T [img][head][64][kv_ld]    */
+#define UD_EPI_QKV 2   /* n <  vsplit: out(fp16) row-major;  n >= vsplit: out2(fp16) = V^T [img][head][64][kv_ld], the 4-key blocks
+                        * of every aligned 16-key group stored in the order [0, 2, 1, 3] (= the k-slot order of the P V MFMA,
+                        * so the attention kernel DMAs V^T tiles to LDS as they are): key t lives at column
+                        * (t & ~15) | ((t & 4) << 1) | ((t & 8) >> 1) | (t & 3)                                                       */
 #define UD_EPI_D2S 3   /* ConvTranspose(k=s) depth-to-space: out(fp32 NHWC) += acc + bias[o]; out2 fp16 = act2(..)   */
 #define UD_EPI_HEAD 4  /* y = sum_n lrelu(acc + bias[n]) * w2[n] + b2;  out(fp32)[m] = exp(clip(y,-8,8) + post_add) */
 
@@ -114,7 +117,8 @@ int ud_attention_small_f32(const float* q, const float* kv, float* out, int B, i
 /* ---- fused multi-head attention forward, head_dim 64 (padded), no mask, fp16 in/out, fp32 softmax ----
  * O = softmax(Q K^T * scale) V per (image, head).  Replaces F.scaled_dot_product_attention at
  * metadinov2/attention.py:58 and layers/attention.py:136-138 (and xformers memory_efficient_attention :77).
- * Q [img*q_rows_per_img + i, h*64 + d] (ldq), K likewise (ldk), Vt = V^T [img][h][64][kv_ld], O like Q (ldo).
+ * Q [img*q_rows_per_img + i, h*64 + d] (ldq), K likewise (ldk), Vt = V^T [img][h][64][kv_ld] in the UD_EPI_QKV block order
+ * (zeros beyond Nk up to the next multiple of 64), O like Q (ldo).
  * kv_broadcast != 0: groups of kv_group consecutive images share one K/V image (single GT camera, decoder.py:400). */
 typedef struct UdAttention {
   const void* Q; const void* K; const void* Vt; void* O;

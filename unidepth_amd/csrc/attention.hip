@@ -1,7 +1,7 @@
 // Fused multi-head attention forward for gfx950 (flash style, online softmax), head_dim = 64, fp16 operands,
-// fp32 scores / statistics / accumulators.  One workgroup = 4 waves x 32 query rows; K and V^T tiles of 64 keys
-// are staged through LDS (register-staged, double buffered: the global loads of tile t+1 are issued before the
-// MFMAs of tile t and written to LDS after them).
+// fp32 scores / statistics / accumulators.  One workgroup = 4 waves x 32 query rows; K and V^T tiles of 64 keys go
+// HBM/L2 -> LDS by global_load_lds_dwordx4 (no VGPR staging, no ds_write pass), double buffered: the DMA of tile t+1 is
+// issued before the MFMAs of tile t and awaited (vmcnt(0) + barrier) after them.
 //
 // MFMA orientation (v_mfma_f32_32x32x16_f16), chosen so that softmax is lane-local:
 //   S^T[key][q] = K[key][:] . Q[q][:]      (A = K fragment from LDS, B = Q fragment held in registers)
@@ -11,21 +11,23 @@
 //        re-used in place: the accumulator layout of S^T is exactly a valid B-operand layout once the k-slots
 //        of the MFMA are mapped to keys {4h+8g+e}; the V^T fragment is read with the same key permutation).
 //     -> the per-row rescale factor alpha is per lane, no shuffles in the main loop.
-// V arrives pre-transposed ([head][d][key], written by the QKV GEMM epilogue), so both LDS tiles are filled with
-// 16-byte row-contiguous loads.  LDS layouts: K [64][64] halves with the 16-byte chunk index XOR-swizzled by
-// (key >> 1) & 7 (conflict-free ds_read_b128); V^T [64 d][64 keys] with rows padded to 144 bytes and the 4-key groups of every
-// 16 keys stored as [0-3, 8-11, 4-7, 12-15], so the 8 keys a lane feeds to one MFMA are 16 contiguous bytes
-// (conflict-free ds_read_b128 for 32 consecutive d).
+// V arrives pre-transposed AND in that k-slot order ([head][d][key'], 4-key blocks of every 16 keys stored [0, 2, 1, 3];
+// written that way by the QKV GEMM epilogue), so the 8 keys a lane feeds to one MFMA are 16 contiguous bytes of a row and
+// both tiles are plain row-contiguous copies.  LDS layouts: K [64 keys][64 d] and V^T [64 d][64 keys] halves, 128-byte
+// rows, the 16-byte chunk index XOR-swizzled by (row >> 1) & 7 -- applied to the per-lane global SOURCE address of the
+// DMA (its LDS destination is lane-linear) and to the ds_read_b128 address: conflict-free fragment reads.
 #include "ud_common.h"
 
 namespace {
 
 constexpr int KT = 64;             // keys per tile
 constexpr int KS_BYTES = 64 * 128;
-constexpr int VS_STRIDE = 144;      // 9 x 16 B: conflict-free ds_read_b128 for 32 consecutive d rows
-constexpr int VS_BYTES = 64 * VS_STRIDE;
+constexpr int VS_BYTES = 64 * 128;
 constexpr int STAGE = KS_BYTES + VS_BYTES;
 
+// ABL: ablation mask for tools/ablate_attn.py (instrumented builds only; the product instantiates ABL = 0):
+//   1 no exp/softmax VALU, 2 no P V MFMAs, 4 no Q K^T MFMAs, 8 no K/V tile traffic (global loads + LDS stores), 16 no barrier
+template <int ABL>
 __global__ __launch_bounds__(256) void attention_kernel(const UdAttention p, const float defer_thr) {
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   const int tid = threadIdx.x;
@@ -33,10 +35,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const UdAttention p, con
   const int wv = tid >> 6;
   const int hh = lane >> 5;
   const int ql = lane & 31;
-  const int head = blockIdx.y;
-  const int img = blockIdx.z;
+  // XCD-aware work map (1-D grid; workgroup b runs on XCD b % 8): the q-tiles of one (image, head) pair share its K / V^T
+  // (2 x 175 KB at N = 1370), so all of them go to ONE XCD, in consecutive dispatch slots -- with the natural 3-D grid they
+  // were spread over all 8 private L2s and every XCD pulled nearly every K/V through the fabric (rocprofv3 FETCH_SIZE
+  // 403 MB per launch against 67 MB of unique Q/K/V: the kernel ran at the fabric read rate, 4.1 TB/s, not at MFMA rate).
+  const int qt = (p.Nq + 127) >> 7;
+  const int pairs = p.B * p.H;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int pr = xcd + 8 * (slot / qt);
+  if (pr >= pairs) return;
+  const int head = pr % p.H;
+  const int img = pr / p.H;
   const int kimg = p.kv_broadcast ? (p.kv_group > 0 ? img / p.kv_group : 0) : img;
-  const int q0 = blockIdx.x * 128 + wv * 32;
+  const int q0 = (slot % qt) * 128 + wv * 32;
 
   const half_t* Q = (const half_t*)p.Q;
   const half_t* K = (const half_t*)p.K;
@@ -52,37 +63,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const UdAttention p, con
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const half8*)(qp + ks * 16);
   }
 
-  // ---- tile loader geometry: 512 16-byte chunks per operand tile, 2 per thread
+  // ---- tile loader: 512 16-byte chunks per operand tile = 8 wave-instructions of 8 rows x 128 B; wave w issues pieces 2w, 2w+1
   const int nt = (p.Nk + KT - 1) / KT;
-  half8 kreg[2], vreg[2];
-  auto gload = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = tid + 256 * i;
-      const int row = c >> 3, ch = c & 7;
-      int key = kt * KT + row;
-      key = key < p.Nk ? key : p.Nk - 1;
-      kreg[i] = *(const half8*)(K + ((size_t)kimg * p.k_rows_per_img + key) * p.ldk + head * 64 + ch * 8);
-      vreg[i] = *(const half8*)(Vt + (size_t)row * p.kv_ld + kt * KT + ch * 8);   // row = d
-    }
-  };
-  auto lstore = [&](int stage) {
+  const int lrow = lane >> 3, lch = lane & 7;
+  auto issue = [&](int kt, int stage) {
     char* sb = smem + stage * STAGE;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int c = tid + 256 * i;
-      const int row = c >> 3, ch = c & 7;
-      *(half8*)(sb + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = kreg[i];
-      half4 lo, hi;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        lo[e] = vreg[i][e];
-        hi[e] = vreg[i][4 + e];
-      }
-      // chunk ch holds keys 8ch..8ch+7; inside its 16-key group the 8-byte slots are ordered [k0-3, k8-11, k4-7, k12-15]
-      char* vp = sb + KS_BYTES + row * VS_STRIDE + (ch >> 1) * 32 + (ch & 1) * 8;
-      *(half4*)vp = lo;
-      *(half4*)(vp + 16) = hi;
+      const int piece = wv * 2 + i;
+      const int row = piece * 8 + lrow;                   // key (K tile) / d (V^T tile)
+      const int ch = lch ^ ((row >> 1) & 7);
+      int key = kt * KT + row;
+      key = key < p.Nk ? key : p.Nk - 1;
+      ud_glds16(K + ((size_t)kimg * p.k_rows_per_img + key) * p.ldk + head * 64 + ch * 8, sb + piece * 1024);
+      ud_glds16(Vt + (size_t)row * p.kv_ld + kt * KT + ch * 8, sb + KS_BYTES + piece * 1024);
     }
   };
 
@@ -95,14 +89,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const UdAttention p, con
   float l_i = 0.0f;
   const float c = p.scale * 1.4426950408889634f;
 
-  gload(0);
-  lstore(0);
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const int kswz = (ql >> 1) & 7;   // (key >> 1) & 7 for key = kb*32 + ql
   for (int kt = 0; kt < nt; ++kt) {
-    if (kt + 1 < nt) gload(kt + 1);
-    const char* sb = smem + (kt & 1) * STAGE;
+    if constexpr (!(ABL & 8)) {
+      if (kt + 1 < nt) issue(kt + 1, (kt + 1) & 1);       // every wave passed the barrier that ended tile kt-1: that stage is free
+    }
+    const char* sb = smem + ((ABL & 8) ? 0 : (kt & 1)) * STAGE;
 
     // ---- S^T = K Q^T  (two 32-key blocks)
     f32x16 s[2];
@@ -114,7 +110,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const UdAttention p, con
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const half8 kf = *(const half8*)(kp + (((ks * 2 + hh) ^ kswz) << 4));
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kb], 0, 0, 0);
+        if constexpr (ABL & 4) {
+          asm volatile("" ::"v"(kf));
+          s[kb][ks] += (float)kf[0];
+        } else {
+          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kb], 0, 0, 0);
+        }
       }
     }
     // ---- mask the key tail (last tile only)
@@ -156,8 +157,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const UdAttention p, con
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
           f32x2 pv;
-          pv[0] = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], c, -mc));
-          pv[1] = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e + 1], c, -mc));
+          if constexpr (ABL & 1) {
+            pv[0] = s[kb][t * 8 + e];
+            pv[1] = s[kb][t * 8 + e + 1];
+          } else {
+            pv[0] = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], c, -mc));
+            pv[1] = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e + 1], c, -mc));
+          }
           ls += pv[0] + pv[1];
           const half2v ph = __builtin_convertvector(pv, half2v);      // v_cvt_pk_f16_f32 (round to nearest even)
           pf[kb][t][e] = ph[0];
@@ -170,19 +176,24 @@ __global__ __launch_bounds__(256) void attention_kernel(const UdAttention p, con
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
-      const char* vrow = vs + (db * 32 + ql) * VS_STRIDE + hh * 16;
+      const char* vrow = vs + (db * 32 + ql) * 128;      // (row >> 1) & 7 == kswz for row = db*32 + ql
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const half8 vf = *(const half8*)(vrow + (kb * 2 + t) * 32);
-          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][t], o[db], 0, 0, 0);
+          const half8 vf = *(const half8*)(vrow + ((((kb * 2 + t) * 2 + hh) ^ kswz) << 4));
+          if constexpr (ABL & 2) {
+            asm volatile("" ::"v"(vf), "v"(pf[kb][t]));
+            o[db][kb * 2 + t] += (float)vf[0];
+          } else {
+            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][t], o[db], 0, 0, 0);
+          }
         }
     }
     __builtin_amdgcn_s_setprio(0);
 
-    if (kt + 1 < nt) lstore((kt + 1) & 1);
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt+1 landed; the barrier covers the others'
+    if constexpr (!(ABL & 16)) __syncthreads();
   }
 
   // ---- normalise and store O[q][head*64 + d]
@@ -212,8 +223,18 @@ extern "C" int ud_attention_f16(const UdAttention* desc, void* stream) {
     ud_set_error("ud_attention_f16: bad argument (ldq/ldk % 8, kv_ld % 64, kv_ld >= roundup(Nk, 64))");
     return UD_ERR_BAD_ARG;
   }
-  dim3 grid((d.Nq + 127) / 128, d.H, d.B);
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, (hipStream_t)stream, d, (ud_debug_flags_host() & 1) ? -1.0f : 8.0f);
+  const int qt = (d.Nq + 127) / 128, pairs = d.B * d.H;
+  dim3 grid(8 * ((pairs + 7) / 8) * qt);
+  const float thr = (ud_debug_flags_host() & 1) ? -1.0f : 8.0f;
+#ifdef UD_ABLATE
+  switch ((ud_debug_flags_host() >> 8) & 31) {
+#define UD_ABL_CASE(X) case X: hipLaunchKernelGGL(attention_kernel<X>, grid, dim3(256), 0, (hipStream_t)stream, d, thr); break;
+    UD_ABL_CASE(1) UD_ABL_CASE(2) UD_ABL_CASE(3) UD_ABL_CASE(4) UD_ABL_CASE(7) UD_ABL_CASE(8) UD_ABL_CASE(9) UD_ABL_CASE(24) UD_ABL_CASE(25) UD_ABL_CASE(31)
+    default: hipLaunchKernelGGL(attention_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, d, thr);
+  }
+#else
+  hipLaunchKernelGGL(attention_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, d, thr);
+#endif
   UD_CHECK_LAUNCH("ud_attention_f16 launch");
   return UD_OK;
 }

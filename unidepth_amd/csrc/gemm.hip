@@ -103,7 +103,9 @@ __device__ __forceinline__ void gemm_epilogue_impl(const UdGemm& p, f32x4 (&acc)
         half4 h;
 #pragma unroll
         for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[i][j][r] + bv);
-        *(half4*)(vt + (((size_t)img * p.heads_v + hd) * 64 + d) * p.kv_ld + t) = h;
+        // V^T key order inside every aligned 16-key group: 4-key blocks [0, 2, 1, 3] (include/unidepth_hip.h, UD_EPI_QKV)
+        const int tp = (t & ~15) | ((t & 4) << 1) | ((t & 8) >> 1);
+        *(half4*)(vt + (((size_t)img * p.heads_v + hd) * 64 + d) * p.kv_ld + tp) = h;
       }
     }
     return;
@@ -468,6 +470,11 @@ __device__ __forceinline__ void ud_pair16(unsigned& a, unsigned& b) {
   a = r[0];
   b = r[1];
 }
+__device__ __forceinline__ void ud_pair32(unsigned& a, unsigned& b) {     // a: lanes 32-63 <-> b: lanes 0-31
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
+}
 __device__ __forceinline__ unsigned ud_pack2(float x, float y) {
   f32x2 v; v[0] = x; v[1] = y;
   const half2v h = __builtin_convertvector(v, half2v);
@@ -698,7 +705,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
     // v_permlane16_swap of the packed dwords of tiles j / j+1 leaves lane q with 8 consecutive columns starting at
     // nbase + 16 (j + (q & 1)) + 8 (q >> 1): 16-byte stores, 64-byte row segments.  V^T tiles (!SWAP) own 4 consecutive rows
     // (tokens) per lane; the same exchange between row tiles i / i+1 gives 8 consecutive tokens starting at
-    // mbase + 16 (i + (q & 1)) + 8 (q >> 1).
+    // (v_permlane32_swap between row tiles i / i+1 packs them in the V^T block order, see below).
     const bool full = (m0 + BM <= p.M) && (n0 + 256 <= p.N) && p.rows_in == 0 && p.add == nullptr && p.bias != nullptr;
     bool fast = false;
     int eln = lane;
@@ -740,7 +747,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
         }
       } else {
         if constexpr (EPI == UD_EPI_QKV) {
-          fast = full && (p.tok_per_img & 7) == 0 && (p.kv_ld & 7) == 0;
+          fast = full && (p.tok_per_img & 15) == 0 && (p.kv_ld & 7) == 0;
           if (fast) {
             half_t* vt = (half_t*)p.out2;
 #pragma unroll
@@ -756,11 +763,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
                 w0[1] = ud_pack2(acc[2 * ip][j][2] + bvn, acc[2 * ip][j][3] + bvn);
                 w1[0] = ud_pack2(acc[2 * ip + 1][j][0] + bvn, acc[2 * ip + 1][j][1] + bvn);
                 w1[1] = ud_pack2(acc[2 * ip + 1][j][2] + bvn, acc[2 * ip + 1][j][3] + bvn);
-                ud_pair16(w0[0], w1[0]);
-                ud_pair16(w0[1], w1[1]);
-                const int mb = mbase + 16 * (2 * ip + (fq & 1)) + 8 * (fq >> 1);
+                // half-wave exchange between row tiles 2ip / 2ip+1: lane q ends up with tokens {4 (q & 1) .. +3, 8 + 4 (q & 1) .. +3}
+                // of row tile 2ip + (q >> 1), i.e. one 16-byte chunk of the [0, 2, 1, 3] block order of that 16-token group
+                ud_pair32(w0[0], w1[0]);
+                ud_pair32(w0[1], w1[1]);
+                const int mb = mbase + 16 * (2 * ip + (fq >> 1));
                 const int img = mb / p.tok_per_img;
-                const int tk = mb - img * p.tok_per_img;
+                const int tk = mb - img * p.tok_per_img + 8 * (fq & 1);
                 u32x4 s;
                 s[0] = w0[0]; s[1] = w0[1]; s[2] = w1[0]; s[3] = w1[1];
                 *(u32x4*)(vrow + (size_t)img * p.heads_v * 64 * p.kv_ld + tk) = s;

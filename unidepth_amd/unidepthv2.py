@@ -77,7 +77,7 @@ class _Plan:
         self.h, self.w = h, wg
         hw = h * wg
         N = hw + 1
-        Np = _rup(N, 8)               # token rows per image (encoder stream)
+        Np = _rup(N, 16)              # token rows per image (encoder stream; 16: V^T block order of the QKV epilogue)
         hwp = _rup(hw, 8)             # token rows per image (decoder streams)
         Nkp = _rup(N, 64)
         hwkp = _rup(hw, 64)
