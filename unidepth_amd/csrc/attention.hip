@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const UdAttention p, con
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wv = tid >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5;
   const int ql = lane & 31;
   // XCD-aware work map (1-D grid; workgroup b runs on XCD b % 8): the q-tiles of one (image, head) pair share its K / V^T
@@ -63,20 +63,29 @@ __global__ __launch_bounds__(256) void attention_kernel(const UdAttention p, con
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const half8*)(qp + ks * 16);
   }
 
-  // ---- tile loader: 512 16-byte chunks per operand tile = 8 wave-instructions of 8 rows x 128 B; wave w issues pieces 2w, 2w+1
+  // ---- tile loader: 512 16-byte chunks per operand tile = 8 wave-instructions of 8 rows x 128 B; wave w issues pieces 2w, 2w+1.
+  // Buffer-descriptor DMA: V^T advances by an SGPR offset (no VALU); K by one v_add per piece, and its descriptor ends after
+  // key Nk-1, so the rows of the last tile beyond the sequence read as zeros instead of the next image's keys.
   const int nt = (p.Nk + KT - 1) / KT;
   const int lrow = lane >> 3, lch = lane & 7;
+  const ud_rsrc_t rK = ud_make_rsrc(K + (size_t)kimg * p.k_rows_per_img * p.ldk + head * 64, (unsigned)((p.Nk - 1) * p.ldk + 64) * 2u);
+  const ud_rsrc_t rV = ud_make_rsrc(Vt, 64u * (unsigned)p.kv_ld * 2u);
+  unsigned koff[2], voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (wv * 2 + i) * 8 + lrow;              // key (K tile) / d (V^T tile)
+    const int ch = lch ^ ((row >> 1) & 7);
+    koff[i] = (unsigned)(row * p.ldk + ch * 8) * 2u;
+    voff[i] = (unsigned)(row * p.kv_ld + ch * 8) * 2u;
+  }
+  const unsigned kstep = (unsigned)(KT * p.ldk) * 2u;
   auto issue = [&](int kt, int stage) {
     char* sb = smem + stage * STAGE;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int piece = wv * 2 + i;
-      const int row = piece * 8 + lrow;                   // key (K tile) / d (V^T tile)
-      const int ch = lch ^ ((row >> 1) & 7);
-      int key = kt * KT + row;
-      key = key < p.Nk ? key : p.Nk - 1;
-      ud_glds16(K + ((size_t)kimg * p.k_rows_per_img + key) * p.ldk + head * 64 + ch * 8, sb + piece * 1024);
-      ud_glds16(Vt + (size_t)row * p.kv_ld + kt * KT + ch * 8, sb + KS_BYTES + piece * 1024);
+      ud_bufl16(rK, koff[i] + (unsigned)kt * kstep, 0, sb + piece * 1024);
+      ud_bufl16(rV, voff[i], kt * (KT * 2), sb + KS_BYTES + piece * 1024);
     }
   };
 
@@ -226,14 +235,15 @@ extern "C" int ud_attention_f16(const UdAttention* desc, void* stream) {
   const int qt = (d.Nq + 127) / 128, pairs = d.B * d.H;
   dim3 grid(8 * ((pairs + 7) / 8) * qt);
   const float thr = (ud_debug_flags_host() & 1) ? -1.0f : 8.0f;
+  const int extra_lds = ((ud_debug_flags_host() >> 16) & 255) * 1024;   // tools only: occupancy experiments
 #ifdef UD_ABLATE
   switch ((ud_debug_flags_host() >> 8) & 31) {
-#define UD_ABL_CASE(X) case X: hipLaunchKernelGGL(attention_kernel<X>, grid, dim3(256), 0, (hipStream_t)stream, d, thr); break;
+#define UD_ABL_CASE(X) case X: hipLaunchKernelGGL(attention_kernel<X>, grid, dim3(256), extra_lds, (hipStream_t)stream, d, thr); break;
     UD_ABL_CASE(1) UD_ABL_CASE(2) UD_ABL_CASE(3) UD_ABL_CASE(4) UD_ABL_CASE(7) UD_ABL_CASE(8) UD_ABL_CASE(9) UD_ABL_CASE(24) UD_ABL_CASE(25) UD_ABL_CASE(31)
-    default: hipLaunchKernelGGL(attention_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, d, thr);
+    default: hipLaunchKernelGGL(attention_kernel<0>, grid, dim3(256), extra_lds, (hipStream_t)stream, d, thr);
   }
 #else
-  hipLaunchKernelGGL(attention_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, d, thr);
+  hipLaunchKernelGGL(attention_kernel<0>, grid, dim3(256), extra_lds, (hipStream_t)stream, d, thr);
 #endif
   UD_CHECK_LAUNCH("ud_attention_f16 launch");
   return UD_OK;
