@@ -514,6 +514,12 @@ def test_camera_fp32_island(ops):
     ref = out0 + F.gelu(x @ W.t() + bias + pos.repeat(B, 1))
     torch.cuda.synchronize()
     assert rel(out, ref) < 2e-6
+    for (M2, N2, K2) in ((40, 10, 200), (32, 1, 512), (5, 2048, 2048)):      # 2 row chunks / K tail / single column / long K
+        x2 = rnd(M2, K2, seed=11); W2 = rnd(N2, K2, scale=K2 ** -0.5, seed=12); o2 = torch.zeros(M2, N2, device="cuda")
+        d2 = ops.mk(ops.UdLinearF32, x=x2, W=W2, out=o2, M=M2, N=N2, K=K2, ldx=K2, ldw=K2, ldc=N2)
+        ops.check(ops.lib.ud_linear_f32(C.byref(d2), ops.cur_stream()))
+        torch.cuda.synchronize()
+        assert rel(o2, x2 @ W2.t()) < 2e-6, (M2, N2, K2)
     q = rnd(M, Cc, seed=6); kv = rnd(M, 2 * Cc, seed=7); o = torch.zeros(M, Cc, device="cuda")
     ops.check(ops.lib.ud_attention_small_f32(q.data_ptr(), kv.data_ptr(), o.data_ptr(), B, T, H, Cc, 0.2, ops.cur_stream()))
     hd = Cc // H

@@ -4,46 +4,81 @@
 
 namespace {
 
-// one wave per output column n; the 64 lanes split K (16 B per lane per step, coalesced, branch-free), every lane carries
-// partial sums for up to 32 rows; wave reductions at the end.  W is streamed exactly once, x (<= 256 KB) comes from L1/L2.
-// (Measured alternatives on MI355X -- K split over several waves per column, reduce-scatter shuffles -- were slower: every
-// extra wave re-reads the activation slice and the kernel is bound by that L2 traffic, not by the shuffles.)
+// out[m, n] for m < 32 rows (a batch chunk), 8 columns per workgroup: thread (m = tid & 31, c = tid >> 5) owns ONE output element
+// and walks K sequentially -- no cross-lane reduction, a fixed summation order.  Both operands are staged through LDS in
+// K-chunks of 256 floats by global_load_lds (one 1 KB row piece per wave-instruction, rows padded by 16 B so the 16 lanes of a
+// ds_read_b128 group hit 64 distinct banks), double buffered; the W fragment of a column is a broadcast read.
+// The first version (one wave per column, K split over the lanes, every wave re-reading the whole activation block through
+// L1) ran 13-38 us per layer at M = 32 -- the 20-launch camera chain cost 0.43 ms per infer(); it was bound by the
+// 32 x K x 4 B activation re-read per wave, not by the 1-4 MB of weights.
+constexpr int LF_KC = 256;                    // floats per K-chunk
+constexpr int LF_ROWB = LF_KC * 4 + 16;       // bytes per staged row
+constexpr int LF_STAGE = 40 * LF_ROWB;        // 32 x rows + 8 W rows
+
 __global__ __launch_bounds__(256) void linear_f32_kernel(const UdLinearF32 p) {
-  const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (n >= p.N) return;
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // 2 * LF_STAGE (83 KB: above the 64 KB static limit)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = tid & 31, c = tid >> 5;
+  const int n0 = blockIdx.x * 8;
   const int m0 = blockIdx.y * 32;
   const int rows = (p.M - m0) < 32 ? (p.M - m0) : 32;
-  float acc[32];
+  const int nch = (p.K + LF_KC - 1) / LF_KC;
+
+  // wave w stages x rows 8w .. 8w+7 and W rows 2w, 2w+1 (rows / columns past the end re-read the last valid one; K tail lanes
+  // read offset 0 and are never multiplied)
+  auto issue = [&](int ch, int stage) {
+    char* sb = smem + stage * LF_STAGE;
+    const int k = ch * LF_KC + lane * 4;
+    const bool kok = k < p.K;
 #pragma unroll
-  for (int m = 0; m < 32; ++m) acc[m] = 0.f;
-  const float* wr = p.W + (size_t)n * p.ldw;
-  const float* xb = p.x + (size_t)m0 * p.ldx;
-  for (int k = lane * 4; k < p.K; k += 256) {
-    const f32x4 wv = *(const f32x4*)(wr + k);
-    f32x4 xv[32];
-#pragma unroll
-    for (int m = 0; m < 32; ++m) {          // rows beyond the batch re-read the last valid row (results unused)
-      const int mr = m < rows ? m : rows - 1;
-      xv[m] = *(const f32x4*)(xb + (size_t)mr * p.ldx + k);
+    for (int i = 0; i < 8; ++i) {
+      int r = wv * 8 + i;
+      r = r < rows ? r : rows - 1;
+      ud_glds16(p.x + (size_t)(m0 + r) * p.ldx + (kok ? k : 0), sb + (wv * 8 + i) * LF_ROWB);
     }
 #pragma unroll
-    for (int m = 0; m < 32; ++m)
-      acc[m] = fmaf(xv[m][0], wv[0], fmaf(xv[m][1], wv[1], fmaf(xv[m][2], wv[2], fmaf(xv[m][3], wv[3], acc[m]))));
+    for (int i = 0; i < 2; ++i) {
+      int n = n0 + wv * 2 + i;
+      n = n < p.N ? n : p.N - 1;
+      ud_glds16(p.W + (size_t)n * p.ldw + (kok ? k : 0), sb + (32 + wv * 2 + i) * LF_ROWB);
+    }
+  };
+
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;     // 4 independent FMA chains (k mod 4), summed in a fixed order at the end
+  issue(0, 0);
+  for (int ch = 0; ch < nch; ++ch) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                          // chunk ch landed for every wave; everyone is done reading the other stage
+    if (ch + 1 < nch) issue(ch + 1, (ch + 1) & 1);
+    const char* xs = smem + (ch & 1) * LF_STAGE + m * LF_ROWB;
+    const char* ws = smem + (ch & 1) * LF_STAGE + (32 + c) * LF_ROWB;
+    const int kn = (p.K - ch * LF_KC) < LF_KC ? (p.K - ch * LF_KC) : LF_KC;      // multiple of 4
+    if (kn == LF_KC) {
+#pragma unroll 16
+      for (int k4 = 0; k4 < LF_KC / 4; ++k4) {
+        const f32x4 xv = *(const f32x4*)(xs + k4 * 16);
+        const f32x4 wq = *(const f32x4*)(ws + k4 * 16);
+        a0 = fmaf(xv[0], wq[0], a0); a1 = fmaf(xv[1], wq[1], a1); a2 = fmaf(xv[2], wq[2], a2); a3 = fmaf(xv[3], wq[3], a3);
+      }
+    } else {
+      for (int k4 = 0; k4 < kn / 4; ++k4) {
+        const f32x4 xv = *(const f32x4*)(xs + k4 * 16);
+        const f32x4 wq = *(const f32x4*)(ws + k4 * 16);
+        a0 = fmaf(xv[0], wq[0], a0); a1 = fmaf(xv[1], wq[1], a1); a2 = fmaf(xv[2], wq[2], a2); a3 = fmaf(xv[3], wq[3], a3);
+      }
+    }
   }
-  float mine = 0.f;   // lane m keeps the reduced value of row m
-#pragma unroll
-  for (int m = 0; m < 32; ++m) {
-    const float s = ud_wave_sum(acc[m]);
-    if (lane == m) mine = s;
-  }
-  if (lane < rows) {
-    const int m = m0 + lane;
-    float y = mine;
+  const float acc = (a0 + a1) + (a2 + a3);
+  const int n = n0 + c;
+  if (m < rows && n < p.N) {
+    const int mm = m0 + m;
+    float y = acc;
     if (p.bias) y += p.bias[n];
-    if (p.add) y += p.add[(size_t)(m % p.add_mod) * p.ldadd + n];
+    if (p.add) y += p.add[(size_t)(mm % p.add_mod) * p.ldadd + n];
     if (p.act == UD_ACT_GELU) y = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
-    float* o = p.out + (size_t)m * p.ldc + n;
+    float* o = p.out + (size_t)mm * p.ldc + n;
     *o = p.accumulate ? *o + y : y;
   }
 }
@@ -93,7 +128,15 @@ extern "C" int ud_linear_f32(const UdLinearF32* desc, void* stream) {
     ud_set_error("ud_linear_f32: bad argument (K, ldx, ldw % 4 == 0)");
     return UD_ERR_BAD_ARG;
   }
-  hipLaunchKernelGGL(linear_f32_kernel, dim3((d.N + 3) / 4, (d.M + 31) / 32), dim3(256), 0, (hipStream_t)stream, d);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)linear_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LF_STAGE) != hipSuccess) {
+      ud_set_error("ud_linear_f32: cannot reserve the LDS staging ring");
+      return UD_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(linear_f32_kernel, dim3((d.N + 7) / 8, (d.M + 31) / 32), dim3(256), 2 * LF_STAGE, (hipStream_t)stream, d);
   UD_CHECK_LAUNCH("ud_linear_f32 launch");
   return UD_OK;
 }
