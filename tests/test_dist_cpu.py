@@ -58,3 +58,77 @@ def test_shard_bounds():
     assert shard_bounds(64, 8) == [(i * 8, i * 8 + 8) for i in range(8)]
     assert shard_bounds(5, 2) == [(0, 3), (3, 5)]
     assert shard_bounds(1, 2) == [(0, 1), (1, 1)]
+
+
+class _FakeShapeModel:
+    """Engine stand-in for mixed-shape lists: per-image outputs, depth at the input resolution."""
+    shape_constraints = {"ratio_bounds": [0.5, 2.5], "pixels_min": 200000.0, "pixels_max": 600000.0}
+
+    def __init__(self):
+        self.calls = []
+
+    def infer(self, rgb, camera=None):
+        x = rgb.float()
+        B = x.shape[0]
+        self.calls.append(tuple(x.shape))
+        return {"depth": x.mean(dim=1, keepdim=True) + 1.0, "confidence": x[:, :1] * 2.0,
+                "intrinsics": x.reshape(B, -1)[:, :9].reshape(B, 3, 3).clone()}
+
+
+def _mixed_images():
+    g = torch.Generator().manual_seed(3)
+    shapes = [(6, 5), (4, 7), (6, 5), (6, 5), (4, 7), (8, 8), (6, 5)]
+    return [torch.randint(0, 256, (3, h, w), dtype=torch.uint8, generator=g) for h, w in shapes]
+
+
+def _worker_mixed(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unidepth_amd.dist import infer_mixed
+    imgs = _mixed_images()
+    model = _FakeShapeModel()
+    out = infer_mixed(model, imgs, keys=("depth", "intrinsics"), max_batch=2)
+    ok = len(out) == len(imgs)
+    for im, o in zip(imgs, out):
+        ref = _FakeShapeModel().infer(im[None])
+        ok = ok and torch.equal(o["depth"], ref["depth"][0]) and torch.equal(o["intrinsics"], ref["intrinsics"][0])
+    ok = ok and all(c[0] <= 2 for c in model.calls) and 0 < len(model.calls) < len(imgs)      # shared the work, batched by shape
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_infer_mixed_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_mixed, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_plan_mixed_balance_and_single_process():
+    from unidepth_amd.dist import infer_mixed, plan_mixed
+    shapes = [(644, 966)] * 16 + [(518, 518)] * 16                   # BASELINE.json configs[4]
+    costs = [2.7] * 16 + [1.0] * 16
+    micro, owner = plan_mixed(shapes, costs, 8, 8)
+    load = [0.0] * 8
+    for (s, idx), r in zip(micro, owner):
+        assert len({shapes[i] for i in idx}) == 1 and len(idx) <= 8
+        load[r] += sum(costs[i] for i in idx)
+    assert sorted(i for _, idx in micro for i in idx) == list(range(32))
+    assert max(load) <= 1.15 * sum(costs) / 8                         # within 15 % of a perfectly even split
+    micro1, owner1 = plan_mixed(shapes, costs, 1, 8)                  # one GPU: full micro-batches, bucketed
+    assert [len(idx) for _, idx in micro1] == [8, 8, 8, 8] and set(owner1) == {0}
+    imgs = _mixed_images()
+    model = _FakeShapeModel()
+    out = infer_mixed(model, imgs, keys=("depth", "intrinsics"), max_batch=8)        # no process group: runs everything here
+    for im, o in zip(imgs, out):
+        ref = _FakeShapeModel().infer(im[None])
+        assert torch.equal(o["depth"], ref["depth"][0])
+    assert sorted(model.calls) == sorted([(4, 3, 6, 5), (2, 3, 4, 7), (1, 3, 8, 8)])

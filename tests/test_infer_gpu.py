@@ -135,3 +135,24 @@ def test_infer_more_shapes_and_call_forms(engine_cls, arch, H, W, B, normalize, 
     out = model.infer(x.cuda(), None, normalize=normalize)
     torch.cuda.synchronize()
     _check(out, ref, f"{arch}_{H}x{W}_b{B}_norm{int(normalize)}")
+
+
+def test_infer_mixed_shapes_single_gpu(engine_cls):
+    """Mixed-resolution list (BASELINE configs[4] pattern, small model): bucketed micro-batches must reproduce per-image infer()
+    -- exactly: the kernels' summation orders do not depend on batch size or batch position."""
+    from unidepth_amd.dist import infer_mixed
+    cfg = synth.load_config("vits14")
+    sd = synth.make_synthetic_checkpoint(cfg, 31)
+    model = engine_cls(cfg).load_state_dict(sd).to("cuda").eval()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(240, 320), (196, 252), (240, 320), (240, 320), (196, 252)]
+    imgs = [torch.randint(0, 256, (3, h, w), dtype=torch.uint8, generator=g).cuda() for h, w in shapes]
+    outs = infer_mixed(model, imgs, keys=("depth", "intrinsics", "confidence"), max_batch=2)
+    torch.cuda.synchronize()
+    assert len(outs) == len(imgs)
+    for im, o in zip(imgs, outs):
+        ref = model.infer(im)
+        assert o["depth"].shape == (1, im.shape[1], im.shape[2])
+        d = ((o["depth"] - ref["depth"][0]).abs() / ref["depth"][0]).mean().item()
+        assert d <= 1e-5, d
+        assert ((o["intrinsics"] - ref["intrinsics"][0]).abs() / ref["intrinsics"][0].abs().clamp_min(1.0)).max().item() <= 1e-5

@@ -68,3 +68,108 @@ def infer_data_parallel(model, rgb: torch.Tensor, camera=None, keys: Optional[It
             continue
         res[k] = all_gather_batch(t.contiguous(), counts, group)
     return res
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Mixed-resolution batches (BASELINE.json configs[4]: e.g. 16 x 644x966 + 16 x 518x518 over 8 GPUs).  One infer() call takes
+# one image shape (as in the reference, whose infer() cannot mix shapes either), so a list of images is bucketed by shape,
+# cut into micro-batches and the micro-batches are spread over the ranks by estimated cost: a 3128-token image costs ~2.7x a
+# 1369-token one, a contiguous split of the list would leave ranks idle.
+# --------------------------------------------------------------------------------------------------------------------
+def image_cost(model, H: int, W: int) -> float:
+    """Relative cost of one image = algorithmic FLOP of encoder + decoder at the network resolution the shape policy picks
+    (SURVEY.md 8(d) model: per encoder layer 24 N D^2 + 4 N^2 D; decoder ~ 0.35 of the encoder at 1369 tokens, linear in N)."""
+    from .unidepthv2 import get_paddings, get_resize_factor
+    sc = model.shape_constraints
+    _, (Hp, Wp) = get_paddings((H, W), sc["ratio_bounds"])
+    bounds = model._pixels_bounds() if hasattr(model, "_pixels_bounds") else (sc["pixels_min"], sc["pixels_max"])
+    _, (Hn, Wn) = get_resize_factor((Hp, Wp), bounds)
+    n = (Hn // 14) * (Wn // 14) + 1
+    arch = getattr(model, "_arch", None) or {"D": 1024, "depth": 24}
+    D, depth = arch["D"], arch["depth"]
+    enc = depth * (24.0 * n * D * D + 4.0 * n * n * D)
+    dec = 258.0e6 * n * (D / 1024.0)
+    return enc + dec
+
+
+def plan_mixed(shapes: List[Tuple[int, int]], costs: List[float], world: int, max_batch: int = 8):
+    """Deterministic plan (identical on every rank): bucket image indices by (H, W), cut buckets into micro-batches of at most
+    `max_batch` images, assign micro-batches to ranks longest-first onto the least-loaded rank (ties -> lowest rank).
+    Returns (micro_batches, owner): micro_batches[j] = (shape, [image indices]); owner[j] = rank."""
+    buckets: Dict[Tuple[int, int], List[int]] = {}
+    for i, s in enumerate(shapes):
+        buckets.setdefault(tuple(s), []).append(i)
+    micro = []
+    # micro-batch granularity: about three micro-batches per rank (a third of the per-rank cost share each) keeps the greedy
+    # assignment within a few % of even, while micro-batches stay as large as that allows (larger batches run faster per image)
+    share = sum(costs) / (3.0 * world) if world > 1 else float("inf")
+    for s in sorted(buckets):
+        idx = buckets[s]
+        cap = max(1, min(max_batch, int(share / max(costs[idx[0]], 1e-30)))) if world > 1 else max_batch
+        nmb = -(-len(idx) // cap)
+        per = -(-len(idx) // nmb)                      # even micro-batches rather than full ones + a small remainder
+        micro += [(s, idx[k:k + per]) for k in range(0, len(idx), per)]
+    order = sorted(range(len(micro)), key=lambda j: (-sum(costs[i] for i in micro[j][1]), j))
+    load = [0.0] * world
+    owner = [0] * len(micro)
+    for j in order:
+        r = min(range(world), key=lambda q: (load[q], q))
+        owner[j] = r
+        load[r] += sum(costs[i] for i in micro[j][1])
+    return micro, owner
+
+
+def infer_mixed(model, images: List[torch.Tensor], cameras: Optional[List[Optional[torch.Tensor]]] = None,
+                keys: Iterable[str] = ("depth", "confidence", "intrinsics"), max_batch: int = 8, group=None, **kw) -> List[Dict[str, torch.Tensor]]:
+    """infer() over a list of [3,H,W] images of arbitrary, mixed shapes.  Single process (no initialised process group): the
+    micro-batches run back to back on this GPU.  Under torch.distributed every rank passes the SAME list, runs the micro-batches
+    the plan gives it and all ranks return the complete, ordered result list; one all-gather per shape bucket (the outputs of a
+    bucket have one shape, so all requested keys travel packed in one message)."""
+    keys = list(keys)
+    distributed = dist.is_available() and dist.is_initialized()
+    world, rank = (dist.get_world_size(group), dist.get_rank(group)) if distributed else (1, 0)
+    shapes = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
+    costs = [image_cost(model, h, w) for h, w in shapes]
+    micro, owner = plan_mixed(shapes, costs, world, max_batch)
+    results: List[Optional[Dict[str, torch.Tensor]]] = [None] * len(images)
+    mine: Dict[Tuple[int, int], List[Tuple[List[int], Dict[str, torch.Tensor]]]] = {}
+    for (s, idx), r in zip(micro, owner):
+        if r != rank:
+            continue
+        rgb = torch.stack([images[i] for i in idx])
+        cam = None
+        if cameras is not None and all(cameras[i] is not None for i in idx):
+            cam = torch.stack([cameras[i] for i in idx])
+        out = model.infer(rgb, cam, **kw)
+        mine.setdefault(s, []).append((idx, {k: out[k] for k in keys}))
+        if not distributed:
+            for b, i in enumerate(idx):
+                results[i] = {k: out[k][b] for k in keys}
+    if not distributed:
+        return results  # type: ignore[return-value]
+    for s in sorted({m[0] for m in micro}):
+        # rank r owns these images of the bucket, in plan order
+        per_rank = [[i for (ss, idx), r in zip(micro, owner) if ss == s and r == q for i in idx] for q in range(world)]
+        counts = [len(p) for p in per_rank]
+        H, W = s
+        widths = {"depth": H * W, "confidence": H * W, "radius": H * W, "points": 3 * H * W, "rays": 3 * H * W, "intrinsics": 9}
+        tail = {"depth": (1, H, W), "confidence": (1, H, W), "radius": (1, H, W), "points": (3, H, W), "rays": (3, H, W), "intrinsics": (3, 3)}
+        for k in keys:
+            if k not in widths:
+                raise KeyError(f"infer_mixed: output '{k}' has no shape rule (depth_features depends on the network grid)")
+        dev = next(iter(mine[s][0][1].values())).device if s in mine else (images[0].device if images[0].is_cuda else torch.device("cpu"))
+        if counts[rank]:
+            packed = torch.cat([torch.cat([o[k].reshape(o[k].shape[0], -1).float() for k in keys], dim=1) for _, o in mine[s]], dim=0)
+        else:
+            packed = torch.zeros((0, sum(widths[k] for k in keys)), dtype=torch.float32, device=dev)
+        g = all_gather_batch(packed.contiguous(), counts, group)
+        row = 0
+        for q in range(world):
+            for i in per_rank[q]:
+                off = 0
+                results[i] = {}
+                for k in keys:
+                    results[i][k] = g[row, off:off + widths[k]].reshape(tail[k])
+                    off += widths[k]
+                row += 1
+    return results  # type: ignore[return-value]
