@@ -156,3 +156,24 @@ def test_infer_mixed_shapes_single_gpu(engine_cls):
         d = ((o["depth"] - ref["depth"][0]).abs() / ref["depth"][0]).mean().item()
         assert d <= 1e-5, d
         assert ((o["intrinsics"] - ref["intrinsics"][0]).abs() / ref["intrinsics"][0].abs().clamp_min(1.0)).max().item() <= 1e-5
+
+
+def test_pipeline_two_calls_in_flight(engine_cls):
+    """unidepth_amd.pipeline: calls on separate HIP streams with separate buffer slots reproduce sequential infer() bit for bit
+    (shared read-only weights, no shared activation state)."""
+    from unidepth_amd.pipeline import InferPipeline
+    cfg = synth.load_config("vits14")
+    sd = synth.make_synthetic_checkpoint(cfg, 31)
+    model = engine_cls(cfg).load_state_dict(sd).to("cuda").eval()
+    g = torch.Generator().manual_seed(9)
+    batches = [torch.randint(0, 256, (2, 3, 252, 336), dtype=torch.uint8, generator=g).cuda() for _ in range(5)]
+    refs = [model.infer(b) for b in batches]
+    torch.cuda.synchronize()
+    pipe = InferPipeline(model, depth=2)
+    outs = [pipe.submit(b) for b in batches]
+    for o in outs:
+        pipe.wait(o)
+    pipe.sync()
+    for o, r in zip(outs, refs):
+        for k in r:
+            assert torch.equal(o[k], r[k]), k

@@ -419,9 +419,9 @@ class UniDepthV2:
         warnings.warn("!! self.resolution_level not set, using default bounds !!")
         return (lo, hi)
 
-    def _plan(self, B, H, W, cam_nb, is_u8, normalize) -> _Plan:
+    def _plan(self, B, H, W, cam_nb, is_u8, normalize, slot=0) -> _Plan:
         bounds = self._pixels_bounds()
-        key = (B, H, W, cam_nb, is_u8, normalize, bounds)
+        key = (B, H, W, cam_nb, is_u8, normalize, bounds, slot)
         plan = self._plans.get(key)
         if plan is None:
             with torch.cuda.device(self._device):
@@ -431,8 +431,10 @@ class UniDepthV2:
 
     # ---- the hot path ----
     @torch.no_grad()
-    def infer(self, rgb: torch.Tensor, camera=None, normalize: bool = True):
-        """Same contract as the reference infer() (unidepthv2.py:239-339)."""
+    def infer(self, rgb: torch.Tensor, camera=None, normalize: bool = True, *, slot: int = 0):
+        """Same contract as the reference infer() (unidepthv2.py:239-339).  `slot` (engine extension, keyword only) selects an
+        independent set of activation buffers: calls with different slots may be in flight at the same time on different HIP
+        streams (unidepth_amd/pipeline.py); calls with the same slot must be stream-ordered, as with the reference module."""
         if self.interpolation_mode != "bilinear":
             raise NotImplementedError("only interpolation_mode='bilinear' (the reference default) is implemented")
         self._ensure_packed()
@@ -448,7 +450,7 @@ class UniDepthV2:
             Kc = Kc.detach().reshape(-1, 3, 3).float().cpu()
         is_u8 = rgb.dtype == torch.uint8
         with torch.cuda.device(self._device):
-            plan = self._plan(B, H, W, 0 if Kc is None else Kc.shape[0], is_u8, bool(normalize))
+            plan = self._plan(B, H, W, 0 if Kc is None else Kc.shape[0], is_u8, bool(normalize), int(slot))
             plan.rgb.copy_(rgb if is_u8 else rgb.float(), non_blocking=True)
             if Kc is not None:
                 pl, _, pt, _ = plan.paddings
