@@ -90,12 +90,8 @@ def main():
 
     def step():
         """One full infer() of the batch; up to --inflight steps overlap on separate HIP streams (independent batches of a
-        stream of requests).  The all-gather of a step is ordered behind that step's outputs on the main stream."""
-        out = pipe.submit(rgb)
-        if world > 1:
-            pipe.wait(out)
-            gather(out)
-        return out
+        stream of requests).  The all-gather of a step is issued on that step's stream, right behind its outputs."""
+        return pipe.submit(rgb, post=gather if world > 1 else None)
 
     def step_single():
         out = model.infer(rgb)

@@ -32,13 +32,17 @@ class InferPipeline:
         self._n = 0
         self._pending: Dict[int, torch.cuda.Event] = {}
 
-    def submit(self, rgb: torch.Tensor, camera=None, normalize: bool = True) -> Dict[str, torch.Tensor]:
+    def submit(self, rgb: torch.Tensor, camera=None, normalize: bool = True, post=None) -> Dict[str, torch.Tensor]:
+        """`post(out)`, if given, runs in the call's stream context right behind infer() (e.g. the RCCL all-gather of a
+        data-parallel step: it must not sit on the caller's stream, where it would order the next submission behind itself)."""
         i = self._n % self.depth
         self._n += 1
         st = self.streams[i]
         st.wait_stream(torch.cuda.current_stream(self.model.device))      # inputs produced on the caller's stream
         with torch.cuda.stream(st):
             out = self.model.infer(rgb, camera, normalize, slot=i)
+            if post is not None:
+                post(out)
             ev = torch.cuda.Event()
             ev.record(st)
         self._events[i] = ev
