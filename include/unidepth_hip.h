@@ -159,7 +159,10 @@ int ud_camera_intrinsics(const float* raw, int raw_stride, float* intr4, float* 
 
 /* rays [nb,3,Hn,Wn] fp32 = normalise(Kinv @ [u+0.5, v+0.5, 1]) (utils/coordinate.py:4-20 pixel centres).
  * gt_mode 0: predicted camera, norm clamp 1e-5 (decoder.py:389-393);
- * gt_mode 1: user camera (utils/camera.py:254-266 Pinhole.unproject: divide by z.clip(1e-4); :88-92 norm clamp 1e-4). */
+ * gt_mode 1: user camera (utils/camera.py:254-266 Pinhole.unproject: divide by z.clip(1e-4); :88-92 norm clamp 1e-4).
+ * gt_mode 2 / 3: user EUCM / Spherical camera (utils/camera.py:307-328 / :371-386 unproject + :88-92 get_rays); the 9 floats per
+ *   camera are then the model parameters at network resolution: (fx, fy, cx, cy, alpha, beta, -, -, -) resp.
+ *   (fx, fy, cx, cy, width, height, hfov/2, vfov/2, -) instead of an inverse intrinsic matrix. */
 int ud_rays_from_kinv(const float* Kinv33, float* rays, int nb, int Hn, int Wn, int gt_mode, void* stream);
 
 /* ray embedding (decoder.py:234-253): antialiased bilinear down-sample of rays [nb,3,Hn,Wn] to (h,w)

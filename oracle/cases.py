@@ -18,13 +18,21 @@ CASES = {
     "vitb_518x518_b1": dict(arch="vitb14", H=518, W=518, B=1, camera=False, ckpt_seed=124, img_seed=4),
     # BASELINE.json configs[1] at bs=1 (same network shape as the headline bs=8 workload)
     "vitl_518x518_b1": dict(arch="vitl14", H=518, W=518, B=1, camera=False, ckpt_seed=125, img_seed=5),
+    # non-pinhole GT cameras: EUCM fisheye-like, and an equirectangular strip wide enough to be aspect-padded
+    "vits_300x400_eucm": dict(arch="vits14", H=300, W=400, B=1, camera=("EUCM", [190.0, 192.0, 203.0, 148.0, 0.62, 1.08]),
+                              ckpt_seed=123, img_seed=6),
+    "vits_200x560_spherical": dict(arch="vits14", H=200, W=560, B=2, camera=("Spherical", [0.0, 0.0, 0.0, 0.0, 560.0, 200.0, 1.4, 0.5]),
+                                   ckpt_seed=123, img_seed=7),
 }
 
 
 def case_inputs(case: dict):
     g = torch.Generator().manual_seed(case["img_seed"])
     rgb = torch.randint(0, 256, (case["B"], 3, case["H"], case["W"]), dtype=torch.uint8, generator=g)
-    cam = torch.tensor(DEMO_K, dtype=torch.float32) if case["camera"] else None
+    if isinstance(case["camera"], tuple):
+        cam = (case["camera"][0], torch.tensor(case["camera"][1], dtype=torch.float32))
+    else:
+        cam = torch.tensor(DEMO_K, dtype=torch.float32) if case["camera"] else None
     return rgb, cam
 
 

@@ -29,8 +29,13 @@ def main(names=None):
         sd = synth.make_synthetic_checkpoint(cfg, case["ckpt_seed"])
         ref = ref_loader.build_reference(case["arch"], sd)
         rgb, cam = cases.case_inputs(case)
+        if isinstance(cam, tuple):                       # the reference's own camera class, built from the case's parameters
+            import unidepth.utils.camera as refcam  # type: ignore
+            cam_ref = getattr(refcam, cam[0])(params=cam[1].clone())
+        else:
+            cam_ref = cam.clone() if cam is not None else None
         with torch.no_grad():
-            out = ref.infer(rgb, cam.clone() if cam is not None else None)
+            out = ref.infer(rgb, cam_ref)
         d = cases.digest({k: v.detach() for k, v in out.items()})
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
         print(name, {k: v.shape for k, v in d.items()}, "depth_mean", float(d["depth_mean"][0]))

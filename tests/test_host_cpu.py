@@ -98,3 +98,35 @@ def test_checkpoint_roundtrip(tmp_path):
     assert m2.config == cfg
     sd2 = m2.state_dict()
     assert set(sd2) == set(sd) and all(torch.equal(sd[k], sd2[k]) for k in sd)
+
+
+def test_camera_bookkeeping_matches_oracle():
+    """unidepth_amd.cameras.network_params (pad = crop by negative offsets, then resize) against the oracle's restatement of the
+    reference bookkeeping, for a padded + resized Spherical case and an EUCM case; reference-class look-alikes are accepted by name."""
+    import torch
+    from oracle import restate
+    from unidepth_amd import cameras
+    pads, rf = (0, 0, 12, 12), 1.3571428
+    sp = cameras.Spherical(torch.tensor([0.0, 0.0, 0.0, 0.0, 560.0, 200.0, 1.4, 0.5]))
+    p = sp.network_params(pads, rf)[0]
+    assert abs(p[4].item() - 560.0 * rf) < 1e-3 and abs(p[5].item() - 224.0 * rf) < 1e-3
+    assert abs(p[7].item() - 0.5 * 224.0 / 200.0) < 1e-6 and abs(p[6].item() - 1.4) < 1e-6 and abs(p[3].item() - 12 * rf) < 1e-4
+    assert sp.params[0, 5].item() == 200.0                                   # the caller's object is not modified
+    eu = cameras.EUCM(torch.tensor([190.0, 192.0, 203.0, 148.0, 0.62, 1.08]))
+    q = eu.network_params((3, 4, 0, 0), 0.5)[0]
+    assert torch.allclose(q, torch.tensor([95.0, 96.0, 103.0, 74.0, 0.62, 1.08]))
+
+    class EUCM:                                                              # stands in for unidepth.utils.camera.EUCM
+        def __init__(self, params):
+            self.params = params
+    w = cameras.as_camera(EUCM(torch.tensor([[190.0, 192.0, 203.0, 148.0, 0.62, 1.08]])))
+    assert isinstance(w, cameras.EUCM) and w.gt_mode == cameras.GT_EUCM
+
+    class MEI:
+        params = torch.zeros(1, 9)
+    import pytest
+    with pytest.raises(NotImplementedError):
+        cameras.as_camera(MEI())
+    # the oracle's rays for the padded Spherical case are unit vectors pointing forward at the image centre
+    r = restate.OracleV2._rays_from_camera_model("Spherical", torch.tensor([0.0, 0.0, 0.0, 0.0, 560.0, 200.0, 1.4, 0.5]), pads, rf, 304, 760)
+    assert torch.allclose(r.norm(dim=1), torch.ones(1, 304, 760), atol=1e-6) and r[0, 2, 152, 380] > 0.99

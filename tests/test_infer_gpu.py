@@ -21,6 +21,16 @@ def engine_cls():
     return UniDepthV2
 
 
+def _engine_camera(cam):
+    """oracle/cases.py camera spec -> what the engine's infer() takes: K tensor (on the GPU) or a unidepth_amd.cameras object."""
+    if cam is None:
+        return None
+    if isinstance(cam, tuple):
+        from unidepth_amd import cameras
+        return getattr(cameras, cam[0])(cam[1])
+    return cam.cuda()
+
+
 def _arel(a, b):
     return ((a - b).abs() / b.abs().clamp_min(1e-6)).mean().item()
 
@@ -59,7 +69,7 @@ def test_infer_matches_oracle_and_golden(engine_cls, name, golden_dir):
     rgb, cam = cases.case_inputs(case)
     ref = restate.OracleV2(cfg, sd).infer(rgb, cam)
     model = engine_cls(cfg).load_state_dict(sd).to("cuda").eval()
-    out = model.infer(rgb.cuda(), cam.cuda() if cam is not None else None)
+    out = model.infer(rgb.cuda(), _engine_camera(cam))
     torch.cuda.synchronize()
     _check(out, ref, name)
     # golden digest produced by the real reference (fixtures)
@@ -68,7 +78,7 @@ def test_infer_matches_oracle_and_golden(engine_cls, name, golden_dir):
     d = np.abs(got["depth"] - want["depth"]) / want["depth"]
     assert d.mean() <= 1e-3, (name, d.mean())
     # second call on the cached plan must reproduce the first bit-for-bit (no state leaks between calls)
-    out2 = model.infer(rgb.cuda(), cam.cuda() if cam is not None else None)
+    out2 = model.infer(rgb.cuda(), _engine_camera(cam))
     torch.cuda.synchronize()
     for k in out:
         assert torch.equal(out[k], out2[k]), k

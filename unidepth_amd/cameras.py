@@ -1,0 +1,95 @@
+"""Ground-truth camera models accepted by UniDepthV2.infer(rgb, camera=...) besides a [...,3,3] pinhole K tensor
+(SURVEY.md 8f next-3).  Parameter conventions follow the reference classes of the same names (unidepth/utils/camera.py):
+
+    Pinhole(K)                                   # utils/camera.py:229-266
+    EUCM(params=[fx, fy, cx, cy, alpha, beta])   # enhanced unified camera model, utils/camera.py:276-328
+    Spherical(params=[fx, fy, cx, cy, W, H, hfov/2, vfov/2])   # equirectangular panorama (angles in rad), :331-410
+
+Only what the infer() path needs is here: the bookkeeping that maps a camera of the ORIGINAL image to the network input
+(aspect padding = a crop by negative offsets, then the resize factor; utils/camera.py:78-81,115-120 and the Spherical overrides
+:336-357) and a tag for the ray kernel (ud_rays_from_kinv gt_mode).  The unprojection itself runs on the GPU
+(csrc/pointwise.hip rays_kernel).  Unlike the reference, infer() does not modify the camera object it is given.
+Objects of the reference's own classes are accepted as well (matched by class name and `.params`)."""
+from __future__ import annotations
+
+import torch
+
+GT_PINHOLE, GT_EUCM, GT_SPHERICAL = 1, 2, 3
+
+
+class Camera:
+    gt_mode = 0
+    n_params = 4
+
+    def __init__(self, params: torch.Tensor):
+        params = torch.as_tensor(params, dtype=torch.float32)
+        if params.ndim == 1:
+            params = params.unsqueeze(0)
+        assert params.shape[-1] == self.n_params, f"{type(self).__name__} takes {self.n_params} parameters"
+        self.params = params.clone()
+
+    @property
+    def K(self) -> torch.Tensor:
+        K = torch.eye(3).repeat(self.params.shape[0], 1, 1)
+        K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2] = self.params[:, 0], self.params[:, 1], self.params[:, 2], self.params[:, 3]
+        return K
+
+    def network_params(self, paddings, resize_factor: float) -> torch.Tensor:
+        """Parameters after `crop(-pad)` and `resize(rf)` (reference unidepthv2.py:299-303), [n, n_params] fp32."""
+        pl, pr, pt, pb = paddings
+        p = self.params.clone()
+        p[:, 2] += pl
+        p[:, 3] += pt
+        p[:, :4] *= resize_factor
+        return p
+
+
+class Pinhole(Camera):
+    gt_mode = GT_PINHOLE
+
+    def __init__(self, K: torch.Tensor = None, params: torch.Tensor = None):
+        if params is None:
+            K = torch.as_tensor(K, dtype=torch.float32).reshape(-1, 3, 3)
+            params = torch.stack([K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]], dim=1)
+        super().__init__(params)
+
+
+class EUCM(Camera):
+    gt_mode = GT_EUCM
+    n_params = 6
+
+
+class Spherical(Camera):
+    gt_mode = GT_SPHERICAL
+    n_params = 8
+
+    def network_params(self, paddings, resize_factor: float) -> torch.Tensor:
+        pl, pr, pt, pb = paddings
+        p = self.params.clone()
+        W, H = p[:, 4].clone(), p[:, 5].clone()
+        p[:, 2] += pl
+        p[:, 3] += pt
+        p[:, 4] = W + pl + pr                    # a padded panorama spans proportionally more angle
+        p[:, 5] = H + pt + pb
+        p[:, 6] *= (W + pl + pr) / W
+        p[:, 7] *= (H + pt + pb) / H
+        p[:, :6] *= resize_factor
+        return p
+
+
+_BY_NAME = {"Pinhole": Pinhole, "EUCM": EUCM, "Spherical": Spherical}
+
+
+def as_camera(obj) -> Camera:
+    """Own classes pass through; reference-class instances (or anything with a matching class name and `.params`) are wrapped."""
+    if isinstance(obj, Camera):
+        return obj
+    name = type(obj).__name__
+    if name == "BatchCamera" and getattr(obj, "cameras", None):
+        return as_camera(obj.cameras[0])
+    cls = _BY_NAME.get(name)
+    if cls is None or not hasattr(obj, "params"):
+        raise NotImplementedError(f"camera model '{name}' is not implemented (Pinhole / [...,3,3] K, EUCM, Spherical are)")
+    if cls is Pinhole:
+        return Pinhole(params=torch.as_tensor(obj.params, dtype=torch.float32)[..., :4])
+    return cls(torch.as_tensor(obj.params, dtype=torch.float32))

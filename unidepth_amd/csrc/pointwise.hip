@@ -87,9 +87,27 @@ __global__ __launch_bounds__(256) void rays_kernel(const float* Kinv33, float* r
     float y = k3 * uf + k4 * vf + k5;
     float z = k6 * uf + k7 * vf + k8;
     float nmin = 1e-5f;
-    if (gt_mode) {
+    if (gt_mode == 1) {
       const float zc = fmaxf(z, 1e-4f);
       x /= zc; y /= zc; z /= zc;
+      nmin = 1e-4f;
+    } else if (gt_mode == 2) {
+      // EUCM (utils/camera.py:307-328): k0..k5 = fx, fy, cx, cy, alpha, beta at network resolution
+      const float mx = (uf - k2) / k0, my = (vf - k3) / k1;
+      const float r2 = mx * mx + my * my;
+      const float sv = 1.0f - (2.0f * k4 - 1.0f) * k5 * r2;
+      const float mz = (1.0f - k5 * k4 * k4 * r2) / (k4 * sqrtf(fmaxf(sv, 1e-5f)) + (1.0f - k4));
+      const float cf = 1.0f / sqrtf(mx * mx + my * my + mz * mz + 1e-5f);
+      x = cf * mx; y = cf * my; z = fmaxf(cf * mz, 1e-3f);
+      nmin = 1e-4f;
+    } else if (gt_mode == 3) {
+      // Spherical / equirectangular (utils/camera.py:371-386): k4, k5 = image width, height; k6, k7 = half fields of view (rad)
+      const float lon = (uf - 0.5f * (k4 - 1.0f)) / (k4 - 1.0f) * (2.0f * k6);
+      const float lat = (vf - 0.5f * (k5 - 1.0f)) / (k5 - 1.0f) * (2.0f * k7);
+      const float cl = cosf(lat);
+      x = cl * sinf(lon); y = sinf(lat); z = cl * cosf(lon);
+      const float n1 = 1.0f / fmaxf(sqrtf(x * x + y * y + z * z), 1e-5f);
+      x *= n1; y *= n1; z *= n1;
       nmin = 1e-4f;
     }
     const float inv = 1.0f / fmaxf(sqrtf(x * x + y * y + z * z), nmin);

@@ -24,6 +24,7 @@ import torch
 from . import ops
 from .ops import (UD_A_CONV3_REFLECT, UD_A_CONV3_ZERO, UD_ACT_GELU, UD_ACT_LRELU, UD_ACT_NONE, UD_EPI_D2S, UD_EPI_F16,
                   UD_EPI_F32, UD_EPI_HEAD, UD_EPI_QKV)
+from .cameras import GT_PINHOLE, as_camera
 from .weights import arch_of, pack
 
 IMAGENET_DATASET_MEAN = (0.485, 0.456, 0.406)      # unidepth/utils/constants.py:12
@@ -63,7 +64,7 @@ def _rup(x, m):
 class _Plan:
     """Device buffers + recorded launch program for one (batch, image shape, camera batch, dtype) signature."""
 
-    def __init__(self, model: "UniDepthV2", B, H, W, cam_nb, is_u8, normalize, pixels_bounds):
+    def __init__(self, model: "UniDepthV2", B, H, W, cam_nb, is_u8, normalize, pixels_bounds, gt_mode=1):
         w, a, dev = model._w, model._arch, model.device
         meta = w["meta"]
         D, C, heads, Hd = a["D"], a["C"], a["heads"], a["dec_heads"]
@@ -205,7 +206,7 @@ class _Plan:
         self.rays = z(nb, 3, Hn, Wn, dtype=f32)
         if cam_nb:
             self.kinv_gt = z(nb, 9, dtype=f32)
-            P.rays(self.kinv_gt, self.rays, nb, Hn, Wn, 1)
+            P.rays(self.kinv_gt, self.rays, nb, Hn, Wn, gt_mode or 1)      # 1 pinhole K^-1, 2 EUCM / 3 Spherical parameters
         else:
             P.rays(kinv, self.rays, nb, Hn, Wn, 0)
         # ---------------- ray embedding + 4 camera-prompt cross-attention blocks (decoder.py:234-260)
@@ -419,13 +420,13 @@ class UniDepthV2:
         warnings.warn("!! self.resolution_level not set, using default bounds !!")
         return (lo, hi)
 
-    def _plan(self, B, H, W, cam_nb, is_u8, normalize, slot=0) -> _Plan:
+    def _plan(self, B, H, W, cam_nb, is_u8, normalize, slot=0, gt_mode=0) -> _Plan:
         bounds = self._pixels_bounds()
-        key = (B, H, W, cam_nb, is_u8, normalize, bounds, slot)
+        key = (B, H, W, cam_nb, is_u8, normalize, bounds, slot, gt_mode)
         plan = self._plans.get(key)
         if plan is None:
             with torch.cuda.device(self._device):
-                plan = _Plan(self, B, H, W, cam_nb, is_u8, normalize, bounds)
+                plan = _Plan(self, B, H, W, cam_nb, is_u8, normalize, bounds, gt_mode)
             self._plans[key] = plan
         return plan
 
@@ -442,16 +443,28 @@ class UniDepthV2:
             rgb = rgb.unsqueeze(0)
         B, _, H, W = rgb.shape
         Kc = None
+        cam_obj = None                                             # EUCM / Spherical: parameters go to the ray kernel as they are
         if camera is not None:
-            Kc = camera if isinstance(camera, torch.Tensor) else getattr(camera, "K", None)
-            if Kc is None:
-                raise NotImplementedError("only pinhole cameras given as [...,3,3] K tensors (or objects with .K) are implemented")
-            assert Kc.shape[-1] == 3 and Kc.shape[-2] == 3, "camera tensor should be of shape (..., 3, 3): assume pinhole"
-            Kc = Kc.detach().reshape(-1, 3, 3).float().cpu()
+            if isinstance(camera, torch.Tensor):
+                Kc = camera
+            else:
+                cam_obj = as_camera(camera)                        # reference-class objects are matched by class name
+                if cam_obj.gt_mode == GT_PINHOLE:
+                    Kc, cam_obj = cam_obj.K, None
+            if Kc is not None:
+                assert Kc.shape[-1] == 3 and Kc.shape[-2] == 3, "camera tensor should be of shape (..., 3, 3): assume pinhole"
+                Kc = Kc.detach().reshape(-1, 3, 3).float().cpu()
         is_u8 = rgb.dtype == torch.uint8
         with torch.cuda.device(self._device):
-            plan = self._plan(B, H, W, 0 if Kc is None else Kc.shape[0], is_u8, bool(normalize), int(slot))
+            cam_nb = 0 if camera is None else (Kc.shape[0] if Kc is not None else cam_obj.params.shape[0])
+            gt_mode = 0 if camera is None else (GT_PINHOLE if Kc is not None else cam_obj.gt_mode)
+            plan = self._plan(B, H, W, cam_nb, is_u8, bool(normalize), int(slot), gt_mode)
             plan.rgb.copy_(rgb if is_u8 else rgb.float(), non_blocking=True)
+            if cam_obj is not None:
+                pn = cam_obj.network_params(plan.paddings, plan.rf)               # [n, <= 8] -> the 9-float slots of the ray kernel
+                buf = torch.zeros(pn.shape[0], 9)
+                buf[:, :pn.shape[1]] = pn
+                plan.kinv_gt.copy_(buf)
             if Kc is not None:
                 pl, _, pt, _ = plan.paddings
                 Kn = Kc.clone()                                    # camera.crop(-pad) then .resize(rf): utils/camera.py:78-81,115-120
