@@ -130,3 +130,17 @@ def test_camera_bookkeeping_matches_oracle():
     # the oracle's rays for the padded Spherical case are unit vectors pointing forward at the image centre
     r = restate.OracleV2._rays_from_camera_model("Spherical", torch.tensor([0.0, 0.0, 0.0, 0.0, 560.0, 200.0, 1.4, 0.5]), pads, rf, 304, 760)
     assert torch.allclose(r.norm(dim=1), torch.ones(1, 304, 760), atol=1e-6) and r[0, 2, 152, 380] > 0.99
+
+
+def test_hub_entry_point_surface():
+    """hubconf.UniDepth(version, backbone, pretrained) signature (reference hubconf.py:25-41): V2 configs resolve, V1 fails loudly."""
+    import pytest
+    import unidepth_amd
+    m = unidepth_amd.UniDepth(version="v2", backbone="vits14", pretrained=False)
+    assert type(m).__name__ == "UniDepthV2" and m.shape_constraints["pixels_max"] > m.shape_constraints["pixels_min"]
+    with pytest.raises(AssertionError):
+        unidepth_amd.UniDepth(version="v2", backbone="cnvnxtl", pretrained=False)
+    with pytest.raises(NotImplementedError):
+        unidepth_amd.UniDepth(version="v1", backbone="cnvnxtl", pretrained=False)
+    with pytest.raises(NotImplementedError):
+        unidepth_amd.UniDepthV1({})

@@ -7,11 +7,14 @@ All device arithmetic runs in libunidepth_hip.so (hand-written HIP); importing t
 built library raises ImportError -- there is no CPU / eager-PyTorch fallback."""
 from . import _lib  # noqa: F401  (fails loudly when the HIP library is missing)
 
-__all__ = ["UniDepthV2"]
+__all__ = ["UniDepthV2", "UniDepthV1", "UniDepth"]
 
 
 def __getattr__(name):
     if name == "UniDepthV2":
         from .unidepthv2 import UniDepthV2
         return UniDepthV2
+    if name in ("UniDepthV1", "UniDepth"):            # hubconf-style entry point / the V1 family (not built: fails loudly)
+        from . import hub
+        return getattr(hub, name)
     raise AttributeError(name)
