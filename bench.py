@@ -57,11 +57,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("UD_BENCH_BACKEND", "nccl")      # "gloo": functional check of the N > 1 path on a box with one GPU
+    if os.environ.get("UD_BENCH_SHARE_GPU"):                 # (all ranks on cuda:0; never a measurement)
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))      # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))      # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
@@ -85,7 +91,10 @@ def main():
         # one exchange step: requested outputs packed per image, ONE RCCL all-gather (xGMI is point-to-point: few, larger messages)
         packed = torch.cat([out[k].reshape(B, -1) for k in gather_keys], dim=1)
         gathered = torch.empty((world * B, packed.shape[1]), dtype=packed.dtype, device=dev)
-        dist.all_gather_into_tensor(gathered, packed)
+        if backend == "nccl":
+            dist.all_gather_into_tensor(gathered, packed)
+        else:
+            dist.all_gather(list(gathered.chunk(world)), packed)
         return gathered
 
     def step():
