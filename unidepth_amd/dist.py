@@ -120,7 +120,8 @@ def plan_mixed(shapes: List[Tuple[int, int]], costs: List[float], world: int, ma
 
 
 def infer_mixed(model, images: List[torch.Tensor], cameras: Optional[List[Optional[torch.Tensor]]] = None,
-                keys: Iterable[str] = ("depth", "confidence", "intrinsics"), max_batch: int = 8, group=None, **kw) -> List[Dict[str, torch.Tensor]]:
+                keys: Iterable[str] = ("depth", "confidence", "intrinsics"), max_batch: int = 8, group=None, inflight: int = 2,
+                **kw) -> List[Dict[str, torch.Tensor]]:
     """infer() over a list of [3,H,W] images of arbitrary, mixed shapes.  Single process (no initialised process group): the
     micro-batches run back to back on this GPU.  Under torch.distributed every rank passes the SAME list, runs the micro-batches
     the plan gives it and all ranks return the complete, ordered result list; one all-gather per shape bucket (the outputs of a
@@ -133,6 +134,12 @@ def infer_mixed(model, images: List[torch.Tensor], cameras: Optional[List[Option
     micro, owner = plan_mixed(shapes, costs, world, max_batch)
     results: List[Optional[Dict[str, torch.Tensor]]] = [None] * len(images)
     mine: Dict[Tuple[int, int], List[Tuple[List[int], Dict[str, torch.Tensor]]]] = {}
+    # consecutive micro-batches of a rank overlap on separate HIP streams (pipeline.py) when the engine supports buffer slots
+    pipe = None
+    if inflight > 1 and hasattr(model, "_plans") and images and images[0].is_cuda:
+        from .pipeline import InferPipeline
+        pipe = InferPipeline(model, depth=inflight)
+    submitted = []
     for (s, idx), r in zip(micro, owner):
         if r != rank:
             continue
@@ -140,11 +147,17 @@ def infer_mixed(model, images: List[torch.Tensor], cameras: Optional[List[Option
         cam = None
         if cameras is not None and all(cameras[i] is not None for i in idx):
             cam = torch.stack([cameras[i] for i in idx])
-        out = model.infer(rgb, cam, **kw)
+        if pipe is not None:
+            out = pipe.submit(rgb, cam, **kw)
+            submitted.append(out)
+        else:
+            out = model.infer(rgb, cam, **kw)
         mine.setdefault(s, []).append((idx, {k: out[k] for k in keys}))
         if not distributed:
             for b, i in enumerate(idx):
                 results[i] = {k: out[k][b] for k in keys}
+    for out in submitted:                              # only now: a wait on the caller's stream would order later submissions behind it
+        pipe.wait(out)
     if not distributed:
         return results  # type: ignore[return-value]
     for s in sorted({m[0] for m in micro}):

@@ -488,6 +488,13 @@ class UniDepthV2:
 
     __call__ = infer
 
+    @torch.no_grad()
+    def forward_export(self, rgbs: torch.Tensor):
+        """Pure-tensor entry with the signature of the reference's ONNX wrapper (unidepthv2/export.py:27-45):
+        rgbs [B,3,H,W] -> (points [B,3,H,W], confidence [B,1,H,W], intrinsics [B,3,3])."""
+        out = self.infer(rgbs)
+        return out["points"], out["confidence"], out["intrinsics"]
+
     # ---- module seams for A/B bisection against the oracle (SURVEY.md 8b/B2) ----
     @torch.no_grad()
     def debug_taps(self, plan: Optional[_Plan] = None):
