@@ -482,6 +482,22 @@ __device__ __forceinline__ unsigned ud_pack2(float x, float y) {
 }
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
+// scheduling-region pattern: R ds_reads spread between M MFMAs (q MFMAs, 1 read, q MFMAs, 1 read, ..., rest), so the matrix pipe is
+// not left idle while a cluster of fragment reads issues (reads of a phase target registers that phase's MFMAs do not use)
+template <int R, int M>
+__device__ __forceinline__ void ud_interleave_reads() {
+  constexpr int q = M / (R + 1);
+  if constexpr (R >= 1) { __builtin_amdgcn_sched_group_barrier(0x8, q, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+  if constexpr (R >= 2) { __builtin_amdgcn_sched_group_barrier(0x8, q, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+  if constexpr (R >= 3) { __builtin_amdgcn_sched_group_barrier(0x8, q, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+  if constexpr (R >= 4) { __builtin_amdgcn_sched_group_barrier(0x8, q, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+  if constexpr (R >= 5) { __builtin_amdgcn_sched_group_barrier(0x8, q, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+  if constexpr (R >= 6) { __builtin_amdgcn_sched_group_barrier(0x8, q, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+  if constexpr (R >= 7) { __builtin_amdgcn_sched_group_barrier(0x8, q, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+  if constexpr (R >= 8) { __builtin_amdgcn_sched_group_barrier(0x8, q, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+  __builtin_amdgcn_sched_group_barrier(0x8, M - q * R, 0);
+}
+
 template <int MH, int EPI, int AMODE>
 __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -657,20 +673,23 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
       }
 #pragma unroll
       for (int i = 0; i < MH; ++i) a1[i] = *(const half8*)(sb + a_off + (MH + i) * 2048 + c0);
-      __builtin_amdgcn_sched_barrier(0);     // keep the fragment prefetch ahead of the MFMAs (hipcc would sink it to first use)
       UD_MFMA_HALF(0, a0, b0)
+      ud_interleave_reads<MH, 4 * MH>();
+      __builtin_amdgcn_sched_barrier(0);
       // ---- phase (k0, m-half 1)
 #pragma unroll
       for (int i = 0; i < MH; ++i) a0[i] = *(const half8*)(sb + a_off + i * 2048 + c1);
 #pragma unroll
       for (int j = 0; j < 4; ++j) b1[j] = *(const half8*)(sb + b_off + j * 2048 + c1);
-      __builtin_amdgcn_sched_barrier(0);
       UD_MFMA_HALF(MH, a1, b0)
+      ud_interleave_reads<MH + 4, 4 * MH>();
+      __builtin_amdgcn_sched_barrier(0);
       // ---- phase (k1, m-half 0)
 #pragma unroll
       for (int i = 0; i < MH; ++i) a1[i] = *(const half8*)(sb + a_off + (MH + i) * 2048 + c1);
-      __builtin_amdgcn_sched_barrier(0);
       UD_MFMA_HALF(0, a0, b1)
+      ud_interleave_reads<MH, 4 * MH>();
+      __builtin_amdgcn_sched_barrier(0);
       // ---- phase (k1, m-half 1): next K-tile must have landed for every wave before anyone reads it
       asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -681,8 +700,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) b0[j] = *(const half8*)(sbn + b_off + j * 2048 + c0);
       }
-      __builtin_amdgcn_sched_barrier(0);
       UD_MFMA_HALF(MH, a1, b1)
+      if constexpr (!LAST) ud_interleave_reads<MH + 4, 4 * MH>();
+      __builtin_amdgcn_sched_barrier(0);
 #undef UD_MFMA_HALF
       stg ^= 1;
     };
