@@ -838,6 +838,61 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
         }
       }
     }
+    if constexpr (EPI == UD_EPI_D2S) {
+      // ConvTranspose(k = s) depth-to-space accumulate, straight-line: the wave's 64 columns lie inside ONE (a, c) sub-pixel block
+      // when Co % 64 == 0, so the destination pixel depends on the row only (one (img, y, x) decode per row tile, not per element);
+      // fp32 read-modify-write in 16-byte pieces, fp16 copy paired to 16-byte stores.
+      fast = (m0 + BM <= p.M) && (n0 + 256 <= p.N) && (p.d2s_Co & 63) == 0 && (p.ldc & 3) == 0 && (p.out2 == nullptr || (p.ldc2 & 7) == 0);
+      if (fast) {
+        const int k = p.d2s_k;
+        const int ac = nbase / p.d2s_Co;
+        const int o0 = nbase - ac * p.d2s_Co;
+        const int sa = ac / k, sc = ac - sa * k;
+        const int Wout = p.d2s_Win * k;
+        f32x4 bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(p.bias + o0 + j * 16 + 4 * fq);
+        const bool lre = p.act2 == UD_ACT_LRELU;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int m = mbase + i * 16 + frow;
+          const int img = m / p.d2s_rows_in_img;
+          const int pp = m - img * p.d2s_rows_in_img;
+          const int y = pp / p.d2s_Win, x = pp - y * p.d2s_Win;
+          const bool ok = pp < p.d2s_Hin * p.d2s_Win;                       // rows past the image are padding tokens
+          const long long pix = (long long)img * p.d2s_out_img_pix + (long long)(y * k + sa) * Wout + (x * k + sc);
+          float* dst = (float*)p.out + pix * p.ldc + o0 + 4 * fq;
+          f32x4 v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = ok ? *(const f32x4*)(dst + j * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          unsigned w[4][2];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[j] += acc[i][j] + bv[j];
+            if (ok) *(f32x4*)(dst + j * 16) = v[j];
+            f32x4 a = v[j];
+            if (lre) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) a[r] = ud_lrelu(v[j][r]);
+            }
+            w[j][0] = ud_pack2(a[0], a[1]);
+            w[j][1] = ud_pack2(a[2], a[3]);
+          }
+          if (p.out2) {
+            // after the exchange lane q holds columns 16 (jp*2 + (q & 1)) + 8 (q >> 1) .. + 7 of ITS OWN row (same row, same pixel)
+            half_t* d2 = (half_t*)p.out2 + pix * p.ldc2 + o0 + 16 * (fq & 1) + 8 * (fq >> 1);
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+              ud_pair16(w[2 * jp][0], w[2 * jp + 1][0]);
+              ud_pair16(w[2 * jp][1], w[2 * jp + 1][1]);
+              u32x4 sv;
+              sv[0] = w[2 * jp][0]; sv[1] = w[2 * jp][1]; sv[2] = w[2 * jp + 1][0]; sv[3] = w[2 * jp + 1][1];
+              if (ok) *(u32x4*)(d2 + jp * 32) = sv;
+            }
+          }
+        }
+      }
+    }
     if (!fast) {
       // generic path: edge tiles, row remaps, `add` operands, depth-to-space (8-byte fp16 stores, per-element bounds checks)
       constexpr bool PRE = ACC_EPI;            // the residual is already inside the accumulators (in-loop or preloaded)
