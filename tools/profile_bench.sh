@@ -4,7 +4,7 @@
 TAG=${1:-r01}
 R=/root/repo
 cd /tmp && export TMPDIR=/tmp
-ARGS="$R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing"
+ARGS="$R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --inflight 1"      # one call at a time: clean per-kernel durations
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG/trace -o t -- python $ARGS > $R/gpurun_out/prof_$TAG.trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_$TAG/fetch -o f -- python $ARGS > $R/gpurun_out/prof_$TAG.fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_$TAG/write -o w -- python $ARGS > $R/gpurun_out/prof_$TAG.write.log 2>&1
