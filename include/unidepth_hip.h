@@ -165,6 +165,15 @@ int ud_camera_intrinsics(const float* raw, int raw_stride, float* intr4, float* 
  *   (fx, fy, cx, cy, width, height, hfov/2, vfov/2, -) instead of an inverse intrinsic matrix. */
 int ud_rays_from_kinv(const float* Kinv33, float* rays, int nb, int Hn, int Wn, int gt_mode, void* stream);
 
+/* rays [1,3,Hn,Wn] fp32 of ONE user camera whose unprojection is iterative (utils/camera.py get_rays :88-92 over
+ * OPENCV.unproject :496-694 (model 4), Fisheye624.unproject :778-974 (model 5), MEI.unproject :985-1082 (model 6)).
+ * params: device pointer, 16 floats [fx, fy, cx, cy, k1..k6, p1, p2, s1..s4] (models 4, 5; OPENCV: k4..k6 = 0) or 9 floats
+ * [fx, fy, cx, cy, k1, k2, p1, p2, xi] (model 6), at network resolution.  Which distortion groups are active is decided on
+ * the device from the parameters, like the reference's use_radial / use_tangential / use_thin_prism.
+ * scratch: 4*Hn*Wn + 16 floats (models 4, 5; may be NULL for MEI) -- per-pixel solver state plus the per-iteration maximum
+ * residual that reproduces the reference's image-wide early exit of the radial trust-region loop (:629-631). */
+int ud_rays_from_camera(const float* params, float* rays, float* scratch, int Hn, int Wn, int model, void* stream);
+
 /* ray embedding (decoder.py:234-253): antialiased bilinear down-sample of rays [nb,3,Hn,Wn] to (h,w)
  * (utils/geometric.py:227-252), renormalise (clip 1e-4), polar/azimuth, C/2 log-spaced sine bands each
  * (utils/positional_embedding.py:218-256; `scales` = the C/2 band frequencies, fp32), then LayerNorm statistics
@@ -224,6 +233,7 @@ int ud_program_add_fill_rows(UdProgram*, float* dst, const float* src, int n_img
 int ud_program_add_camera_intrinsics(UdProgram*, const float* raw, int raw_stride, float* intr4, float* K33, float* Kinv33, float* Kpost33,
                                      int B, int Hn, int Wn, float resize_factor, int pad_l, int pad_t);
 int ud_program_add_rays(UdProgram*, const float* Kinv33, float* rays, int nb, int Hn, int Wn, int gt_mode);
+int ud_program_add_rays_camera(UdProgram*, const float* params, float* rays, float* scratch, int Hn, int Wn, int model);
 int ud_program_add_ray_embed(UdProgram*, const UdRayEmbed*);
 int ud_program_add_upsample2x(UdProgram*, const UdUpsample2x*);
 int ud_program_add_resize_ac(UdProgram*, const UdResizeAC*);

@@ -23,6 +23,14 @@ CASES = {
                               ckpt_seed=123, img_seed=6),
     "vits_200x560_spherical": dict(arch="vits14", H=200, W=560, B=2, camera=("Spherical", [0.0, 0.0, 0.0, 0.0, 560.0, 200.0, 1.4, 0.5]),
                                    ckpt_seed=123, img_seed=7),
+    # GT cameras with iterative unprojection (utils/camera.py OPENCV / Fisheye624 / MEI): radial + tangential + thin-prism terms all
+    # active; the MEI strip is wide enough to be aspect-padded (pads 28/28) and resized
+    "vits_300x400_opencv": dict(arch="vits14", H=300, W=400, B=1, ckpt_seed=123, img_seed=8,
+                                camera=("OPENCV", [300.0, 302.0, 203.0, 148.0, -0.25, 0.08, -0.01, 0.0, 0.0, 0.0, 1e-3, -2e-3, 1e-3, 5e-4, -1e-3, 2e-4])),
+    "vits_300x400_fisheye624": dict(arch="vits14", H=300, W=400, B=1, ckpt_seed=123, img_seed=9,
+                                    camera=("Fisheye624", [190.0, 192.0, 203.0, 148.0, 0.05, -0.01, 0.002, -5e-4, 1e-4, -1e-5, 1e-3, -1e-3, 5e-4, 1e-4, -5e-4, 1e-4])),
+    "vits_200x640_mei": dict(arch="vits14", H=200, W=640, B=2, ckpt_seed=123, img_seed=10,
+                             camera=("MEI", [250.0, 252.0, 318.0, 101.0, -0.1, 0.02, 1e-3, -1e-3, 0.9])),
 }
 
 

@@ -122,11 +122,20 @@ def test_camera_bookkeeping_matches_oracle():
     w = cameras.as_camera(EUCM(torch.tensor([[190.0, 192.0, 203.0, 148.0, 0.62, 1.08]])))
     assert isinstance(w, cameras.EUCM) and w.gt_mode == cameras.GT_EUCM
 
-    class MEI:
-        params = torch.zeros(1, 9)
+    class MEI:                                                               # iterative models are matched by name as well
+        params = torch.tensor([[150.0, 151.0, 98.0, 70.0, -0.1, 0.02, 1e-3, -1e-3, 0.9]])
+    m = cameras.as_camera(MEI())
+    assert m.gt_mode == cameras.GT_MEI and torch.allclose(m.network_params((2, 2, 0, 0), 2.0)[0, :4], torch.tensor([300.0, 302.0, 200.0, 140.0]))
+
+    class Kannala:
+        params = torch.zeros(1, 8)
     import pytest
     with pytest.raises(NotImplementedError):
-        cameras.as_camera(MEI())
+        cameras.as_camera(Kannala())
+    with pytest.raises(AssertionError):                                      # OPENCV's rational (poly-division) terms are rejected, as in the reference
+        cameras.OPENCV(torch.tensor([180.0, 180, 98, 70, -0.2, 0.05, 0, 0.01, 0, 0, 0, 0, 0, 0, 0, 0]))
+    with pytest.raises(AssertionError):                                      # one camera per call for the iterative models
+        cameras.Fisheye624(torch.zeros(2, 16))
     # the oracle's rays for the padded Spherical case are unit vectors pointing forward at the image centre
     r = restate.OracleV2._rays_from_camera_model("Spherical", torch.tensor([0.0, 0.0, 0.0, 0.0, 560.0, 200.0, 1.4, 0.5]), pads, rf, 304, 760)
     assert torch.allclose(r.norm(dim=1), torch.ones(1, 304, 760), atol=1e-6) and r[0, 2, 152, 380] > 0.99

@@ -71,12 +71,16 @@ def test_infer_matches_oracle_and_golden(engine_cls, name, golden_dir):
     model = engine_cls(cfg).load_state_dict(sd).to("cuda").eval()
     out = model.infer(rgb.cuda(), _engine_camera(cam))
     torch.cuda.synchronize()
-    _check(out, ref, name)
+    stats = _check(out, ref, name)
+    if cam is not None:                                             # GT-camera rays are plain fp32 geometry, not network output
+        assert stats["rays_maxabs"] <= 2e-5, (name, stats)
     # golden digest produced by the real reference (fixtures)
     got = cases.digest({k: v.float().cpu() for k, v in out.items()})
     want = np.load(os.path.join(golden_dir, name + ".npz"))
     d = np.abs(got["depth"] - want["depth"]) / want["depth"]
     assert d.mean() <= 1e-3, (name, d.mean())
+    if cam is not None:
+        assert np.abs(got["rays"] - want["rays"]).max() <= 2e-5, name
     # second call on the cached plan must reproduce the first bit-for-bit (no state leaks between calls)
     out2 = model.infer(rgb.cuda(), _engine_camera(cam))
     torch.cuda.synchronize()

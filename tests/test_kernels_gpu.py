@@ -405,6 +405,47 @@ def test_preprocess_patches(ops, H, W, pads, Hn, Wn, u8):
     assert patches[:, 588:].abs().max() == 0
 
 
+_ITER_CAMERAS = [
+    ("OPENCV", 4, [180., 182., 98., 70., -0.25, 0.08, -0.01, 0, 0, 0, 1e-3, -2e-3, 0, 0, 0, 0]),
+    ("OPENCV", 4, [180., 182., 98., 70., -0.25, 0.08, -0.01, 0, 0, 0, 1e-3, -2e-3, 1e-3, 5e-4, -1e-3, 2e-4]),
+    ("OPENCV", 4, [180., 182., 98., 70., -0.3, 0.1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]),
+    ("OPENCV", 4, [180., 182., 98., 70., 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]),
+    ("Fisheye624", 5, [120., 121., 98., 70., -0.02, 0.01, -0.003, 0.001, 0, 0, 1e-3, -1e-3, 5e-4, 1e-4, -5e-4, 1e-4]),
+    ("Fisheye624", 5, [90., 90., 98., 70., 0.05, -0.01, 0.002, -0.0005, 1e-4, -1e-5, 0, 0, 0, 0, 0, 0]),
+    ("MEI", 6, [150., 151., 98., 70., -0.1, 0.02, 1e-3, -1e-3, 0.9]),
+    ("MEI", 6, [150., 151., 98., 70., -0.1, 0.02, 0, 0, 1.0]),
+    ("MEI", 6, [150., 151., 98., 70., 0, 0, 0, 0, 0.5]),
+]
+
+
+@pytest.mark.parametrize("name,model,params", _ITER_CAMERAS)
+def test_rays_from_iterative_camera(ops, name, model, params):
+    """ud_rays_from_camera against the oracle's restatement of OPENCV / Fisheye624 / MEI get_rays (utils/camera.py), fp32 both
+    sides; tolerance 5e-6 absolute on unit vectors (the device build fuses multiply-adds, the solvers stop on a 1e-3 residual
+    image-wide, so the same iteration count is what this checks).  Scratch is dirtied first: per-call state must be re-initialised."""
+    from oracle.restate import OracleV2
+    Hn, Wn = 140, 196
+    p = torch.zeros(16)
+    p[: len(params)] = torch.tensor(params)
+    pd = p.cuda()
+    rays = torch.zeros(1, 3, Hn, Wn, device="cuda")
+    scratch = torch.full((4 * Hn * Wn + 16,), 1.0e9, device="cuda")
+    for _ in range(2):
+        ops.check(ops.lib.ud_rays_from_camera(pd.data_ptr(), rays.data_ptr(), scratch.data_ptr(), Hn, Wn, model, ops.cur_stream()))
+    torch.cuda.synchronize()
+    ref = OracleV2._rays_from_camera_model(name, torch.tensor(params), (0, 0, 0, 0), 1.0, Hn, Wn)
+    assert torch.isfinite(rays).all()
+    assert (rays.cpu() - ref).abs().max() < 5e-6, (rays.cpu() - ref).abs().max()
+
+
+def test_rays_from_camera_rejects_bad_arguments(ops):
+    rays = torch.zeros(1, 3, 8, 8, device="cuda")
+    p = torch.zeros(16, device="cuda")
+    assert ops.lib.ud_rays_from_camera(p.data_ptr(), rays.data_ptr(), None, 8, 8, 4, ops.cur_stream()) != 0      # OPENCV needs scratch
+    assert ops.lib.ud_rays_from_camera(p.data_ptr(), rays.data_ptr(), None, 8, 8, 3, ops.cur_stream()) != 0      # not an iterative model
+    assert ops.lib.ud_rays_from_camera(None, rays.data_ptr(), None, 8, 8, 6, ops.cur_stream()) != 0
+
+
 def test_camera_rays_embed(ops):
     import ctypes as C
     from oracle.restate import OracleV2

@@ -98,6 +98,7 @@ def _load():
         "ud_fill_rows_f32": [vp, vp, i32, i32, i32, i32, i32, vp],
         "ud_camera_intrinsics": [vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32, vp],
         "ud_rays_from_kinv": [vp, vp, i32, i32, i32, i32, vp],
+        "ud_rays_from_camera": [vp, vp, vp, i32, i32, i32, vp],
         "ud_ray_embed": [P(UdRayEmbed), vp],
         "ud_upsample2x_nhwc": [P(UdUpsample2x), vp],
         "ud_resize_ac_nhwc_f16": [P(UdResizeAC), vp],
@@ -112,6 +113,7 @@ def _load():
         "ud_program_add_fill_rows": [vp, vp, vp, i32, i32, i32, i32, i32],
         "ud_program_add_camera_intrinsics": [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, i32, i32],
         "ud_program_add_rays": [vp, vp, vp, i32, i32, i32, i32],
+        "ud_program_add_rays_camera": [vp, vp, vp, vp, i32, i32, i32],
         "ud_program_add_ray_embed": [vp, P(UdRayEmbed)],
         "ud_program_add_upsample2x": [vp, P(UdUpsample2x)],
         "ud_program_add_resize_ac": [vp, P(UdResizeAC)],

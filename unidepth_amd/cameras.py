@@ -4,17 +4,21 @@
     Pinhole(K)                                   # utils/camera.py:229-266
     EUCM(params=[fx, fy, cx, cy, alpha, beta])   # enhanced unified camera model, utils/camera.py:276-328
     Spherical(params=[fx, fy, cx, cy, W, H, hfov/2, vfov/2])   # equirectangular panorama (angles in rad), :331-410
+    OPENCV(params=[fx, fy, cx, cy, k1..k6, p1, p2, s1..s4])    # radial (k1..k3; k4..k6 must be 0) + tangential + thin prism, :412-694
+    Fisheye624(params=[fx, fy, cx, cy, k1..k6, p1, p2, s1..s4])  # 6-coefficient fisheye + tangential + thin prism, :697-974
+    MEI(params=[fx, fy, cx, cy, k1, k2, p1, p2, xi])           # unified omnidirectional model, :977-1082
 
 Only what the infer() path needs is here: the bookkeeping that maps a camera of the ORIGINAL image to the network input
 (aspect padding = a crop by negative offsets, then the resize factor; utils/camera.py:78-81,115-120 and the Spherical overrides
 :336-357) and a tag for the ray kernel (ud_rays_from_kinv gt_mode).  The unprojection itself runs on the GPU
-(csrc/pointwise.hip rays_kernel).  Unlike the reference, infer() does not modify the camera object it is given.
+(csrc/pointwise.hip rays_kernel; the iterative models -- OPENCV, Fisheye624, MEI -- through ud_rays_from_camera, which
+reproduces the reference's Newton / trust-region solvers including the image-wide early exit of the radial loop).  Unlike the reference, infer() does not modify the camera object it is given.
 Objects of the reference's own classes are accepted as well (matched by class name and `.params`)."""
 from __future__ import annotations
 
 import torch
 
-GT_PINHOLE, GT_EUCM, GT_SPHERICAL = 1, 2, 3
+GT_PINHOLE, GT_EUCM, GT_SPHERICAL, GT_OPENCV, GT_FISHEYE624, GT_MEI = 1, 2, 3, 4, 5, 6
 
 
 class Camera:
@@ -77,7 +81,35 @@ class Spherical(Camera):
         return p
 
 
-_BY_NAME = {"Pinhole": Pinhole, "EUCM": EUCM, "Spherical": Spherical}
+class _SingleCamera(Camera):
+    """The iterative models unproject one camera at a time in the reference (`B` is taken from the pixel grid, which has batch
+    1: utils/camera.py:498-509), so one parameter row is what infer() can be given."""
+
+    def __init__(self, params: torch.Tensor):
+        super().__init__(params)
+        assert self.params.shape[0] == 1, f"{type(self).__name__}: one camera per infer() call (as in the reference)"
+
+
+class OPENCV(_SingleCamera):
+    gt_mode = GT_OPENCV
+    n_params = 16
+
+    def __init__(self, params: torch.Tensor):
+        super().__init__(params)
+        assert float(self.params[..., 7:10].abs().sum()) == 0.0, "Do not support poly division model"   # utils/camera.py:416-418
+
+
+class Fisheye624(_SingleCamera):
+    gt_mode = GT_FISHEYE624
+    n_params = 16
+
+
+class MEI(_SingleCamera):
+    gt_mode = GT_MEI
+    n_params = 9
+
+
+_BY_NAME = {"Pinhole": Pinhole, "EUCM": EUCM, "Spherical": Spherical, "OPENCV": OPENCV, "Fisheye624": Fisheye624, "MEI": MEI}
 
 
 def as_camera(obj) -> Camera:
@@ -89,7 +121,7 @@ def as_camera(obj) -> Camera:
         return as_camera(obj.cameras[0])
     cls = _BY_NAME.get(name)
     if cls is None or not hasattr(obj, "params"):
-        raise NotImplementedError(f"camera model '{name}' is not implemented (Pinhole / [...,3,3] K, EUCM, Spherical are)")
+        raise NotImplementedError(f"camera model '{name}' is not implemented ({', '.join(_BY_NAME)} are)")
     if cls is Pinhole:
         return Pinhole(params=torch.as_tensor(obj.params, dtype=torch.float32)[..., :4])
     return cls(torch.as_tensor(obj.params, dtype=torch.float32))

@@ -2,6 +2,7 @@
 // ray angle embedding (+LayerNorm statistics), bilinear resamplers, output assembly, layout change.
 // All are coalesced along the fastest-varying dimension, 8/16-byte accesses where layout allows, wave64 reductions.
 #include "ud_common.h"
+#include "camera_models.h"
 
 namespace {
 
@@ -114,6 +115,81 @@ __global__ __launch_bounds__(256) void rays_kernel(const float* Kinv33, float* r
     float* r = rays + (size_t)b * 3 * HW + pix;
     r[0] = x * inv; r[HW] = y * inv; r[2 * (size_t)HW] = z * inv;
   }
+}
+
+// ------------------------------------------------------------------------------------------------ iterative GT cameras
+// OPENCV / Fisheye624 (utils/camera.py:496-694 / :778-974): the radial solver is a trust-region Newton loop that the reference
+// leaves for ALL pixels at once, as soon as the largest |residual| of the image drops below 1e-3.  To reproduce that the loop
+// is unrolled over launches: init (tangential / thin-prism Newton, theta_0, trust radius) -> up to 10 step kernels -> final.
+// Step kernel `it` first looks at maxres[it], the largest residual at theta_it written by its predecessor with one atomicMax per
+// wave (non-negative floats order like their bit patterns), and returns at once when the reference would have left the loop;
+// maxres[] is cleared per call, so every later step kernel returns too.  Per-pixel state: float4 {xr, yr, theta, trust radius}.
+__device__ __forceinline__ bool cam_use_radial(const float* p) {
+  return fabsf(p[4]) + fabsf(p[5]) + fabsf(p[6]) + fabsf(p[7]) + fabsf(p[8]) + fabsf(p[9]) > 1e-6f;
+}
+
+__device__ __forceinline__ void cam_publish_max(float r, unsigned* slot) {
+  // NaN compares above every finite value as a bit pattern as well: the loop then runs on, as `nan < eps` is false in the reference
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float other = __shfl_xor(r, o, 64);
+    r = (other > r || other != other) ? other : r;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMax(slot, __float_as_uint(r));
+}
+
+__global__ __launch_bounds__(256) void rays_iter_init_kernel(const float* params, float4* st, unsigned* maxres, int Hn, int Wn, int nk) {
+  const float* p = params;
+  const bool use_tan = fabsf(p[10]) + fabsf(p[11]) > 1e-6f;
+  const bool use_prism = fabsf(p[12]) + fabsf(p[13]) + fabsf(p[14]) + fabsf(p[15]) > 1e-6f;
+  const bool use_radial = cam_use_radial(p);
+  const int HW = Hn * Wn;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  float r = 0.0f;
+  if (pix < HW) {
+    const int v = pix / Wn, u = pix - v * Wn;
+    const float ud = ((float)u + 0.5f - p[2]) / p[0], vd = ((float)v + 0.5f - p[3]) / p[1];
+    float xr, yr;
+    ud_cam_undistort_tanprism(ud, vd, p[10], p[11], p[12], p[13], p[14], p[15], use_tan, use_prism, (use_tan || use_prism) ? 10 : 0, xr, yr);
+    const float rnorm = sqrtf(xr * xr + yr * yr);
+    st[pix] = make_float4(xr, yr, rnorm, 0.1f);
+    if (use_radial) r = fabsf(ud_cam_radial_residual(p + 4, nk, rnorm, rnorm));
+  }
+  if (use_radial) cam_publish_max(r, maxres);
+}
+
+__global__ __launch_bounds__(256) void rays_iter_step_kernel(const float* params, float4* st, unsigned* maxres, int HW, int it, int nk) {
+  if (!cam_use_radial(params)) return;
+  if (__uint_as_float(maxres[it]) < UD_CAM_EPS) return;            // the reference left the loop at (or before) this iteration
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  float r = 0.0f;
+  if (pix < HW) {
+    float4 s = st[pix];
+    const float rnorm = sqrtf(s.x * s.x + s.y * s.y);
+    ud_cam_radial_step(params + 4, nk, rnorm, s.z, s.w);
+    st[pix] = s;
+    r = fabsf(ud_cam_radial_residual(params + 4, nk, s.z, rnorm));
+  }
+  cam_publish_max(r, maxres + it + 1);
+}
+
+__global__ __launch_bounds__(256) void rays_iter_final_kernel(const float4* st, float* rays, int HW, int tan_theta) {
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= HW) return;
+  const float4 s = st[pix];
+  float x, y, z;
+  ud_cam_finish_radial(s.x, s.y, sqrtf(s.x * s.x + s.y * s.y), s.z, tan_theta, x, y, z);
+  rays[pix] = x; rays[HW + pix] = y; rays[2 * (size_t)HW + pix] = z;
+}
+
+__global__ __launch_bounds__(256) void rays_mei_kernel(const float* params, float* rays, int Hn, int Wn) {
+  const int HW = Hn * Wn;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= HW) return;
+  const int v = pix / Wn, u = pix - v * Wn;
+  float x, y, z;
+  ud_cam_mei(params, (float)u + 0.5f, (float)v + 0.5f, x, y, z);
+  rays[pix] = x; rays[HW + pix] = y; rays[2 * (size_t)HW + pix] = z;
 }
 
 // ------------------------------------------------------------------------------------------------ ray embedding
@@ -471,6 +547,30 @@ extern "C" int ud_rays_from_kinv(const float* Kinv33, float* rays, int nb, int H
   if (!Kinv33 || !rays || nb <= 0 || Hn <= 0 || Wn <= 0) { ud_set_error("ud_rays_from_kinv: bad argument"); return UD_ERR_BAD_ARG; }
   hipLaunchKernelGGL(rays_kernel, dim3(grid_for((long long)Hn * Wn, 256, 1024), nb), dim3(256), 0, (hipStream_t)stream, Kinv33, rays, nb, Hn, Wn, gt_mode);
   UD_CHECK_LAUNCH("ud_rays_from_kinv launch");
+  return UD_OK;
+}
+
+extern "C" int ud_rays_from_camera(const float* params, float* rays, float* scratch, int Hn, int Wn, int model, void* stream) {
+  if (!params || !rays || Hn <= 0 || Wn <= 0 || model < 4 || model > 6 || (model != 6 && !scratch)) {
+    ud_set_error("ud_rays_from_camera: bad argument (model 4 OPENCV, 5 Fisheye624, 6 MEI; scratch needed for 4 and 5)");
+    return UD_ERR_BAD_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int HW = Hn * Wn;
+  const dim3 grid((HW + 255) / 256);
+  if (model == 6) {
+    hipLaunchKernelGGL(rays_mei_kernel, grid, dim3(256), 0, s, params, rays, Hn, Wn);
+    UD_CHECK_LAUNCH("ud_rays_from_camera (MEI) launch");
+    return UD_OK;
+  }
+  float4* st = (float4*)scratch;
+  unsigned* maxres = (unsigned*)(scratch + 4 * (size_t)HW);
+  const int nk = model == 5 ? 6 : 3;
+  if (hipMemsetAsync(maxres, 0, 16 * sizeof(unsigned), s) != hipSuccess) { ud_set_error("ud_rays_from_camera: memset failed"); return UD_ERR_LAUNCH; }
+  hipLaunchKernelGGL(rays_iter_init_kernel, grid, dim3(256), 0, s, params, st, maxres, Hn, Wn, nk);
+  for (int it = 0; it < 10; ++it) hipLaunchKernelGGL(rays_iter_step_kernel, grid, dim3(256), 0, s, params, st, maxres, HW, it, nk);
+  hipLaunchKernelGGL(rays_iter_final_kernel, grid, dim3(256), 0, s, (const float4*)st, rays, HW, model == 5 ? 1 : 0);
+  UD_CHECK_LAUNCH("ud_rays_from_camera launch");
   return UD_OK;
 }
 

@@ -9,16 +9,17 @@
 void ud_set_error(const char* msg);
 
 namespace {
-enum Kind { K_LIN32, K_ATTS, K_GEMM, K_LN, K_ATTN, K_PRE, K_FILL, K_CAM, K_RAYS, K_EMBED, K_UP2, K_RESIZE, K_FINAL, K_T };
+enum Kind { K_LIN32, K_ATTS, K_GEMM, K_LN, K_ATTN, K_PRE, K_FILL, K_CAM, K_RAYS, K_RAYS_CAM, K_EMBED, K_UP2, K_RESIZE, K_FINAL, K_T };
 struct FillArgs { float* dst; const float* src; int n_img, rows_per_img, row_off, D, ld; };
 struct CamArgs { const float* raw; int raw_stride; float* intr4; float* K33; float* Kinv33; float* Kpost33; int B, Hn, Wn; float rf; int pad_l, pad_t; };
 struct RaysArgs { const float* Kinv33; float* rays; int nb, Hn, Wn, gt_mode; };
+struct RaysCamArgs { const float* params; float* rays; float* scratch; int Hn, Wn, model; };
 struct AttSArgs { const float* q; const float* kv; float* out; int B, T, H, C; float scale; };
 struct TArgs { const float* in; float* out; int B, hw, C, ld, rows_per_img; };
 struct Op {
   Kind kind;
   union {
-    UdGemm gemm; UdLayerNorm ln; UdAttention attn; UdPreprocess pre; FillArgs fill; CamArgs cam; RaysArgs rays;
+    UdGemm gemm; UdLayerNorm ln; UdAttention attn; UdPreprocess pre; FillArgs fill; CamArgs cam; RaysArgs rays; RaysCamArgs rays_cam;
     UdRayEmbed embed; UdUpsample2x up2; UdResizeAC resize; UdFinalize fin; TArgs t; UdLinearF32 lin32; AttSArgs atts;
   };
   Op() {}
@@ -58,6 +59,10 @@ int ud_program_add_rays(UdProgram* p, const float* Kinv33, float* rays, int nb, 
   RaysArgs a = {Kinv33, rays, nb, Hn, Wn, gt_mode};
   ADD(K_RAYS, rays, a)
 }
+int ud_program_add_rays_camera(UdProgram* p, const float* params, float* rays, float* scratch, int Hn, int Wn, int model) {
+  RaysCamArgs a = {params, rays, scratch, Hn, Wn, model};
+  ADD(K_RAYS_CAM, rays_cam, a)
+}
 int ud_program_add_ray_embed(UdProgram* p, const UdRayEmbed* d) { ADD(K_EMBED, embed, *d) }
 int ud_program_add_upsample2x(UdProgram* p, const UdUpsample2x* d) { ADD(K_UP2, up2, *d) }
 int ud_program_add_resize_ac(UdProgram* p, const UdResizeAC* d) { ADD(K_RESIZE, resize, *d) }
@@ -82,6 +87,7 @@ int ud_program_run(const UdProgram* p, int first, int last, void* stream) {
       case K_FILL: rc = ud_fill_rows_f32(op.fill.dst, op.fill.src, op.fill.n_img, op.fill.rows_per_img, op.fill.row_off, op.fill.D, op.fill.ld, stream); break;
       case K_CAM: rc = ud_camera_intrinsics(op.cam.raw, op.cam.raw_stride, op.cam.intr4, op.cam.K33, op.cam.Kinv33, op.cam.Kpost33, op.cam.B, op.cam.Hn, op.cam.Wn, op.cam.rf, op.cam.pad_l, op.cam.pad_t, stream); break;
       case K_RAYS: rc = ud_rays_from_kinv(op.rays.Kinv33, op.rays.rays, op.rays.nb, op.rays.Hn, op.rays.Wn, op.rays.gt_mode, stream); break;
+      case K_RAYS_CAM: rc = ud_rays_from_camera(op.rays_cam.params, op.rays_cam.rays, op.rays_cam.scratch, op.rays_cam.Hn, op.rays_cam.Wn, op.rays_cam.model, stream); break;
       case K_EMBED: rc = ud_ray_embed(&op.embed, stream); break;
       case K_UP2: rc = ud_upsample2x_nhwc(&op.up2, stream); break;
       case K_RESIZE: rc = ud_resize_ac_nhwc_f16(&op.resize, stream); break;

@@ -127,6 +127,11 @@ class Program:
         self.meta.append(("misc", "rays", 0.0, 12.0 * nb * Hn * Wn))
         return check(lib.ud_program_add_rays(self.h, ptr(Kinv33), ptr(rays), nb, Hn, Wn, gt_mode))
 
+    def rays_camera(self, params, rays, scratch, Hn, Wn, model):
+        self.keep += [params, rays, scratch]
+        self.meta.append(("misc", "rays_camera", 0.0, 12.0 * Hn * Wn))
+        return check(lib.ud_program_add_rays_camera(self.h, ptr(params), ptr(rays), ptr(scratch), Hn, Wn, model))
+
     def ray_embed(self, **kw):
         self._k(kw, "ray_embed"); return check(lib.ud_program_add_ray_embed(self.h, C.byref(mk(UdRayEmbed, **kw))))
 

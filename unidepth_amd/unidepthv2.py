@@ -24,7 +24,7 @@ import torch
 from . import ops
 from .ops import (UD_A_CONV3_REFLECT, UD_A_CONV3_ZERO, UD_ACT_GELU, UD_ACT_LRELU, UD_ACT_NONE, UD_EPI_D2S, UD_EPI_F16,
                   UD_EPI_F32, UD_EPI_HEAD, UD_EPI_QKV)
-from .cameras import GT_PINHOLE, as_camera
+from .cameras import GT_OPENCV, GT_PINHOLE, as_camera
 from .weights import arch_of, pack
 
 IMAGENET_DATASET_MEAN = (0.485, 0.456, 0.406)      # unidepth/utils/constants.py:12
@@ -204,7 +204,11 @@ class _Plan:
         P.camera_intrinsics(raw, 1, self.intr4, self.K33, kinv, self.Kpost, B, Hn, Wn, float(self.rf), pl, pt)
         # ---------------- rays (decoder.py:361-403 / GT camera: unidepthv2.py:299-303,361-362)
         self.rays = z(nb, 3, Hn, Wn, dtype=f32)
-        if cam_nb:
+        if cam_nb and gt_mode >= GT_OPENCV:                                 # iterative models: OPENCV, Fisheye624, MEI (one camera)
+            self.kinv_gt = z(1, 16, dtype=f32)
+            self.cam_scratch = z(4 * Hn * Wn + 16, dtype=f32)
+            P.rays_camera(self.kinv_gt, self.rays, self.cam_scratch, Hn, Wn, gt_mode)
+        elif cam_nb:
             self.kinv_gt = z(nb, 9, dtype=f32)
             P.rays(self.kinv_gt, self.rays, nb, Hn, Wn, gt_mode or 1)      # 1 pinhole K^-1, 2 EUCM / 3 Spherical parameters
         else:
@@ -443,7 +447,7 @@ class UniDepthV2:
             rgb = rgb.unsqueeze(0)
         B, _, H, W = rgb.shape
         Kc = None
-        cam_obj = None                                             # EUCM / Spherical: parameters go to the ray kernel as they are
+        cam_obj = None                                             # non-pinhole models: parameters go to the ray kernels as they are
         if camera is not None:
             if isinstance(camera, torch.Tensor):
                 Kc = camera
@@ -461,8 +465,8 @@ class UniDepthV2:
             plan = self._plan(B, H, W, cam_nb, is_u8, bool(normalize), int(slot), gt_mode)
             plan.rgb.copy_(rgb if is_u8 else rgb.float(), non_blocking=True)
             if cam_obj is not None:
-                pn = cam_obj.network_params(plan.paddings, plan.rf)               # [n, <= 8] -> the 9-float slots of the ray kernel
-                buf = torch.zeros(pn.shape[0], 9)
+                pn = cam_obj.network_params(plan.paddings, plan.rf)               # [n, <= 16] -> the parameter slots of the ray kernel
+                buf = torch.zeros(pn.shape[0], plan.kinv_gt.shape[1])
                 buf[:, :pn.shape[1]] = pn
                 plan.kinv_gt.copy_(buf)
             if Kc is not None:
