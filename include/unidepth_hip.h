@@ -75,7 +75,9 @@ typedef struct UdGemm {
   int groups;
   long long gA, gW, gBias, gOut, gOut2, gW2;
   float b2_g1, post_add_g1;    /* group 1 constants for UD_EPI_HEAD */
-  int tile_hint;               /* 0 = auto, 1 = force 128x128 tiles, 2 = force 256x256, 3 = force 192x256 (dense A only) */
+  int tile_hint;               /* 0 = auto, 1 = force 128x128 tiles, 2 = force 256x256, 3 = force 192x256 (dense A only),
+                                  5 / 6 = 128x128 tiles: plain 2-stage kernel / 4-stage pipelined ring (6 is what auto picks when the
+                                  tile count is at most the CU count and K >= 512) */
 } UdGemm;
 
 int ud_gemm_f16(const UdGemm* desc, void* stream);

@@ -135,6 +135,8 @@ def test_resolution_level_and_float_input(engine_cls):
 
 @pytest.mark.parametrize("arch,H,W,B,normalize,ndim3", [("vits14", 240, 320, 1, True, True),      # up-resized input, [3,H,W] call form
                                                       ("vits14", 462, 616, 2, False, False),    # caller-normalised float input
+                                                      ("vits14", 640, 200, 1, True, False),     # tall: aspect padding left / right (60 / 60)
+                                                      ("vits14", 70, 90, 2, True, False),       # tiny input, up-resized ~5.6x; passed as a CPU tensor
                                                       ("vitl14", 644, 966, 1, True, False)])    # BASELINE configs[4] shape (3128 tokens)
 def test_infer_more_shapes_and_call_forms(engine_cls, arch, H, W, B, normalize, ndim3):
     cfg = synth.load_config(arch)
@@ -146,8 +148,9 @@ def test_infer_more_shapes_and_call_forms(engine_cls, arch, H, W, B, normalize, 
     x = rgb[0] if ndim3 else rgb
     ref = restate.OracleV2(cfg, sd).infer(x, None, normalize=normalize)
     model = engine_cls(cfg).load_state_dict(sd).to("cuda").eval()
-    out = model.infer(x.cuda(), None, normalize=normalize)
+    out = model.infer(x if H < 100 else x.cuda(), None, normalize=normalize)     # the reference moves a CPU input to its device itself
     torch.cuda.synchronize()
+    assert out["depth"].is_cuda and out["depth"].shape[-2:] == (H, W)
     _check(out, ref, f"{arch}_{H}x{W}_b{B}_norm{int(normalize)}")
 
 

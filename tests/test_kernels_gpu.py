@@ -107,7 +107,7 @@ def test_gemm_big_tiles_persistent(ops, hint):
     qk = torch.zeros(M, 2 * D, dtype=torch.half, device="cuda")
     vt = torch.zeros(B, H, 64, kv_ld, dtype=torch.half, device="cuda")
     ops.gemm(A=A, W=W, bias=bias, out=qk, out2=vt, M=M, N=N, K=K, lda=K, ldw=K, ldc=2 * D, epi=ops.UD_EPI_QKV,
-             vsplit=2 * D, tok_per_img=Npad, kv_ld=kv_ld, heads_v=H, tile_hint=hint)
+             vsplit=2 * D, tok_per_img=Npad, kv_ld=kv_ld, heads_v=H, tile_hint=6)
     ref = A.float() @ W.float().t() + bias
     torch.cuda.synchronize()
     assert rel(qk.float(), ref[:, :2 * D]) < 1e-3
@@ -172,6 +172,52 @@ def test_gemm_f32_accumulate_remap_add(ops):
     ops.gemm(**kw)
     torch.cuda.synchronize()
     assert rel(x.view(B, Npad, N)[:, 1:hw + 1], 2 * ref) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(1370, 1024, 1024), (1370, 1024, 4096), (700, 512, 2048), (2740, 1024, 512), (300, 256, 576)])
+def test_gemm_pipelined_ring(ops, M, N, K):
+    """Fewer 128x128 tiles than CUs (small batches): 4-stage ring, software-pipelined over K-tiles, raw LDS reads (tile_hint 6,
+    what auto picks here) against the fp32 statement and against the plain 2-stage kernel (tile_hint 5): fp16 + GELU, fp32
+    residual-accumulate with fp16 copy, edge tiles in M, odd K-tile counts; auto twice for bit-exact repeatability."""
+    A = rnd(M, K, seed=1).half()
+    W = rnd(N, K, scale=K ** -0.5, seed=2).half()
+    bias = rnd(N, seed=3)
+    ref = A.float() @ W.float().t() + bias
+    outs = {}
+    for tag, hint in (("auto", 1), ("auto2", 1), ("plain", 5), ("ring", 6)):
+        out = torch.zeros(M, N, dtype=torch.half, device="cuda")
+        ops.gemm(A=A, W=W, bias=bias, out=out, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, epi=ops.UD_EPI_F16, act=ops.UD_ACT_GELU, tile_hint=hint)
+        x = rnd(M, N, seed=5)
+        x16 = torch.zeros(M, N, dtype=torch.half, device="cuda")
+        ops.gemm(A=A, W=W, bias=bias, out=x, out2=x16, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, ldc2=N, epi=ops.UD_EPI_F32, accumulate=1, tile_hint=hint)
+        outs[tag] = (out, x, x16)
+    torch.cuda.synchronize()
+    x0 = rnd(M, N, seed=5)
+    for tag, (out, x, x16) in outs.items():
+        assert rel(out.float(), F.gelu(ref)) < 1e-3, tag
+        assert rel(x, x0 + ref) < 2e-5, tag
+        assert rel(x16.float(), x0 + ref) < 1e-3, tag
+    assert torch.equal(outs["auto"][0], outs["auto2"][0]) and torch.equal(outs["auto"][1], outs["auto2"][1])
+    assert torch.equal(outs["auto"][1], outs["ring"][1]) and torch.equal(outs["ring"][1], outs["plain"][1])   # same summation order
+
+
+def test_gemm_pipelined_ring_qkv(ops):
+    B, Npad, D, H = 2, 688, 512, 8           # 11 x 12 = 132 tiles, 8 K-tiles: Q|K tiles and V^T tiles
+    M, N, K = B * Npad, 3 * D, D
+    kv_ld = 704
+    A = rnd(M, K, seed=1).half()
+    W = rnd(N, K, scale=K ** -0.5, seed=2).half()
+    bias = rnd(N, seed=3)
+    qk = torch.zeros(M, 2 * D, dtype=torch.half, device="cuda")
+    vt = torch.zeros(B, H, 64, kv_ld, dtype=torch.half, device="cuda")
+    ops.gemm(A=A, W=W, bias=bias, out=qk, out2=vt, M=M, N=N, K=K, lda=K, ldw=K, ldc=2 * D, epi=ops.UD_EPI_QKV,
+             vsplit=2 * D, tok_per_img=Npad, kv_ld=kv_ld, heads_v=H, tile_hint=6)
+    ref = A.float() @ W.float().t() + bias
+    torch.cuda.synchronize()
+    assert rel(qk.float(), ref[:, :2 * D]) < 1e-3
+    vref = ref[:, 2 * D:].view(B, Npad, H, 64).permute(0, 2, 3, 1)
+    assert rel(vt[..., vt_cols(Npad)].float(), vref) < 1e-3
+    assert vt_unused_zero(vt, Npad)
 
 
 def test_gemm_qkv_epilogue(ops):

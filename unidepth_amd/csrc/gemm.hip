@@ -6,7 +6,9 @@
 //    the LDS image is lane-linear [row][64 halves]; bank conflicts of the ds_read_b128 fragment reads are removed
 //    by an XOR swizzle of the 16-byte chunk index, applied on the *global source* address and on the read address:
 //    chunk' = chunk ^ ((row >> 1) & 7)  -> the 16 lanes of every ds_read_b128 service group hit 16 distinct slots.
-//  * 2-stage LDS ring: tile kt+1 streams in while tile kt is multiplied; one s_barrier per K-tile.
+//  * 2-stage LDS ring: tile kt+1 streams in while tile kt is multiplied; one s_barrier per K-tile (two workgroups per CU
+//    cover each other's stalls).  With at most one workgroup per CU (tile count <= CU count, small batches) the 128 x 128
+//    configuration switches to a 4-stage ring, software-pipelined over K-tiles (gemm_body, NST = 4).
 //  * operands are issued as mfma(W_frag, A_frag): the accumulator then holds C^T fragments, i.e. each lane owns
 //    4 consecutive n for one m -> 8-byte fp16 / 16-byte fp32 row-major stores.  Tiles that produce V^T for the
 //    attention kernel use the opposite order (4 consecutive tokens per lane -> 8-byte stores into [head][d][token]).
@@ -39,6 +41,8 @@ struct Cfg {
   static constexpr int B_INSTR = BN / 32;
   static_assert(NWM * NWN == 4, "4 waves");
 };
+
+template <int I> struct IntTag { static constexpr int value = I; };
 
 struct ConvLane {
   long long base;  // element offset of the image
@@ -278,7 +282,24 @@ __device__ __forceinline__ void gemm_epilogue(const UdGemm& p, f32x4 (&acc)[TM][
   }
 }
 
-template <class C, int EPI, int AMODE, bool SWAP>
+// LDS fragment read the compiler does not see as an LDS access.  With ordinary ds_reads in the loop, the waitcnt pass puts
+// `s_waitcnt vmcnt(0)` in front of them whenever a global_load_lds is in flight (it cannot tell the ring stages apart), which
+// turns any ring deeper than two stages back into a two-stage one.  The caller owns the lgkmcnt wait (ud_lds_wait16).
+template <int OFF>
+__device__ __forceinline__ half8 ud_lds_read16_raw(unsigned addr) {
+  half8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+__device__ __forceinline__ void ud_lds_wait16(half8 (&a)[2][4], half8 (&b)[2][4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]),
+                 "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]), "+v"(b[1][3]));
+}
+
+// NST = stages of the operand ring (NST - 1 K-tiles in flight).  Two stages are enough when two workgroups share a CU; with one
+// workgroup per CU (fewer tiles than CUs) the loop waits on the DMA round trip every K-tile, and a deeper ring hides it.
+template <class C, int EPI, int AMODE, bool SWAP, int NST = 2>
 __device__ __forceinline__ void gemm_body(const UdGemm& p, char* smem, int m0, int n0, const half_t* A, const half_t* W,
                                           const float* bias, char* out, char* out2, const float* w2, float b2, float post_add) {
   const int tid = threadIdx.x;
@@ -365,33 +386,112 @@ __device__ __forceinline__ void gemm_body(const UdGemm& p, char* smem, int m0, i
 #pragma unroll
     for (int j = 0; j < C::TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  issue(0, 0);
   constexpr bool PRE = (EPI == UD_EPI_F32) && SWAP;
-  if constexpr (PRE) {
-    if (p.accumulate) gemm_preload_acc<C::TM, C::TN>(p, acc, m0 + wm * C::WM, n0 + wn * C::WN, lane, out);
-  }
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-    const char* sb = smem + (kt & 1) * C::STAGE_BYTES;
+  constexpr int LOADS = C::A_INSTR + C::B_INSTR;           // DMA instructions per thread per K-tile (vmcnt units)
+  static_assert(NST == 2 || NST == 4, "ring depth");
+  auto mfma_kstep = [&](half8 (&af)[2][C::TM], half8 (&bf)[2][C::TN], auto KS_) {
+    constexpr int ks = decltype(KS_)::value;
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < C::TN; ++j) {
+        if constexpr (SWAP)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+        else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
+      }
+  };
+  if constexpr (NST > 2) {
+    // ---- one workgroup per CU (fewer tiles than CUs): 4-stage ring, software-pipelined over K-tiles.
+    // Iteration kt:  [fragments of kt are in registers, read during kt-1]  16 MFMAs (k-step 0)  ->  wait for the DMA of kt+1,
+    // barrier  ->  DMA of kt+3 into the stage kt-1 left, fragment reads of kt+1 into the other register set  ->  16 MFMAs
+    // (k-step 1) covering those reads.  Nothing of the LDS or DMA round trips is exposed unless a K-tile takes longer than
+    // 1.5 iterations to arrive.  Fragment reads are raw asm (ud_lds_read16_raw explains why), the barrier is the bare s_barrier.
+    static_assert(C::TM == 4 && C::TN == 4, "deep ring: 128 x 128 tiles only");
+    if constexpr (PRE) {   // residual first: loads retire in order, so waiting for K-tile 0 below also covers it
+      if (p.accumulate) gemm_preload_acc<C::TM, C::TN>(p, acc, m0 + wm * C::WM, n0 + wn * C::WN, lane, out);
+    }
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st)
+      if (st < nk) issue(st, st);
+    const unsigned lds0 = (unsigned)(size_t)smem;          // low half of the flat address of an LDS object = its LDS offset
+    unsigned aa[2], ba[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const int coff = ((ks * 4 + fq) ^ fswz) << 4;
-      half8 af[C::TM], bf[C::TN];
+      aa[ks] = lds0 + a_row_off + (((ks * 4 + fq) ^ fswz) << 4);
+      ba[ks] = lds0 + b_row_off + (((ks * 4 + fq) ^ fswz) << 4);
+    }
+    auto read_frags = [&](half8 (&af)[2][4], half8 (&bf)[2][4], int stage) {
+      const unsigned so = (unsigned)stage * C::STAGE_BYTES;
 #pragma unroll
-      for (int i = 0; i < C::TM; ++i) af[i] = *(const half8*)(sb + a_row_off + i * 2048 + coff);
+      for (int ks = 0; ks < 2; ++ks) {
+        const unsigned a = aa[ks] + so, b = ba[ks] + so;
+        af[ks][0] = ud_lds_read16_raw<0>(a); af[ks][1] = ud_lds_read16_raw<2048>(a);
+        af[ks][2] = ud_lds_read16_raw<4096>(a); af[ks][3] = ud_lds_read16_raw<6144>(a);
+        bf[ks][0] = ud_lds_read16_raw<0>(b); bf[ks][1] = ud_lds_read16_raw<2048>(b);
+        bf[ks][2] = ud_lds_read16_raw<4096>(b); bf[ks][3] = ud_lds_read16_raw<6144>(b);
+      }
+    };
+    auto wait_tile = [&](int kt) {       // own DMA of K-tile kt has landed; K-tiles kt+1 .. (at most two) may still be in flight
+      const int later = nk - 1 - kt;
+      if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    half8 fa0[2][4], fb0[2][4], fa1[2][4], fb1[2][4];
+    wait_tile(0);
+    __builtin_amdgcn_s_barrier();
+    read_frags(fa0, fb0, 0);
+    auto step = [&](half8 (&ca)[2][4], half8 (&cb)[2][4], half8 (&na)[2][4], half8 (&nb)[2][4], int kt) {
+      ud_lds_wait16(ca, cb);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_kstep(ca, cb, IntTag<0>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < nk) {
+        // at this point K-tile kt+2 is the only later one issued (kt+3 goes out below)
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 3 < nk) issue(kt + 3, (kt + 3) & 3);
+        read_frags(na, nb, (kt + 1) & 3);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_kstep(ca, cb, IntTag<1>{});
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      step(fa0, fb0, fa1, fb1, kt);
+      step(fa1, fb1, fa0, fb0, kt + 1);
+    }
+    if (kt < nk) step(fa0, fb0, fa1, fb1, kt);
+  } else {
+    issue(0, 0);
+    if constexpr (PRE) {
+      if (p.accumulate) gemm_preload_acc<C::TM, C::TN>(p, acc, m0 + wm * C::WM, n0 + wn * C::WN, lane, out);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+      const char* sb = smem + (kt & 1) * C::STAGE_BYTES;
+      // all 16 fragment reads of the K-tile go out back to back, then the 32 MFMAs: one exposed LDS round trip per K-tile and
+      // wave.  Left alone the compiler serialises four read -> lgkmcnt(0) -> 8 MFMA groups per K-tile (fewest registers).
+      half8 af[2][C::TM], bf[2][C::TN];
 #pragma unroll
-      for (int j = 0; j < C::TN; ++j) bf[j] = *(const half8*)(sb + b_row_off + j * 2048 + coff);
+      for (int ks = 0; ks < 2; ++ks) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int coff = ((ks * 4 + fq) ^ fswz) << 4;
 #pragma unroll
-      for (int i = 0; i < C::TM; ++i)
+        for (int i = 0; i < C::TM; ++i) af[ks][i] = *(const half8*)(sb + a_row_off + i * 2048 + coff);
 #pragma unroll
-        for (int j = 0; j < C::TN; ++j) {
-          if constexpr (SWAP)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
-          else
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < C::TN; ++j) bf[ks][j] = *(const half8*)(sb + b_row_off + j * 2048 + coff);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_kstep(af, bf, IntTag<0>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_kstep(af, bf, IntTag<1>{});
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   char* stage = nullptr;
@@ -402,7 +502,7 @@ __device__ __forceinline__ void gemm_body(const UdGemm& p, char* smem, int m0, i
   gemm_epilogue<C::TM, C::TN, EPI, SWAP, PRE>(p, acc, m0 + wm * C::WM, n0 + wn * C::WN, lane, bias, out, out2, w2, b2, post_add, stage);
 }
 
-template <class C, int EPI, int AMODE>
+template <class C, int EPI, int AMODE, int NST = 2>
 __global__ __launch_bounds__(256) void gemm_kernel(const UdGemm p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tiles_n = (p.N + C::BN - 1) / C::BN;
@@ -428,11 +528,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const UdGemm p) {
   const float post_add = g == 0 ? p.post_add : p.post_add_g1;
   if constexpr (EPI == UD_EPI_QKV) {
     if (n0 >= p.vsplit) {
-      gemm_body<C, EPI, AMODE, false>(p, smem, m0, n0, A, W, bias, out, out2, w2, b2, post_add);
+      gemm_body<C, EPI, AMODE, false, NST>(p, smem, m0, n0, A, W, bias, out, out2, w2, b2, post_add);
       return;
     }
   }
-  gemm_body<C, EPI, AMODE, true>(p, smem, m0, n0, A, W, bias, out, out2, w2, b2, post_add);
+  gemm_body<C, EPI, AMODE, true, NST>(p, smem, m0, n0, A, W, bias, out, out2, w2, b2, post_add);
 }
 
 // ================================================================================================================
@@ -462,7 +562,6 @@ struct BigCfg {
 };
 
 template <bool B> struct BoolTag { static constexpr bool value = B; };
-template <int I> struct IntTag { static constexpr int value = I; };
 
 // two packed-fp16 dwords of column tiles j / j+1 -> 8 consecutive columns per lane (see the layout note in the kernel)
 __device__ __forceinline__ void ud_pair16(unsigned& a, unsigned& b) {
@@ -944,7 +1043,7 @@ inline int pick_tiles(const UdGemm& d) {
     if (a_bytes >= 2147483648.0 || 2.0 * d.N * d.ldw >= 2147483648.0) return 0;
   }
   if (d.epi == UD_EPI_QKV && (d.vsplit & 255)) return 0;
-  if (d.tile_hint == 1) return 0;
+  if (d.tile_hint == 1 || d.tile_hint >= 5) return 0;
   if (d.tile_hint == 2) return 4;
   if (d.tile_hint == 3) return 3;
   const double kk = (double)d.K / 1024.0;
@@ -1130,6 +1229,26 @@ template <class C, int EPI, int AMODE>
 int launch(const UdGemm& d, hipStream_t s) {
   const int tiles_n = (d.N + C::BN - 1) / C::BN;
   const int tiles_m = (d.M + C::BM - 1) / C::BM;
+  if constexpr (C::BN == 128 && AMODE == UD_A_DENSE && (EPI == UD_EPI_F16 || EPI == UD_EPI_F32 || EPI == UD_EPI_QKV)) {
+    // At most one workgroup per CU anyway (small batches): the plain kernel, tuned for two co-resident workgroups hiding each
+    // other's stalls, leaves the CU idle through every DMA / LDS round trip -> 4-stage ring, software-pipelined over K-tiles
+    // (gemm_body, NST = 4).  tile_hint 5 keeps the plain kernel, 6 forces the ring.
+    const int nkt = d.K >> 6;
+    if (d.groups <= 1 && nkt >= 4 && d.tile_hint != 5 && ((tiles_m * tiles_n <= 256 && nkt >= 8) || d.tile_hint == 6) && !(ud_debug_flags_host() & 16)) {
+      const int lds4 = 4 * C::STAGE_BYTES;
+      static bool attr4_set = false;
+      if (!attr4_set) {
+        if (hipFuncSetAttribute((const void*)gemm_kernel<C, EPI, AMODE, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4) != hipSuccess) {
+          ud_set_error("ud_gemm_f16: cannot reserve the 4-stage LDS ring");
+          return UD_ERR_LAUNCH;
+        }
+        attr4_set = true;
+      }
+      hipLaunchKernelGGL((gemm_kernel<C, EPI, AMODE, 4>), dim3(tiles_m * tiles_n), dim3(256), lds4, s, d);
+      UD_CHECK_LAUNCH("ud_gemm_f16 (4-stage ring) launch");
+      return UD_OK;
+    }
+  }
   const int lds = 2 * C::STAGE_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
