@@ -201,6 +201,41 @@ def test_gemm_pipelined_ring(ops, M, N, K):
     assert torch.equal(outs["auto"][1], outs["ring"][1]) and torch.equal(outs["ring"][1], outs["plain"][1])   # same summation order
 
 
+@pytest.mark.parametrize("M,N,K", [(1370, 1024, 1024), (1370, 1024, 4096), (700, 512, 2048), (300, 256, 512)])
+def test_gemm_two_way_k_split(ops, M, N, K):
+    """At most 128 tiles and a long K (proj / fc2 at batch 1): two workgroups on different CUs take half of K each and the later
+    one adds the other's fp32 partial tile, exchanged without agent-scope fences (tile_hint 7).  Against the fp32 statement and
+    the unsplit ring (6); five launches in a row must agree bit for bit (the join must not depend on arrival order, tickets
+    carry over between launches), fp16 + GELU and fp32 residual-accumulate + fp16 copy epilogues."""
+    A = rnd(M, K, seed=1).half()
+    W = rnd(N, K, scale=K ** -0.5, seed=2).half()
+    bias = rnd(N, seed=3)
+    ref = A.float() @ W.float().t() + bias
+    ws = torch.empty(256 * 16384, device="cuda")
+    cnt = torch.zeros(128, dtype=torch.int32, device="cuda")
+    runs = []
+    for hint in (7, 7, 7, 7, 7, 6):
+        out = torch.zeros(M, N, dtype=torch.half, device="cuda")
+        ops.gemm(A=A, W=W, bias=bias, out=out, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, epi=ops.UD_EPI_F16, act=ops.UD_ACT_GELU, tile_hint=hint,
+                 splitk_ws=ws, splitk_cnt=cnt)
+        x = rnd(M, N, seed=5)
+        x16 = torch.zeros(M, N, dtype=torch.half, device="cuda")
+        ops.gemm(A=A, W=W, bias=bias, out=x, out2=x16, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, ldc2=N, epi=ops.UD_EPI_F32, accumulate=1,
+                 tile_hint=hint, splitk_ws=ws, splitk_cnt=cnt)
+        runs.append((out, x, x16))
+    torch.cuda.synchronize()
+    x0 = rnd(M, N, seed=5)
+    for out, x, x16 in runs:
+        assert rel(out.float(), F.gelu(ref)) < 1e-3
+        assert rel(x, x0 + ref) < 2e-5
+        assert rel(x16.float(), x0 + ref) < 1e-3
+    for out, x, x16 in runs[1:5]:
+        assert torch.equal(out, runs[0][0]) and torch.equal(x, runs[0][1]) and torch.equal(x16, runs[0][2])
+    assert rel(runs[0][1], runs[5][1]) < 2e-6
+    tiles = -(-M // 128) * -(-N // 128)
+    assert int(cnt[:tiles].min()) == 20 and int(cnt[:tiles].max()) == 20 and int(cnt[tiles:].abs().max() if tiles < 128 else 0) == 0
+
+
 def test_gemm_pipelined_ring_qkv(ops):
     B, Npad, D, H = 2, 688, 512, 8           # 11 x 12 = 132 tiles, 8 K-tiles: Q|K tiles and V^T tiles
     M, N, K = B * Npad, 3 * D, D

@@ -31,6 +31,7 @@ class UdGemm(C.Structure):
         ("groups", i32),
         ("gA", i64), ("gW", i64), ("gBias", i64), ("gOut", i64), ("gOut2", i64), ("gW2", i64),
         ("b2_g1", f32), ("post_add_g1", f32), ("tile_hint", i32),
+        ("splitk_ws", vp), ("splitk_cnt", vp),
     ]
 
 

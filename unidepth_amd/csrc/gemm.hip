@@ -299,14 +299,16 @@ __device__ __forceinline__ void ud_lds_wait16(half8 (&a)[2][4], half8 (&b)[2][4]
 
 // NST = stages of the operand ring (NST - 1 K-tiles in flight).  Two stages are enough when two workgroups share a CU; with one
 // workgroup per CU (fewer tiles than CUs) the loop waits on the DMA round trip every K-tile, and a deeper ring hides it.
-template <class C, int EPI, int AMODE, bool SWAP, int NST = 2>
+template <class C, int EPI, int AMODE, bool SWAP, int NST = 2, bool SPLIT = false>
 __device__ __forceinline__ void gemm_body(const UdGemm& p, char* smem, int m0, int n0, const half_t* A, const half_t* W,
-                                          const float* bias, char* out, char* out2, const float* w2, float b2, float post_add) {
+                                          const float* bias, char* out, char* out2, const float* w2, float b2, float post_add,
+                                          int tile = 0, int half_k = 0) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wv / C::NWN, wn = wv % C::NWN;
-  const int nk = p.K >> 6;
+  const int nk = SPLIT ? (p.K >> 7) : (p.K >> 6);          // SPLIT: this workgroup multiplies K-tiles [kbase, kbase + nk)
+  const int kbase = SPLIT ? half_k * nk : 0;
 
   // ---------------- loader geometry: lane -> (row within 8-row group, chunk position) ----------------
   const int lrow = lane >> 3;   // 0..7
@@ -409,11 +411,11 @@ __device__ __forceinline__ void gemm_body(const UdGemm& p, char* smem, int m0, i
     // 1.5 iterations to arrive.  Fragment reads are raw asm (ud_lds_read16_raw explains why), the barrier is the bare s_barrier.
     static_assert(C::TM == 4 && C::TN == 4, "deep ring: 128 x 128 tiles only");
     if constexpr (PRE) {   // residual first: loads retire in order, so waiting for K-tile 0 below also covers it
-      if (p.accumulate) gemm_preload_acc<C::TM, C::TN>(p, acc, m0 + wm * C::WM, n0 + wn * C::WN, lane, out);
+      if (p.accumulate && half_k == 0) gemm_preload_acc<C::TM, C::TN>(p, acc, m0 + wm * C::WM, n0 + wn * C::WN, lane, out);
     }
 #pragma unroll
     for (int st = 0; st < NST - 1; ++st)
-      if (st < nk) issue(st, st);
+      if (st < nk) issue(kbase + st, st);
     const unsigned lds0 = (unsigned)(size_t)smem;          // low half of the flat address of an LDS object = its LDS offset
     unsigned aa[2], ba[2];
 #pragma unroll
@@ -452,7 +454,7 @@ __device__ __forceinline__ void gemm_body(const UdGemm& p, char* smem, int m0, i
         if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + 3 < nk) issue(kt + 3, (kt + 3) & 3);
+        if (kt + 3 < nk) issue(kbase + kt + 3, (kt + 3) & 3);
         read_frags(na, nb, (kt + 1) & 3);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -494,6 +496,43 @@ __device__ __forceinline__ void gemm_body(const UdGemm& p, char* smem, int m0, i
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  if constexpr (SPLIT) {
+    // ---- join of the two K halves (workgroups on different CUs, in general on different XCDs with private L2s).
+    // Partials travel with system-scope cache policy (sc0 sc1: stores write through, loads bypass the non-coherent L2), ordered
+    // by vmcnt(0) around one ticket atomic per workgroup: no agent-scope fence -- __threadfence() writes back / invalidates the
+    // whole L2 and costs 20-50 us per launch here (tools/ubench/partial_exchange.hip: 56 us vs 7.8 us for 256 x 64 KB).
+    static_assert(C::TM == 4 && C::TN == 4 && NST == 4, "split: 128 x 128 ring kernel only");
+    f32x4* mine = (f32x4*)p.splitk_ws + ((size_t)(tile * 2 + half_k) * 4 + wv) * 1024 + lane;
+    const f32x4* other = (const f32x4*)p.splitk_ws + ((size_t)(tile * 2 + (half_k ^ 1)) * 4 + wv) * 1024 + lane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 v = acc[i][j];
+        // s_nop: the data VGPRs of a 16-byte store must not be rewritten in the next cycles (the compiler guards only its own stores)
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 2" ::"v"(mine + (i * 4 + j) * 64), "v"(v) : "memory");
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                       // every wave's partial is out (and nobody reads operand tiles any more)
+    unsigned* tk = (unsigned*)smem;
+    if (tid == 0) *tk = atomicAdd((unsigned*)p.splitk_cnt + tile, 1u);
+    __syncthreads();
+    const unsigned ticket = *tk;
+    if ((ticket & 1u) == 0) return;        // first of the pair: the partner finishes the tile (tickets: parity, never reset)
+    f32x4 o[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(o[q]) : "v"(other + q * 64) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]), "+v"(o[8]), "+v"(o[9]),
+                   "+v"(o[10]), "+v"(o[11]), "+v"(o[12]), "+v"(o[13]), "+v"(o[14]), "+v"(o[15])
+                 :
+                 : "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] += o[i * 4 + j];     // a + b == b + a: the sum does not depend on which half came last
+    __syncthreads();                       // the ticket word is read: LDS may become the store staging area
+  }
   char* stage = nullptr;
   if constexpr ((EPI == UD_EPI_F16 || EPI == UD_EPI_QKV) && SWAP && C::TN == 4 && C::TM == 4) {
     __syncthreads();                       // every wave is done reading operand tiles: LDS becomes the store staging area
@@ -502,13 +541,19 @@ __device__ __forceinline__ void gemm_body(const UdGemm& p, char* smem, int m0, i
   gemm_epilogue<C::TM, C::TN, EPI, SWAP, PRE>(p, acc, m0 + wm * C::WM, n0 + wn * C::WN, lane, bias, out, out2, w2, b2, post_add, stage);
 }
 
-template <class C, int EPI, int AMODE, int NST = 2>
+template <class C, int EPI, int AMODE, int NST = 2, bool SPLIT = false>
 __global__ __launch_bounds__(256) void gemm_kernel(const UdGemm p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tiles_n = (p.N + C::BN - 1) / C::BN;
   const int tiles_m = (p.M + C::BM - 1) / C::BM;
   const int nblk = tiles_m * tiles_n;
   int bid = blockIdx.x;
+  if constexpr (SPLIT) {                // blocks 2t / 2t+1 (different XCDs) = K halves 0 / 1 of tile t; fewer blocks than CUs
+    const int tile_m = (bid >> 1) / tiles_n, tile_n = (bid >> 1) - tile_m * tiles_n;
+    gemm_body<C, EPI, AMODE, true, NST, true>(p, smem, tile_m * C::BM, tile_n * C::BN, (const half_t*)p.A, (const half_t*)p.W, p.bias,
+                                              (char*)p.out, (char*)p.out2, p.w2, p.b2, p.post_add, bid >> 1, bid & 1);
+    return;
+  }
   {  // bijective XCD-aware remap: block b runs on XCD b % 8 -> give each XCD a contiguous range of tiles
     const int q = nblk >> 3, r = nblk & 7;
     const int xcd = bid & 7, idx = bid >> 3;
@@ -528,11 +573,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const UdGemm p) {
   const float post_add = g == 0 ? p.post_add : p.post_add_g1;
   if constexpr (EPI == UD_EPI_QKV) {
     if (n0 >= p.vsplit) {
-      gemm_body<C, EPI, AMODE, false, NST>(p, smem, m0, n0, A, W, bias, out, out2, w2, b2, post_add);
+      gemm_body<C, EPI, AMODE, false, NST, false>(p, smem, m0, n0, A, W, bias, out, out2, w2, b2, post_add);
       return;
     }
   }
-  gemm_body<C, EPI, AMODE, true, NST>(p, smem, m0, n0, A, W, bias, out, out2, w2, b2, post_add);
+  gemm_body<C, EPI, AMODE, true, NST, false>(p, smem, m0, n0, A, W, bias, out, out2, w2, b2, post_add);
 }
 
 // ================================================================================================================
@@ -1234,8 +1279,25 @@ int launch(const UdGemm& d, hipStream_t s) {
     // other's stalls, leaves the CU idle through every DMA / LDS round trip -> 4-stage ring, software-pipelined over K-tiles
     // (gemm_body, NST = 4).  tile_hint 5 keeps the plain kernel, 6 forces the ring.
     const int nkt = d.K >> 6;
-    if (d.groups <= 1 && nkt >= 4 && d.tile_hint != 5 && ((tiles_m * tiles_n <= 256 && nkt >= 8) || d.tile_hint == 6) && !(ud_debug_flags_host() & 16)) {
+    if (d.groups <= 1 && nkt >= 4 && d.tile_hint != 5 && ((tiles_m * tiles_n <= 256 && nkt >= 8) || d.tile_hint >= 6) && !(ud_debug_flags_host() & 16)) {
       const int lds4 = 4 * C::STAGE_BYTES;
+      if constexpr (EPI == UD_EPI_F16 || EPI == UD_EPI_F32) {
+        // two-way K split across CUs (see UdGemm.splitk_ws): twice the workgroups, i.e. twice the DMA bytes in flight
+        if (d.splitk_ws && d.splitk_cnt && tiles_m * tiles_n <= 128 && (nkt & 1) == 0 && (nkt >= 16 || (d.tile_hint == 7 && nkt >= 8)) &&
+            d.tile_hint != 6 && !(ud_debug_flags_host() & 32)) {
+          static bool attrs_set = false;
+          if (!attrs_set) {
+            if (hipFuncSetAttribute((const void*)gemm_kernel<C, EPI, AMODE, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4) != hipSuccess) {
+              ud_set_error("ud_gemm_f16: cannot reserve the 4-stage LDS ring");
+              return UD_ERR_LAUNCH;
+            }
+            attrs_set = true;
+          }
+          hipLaunchKernelGGL((gemm_kernel<C, EPI, AMODE, 4, true>), dim3(2 * tiles_m * tiles_n), dim3(256), lds4, s, d);
+          UD_CHECK_LAUNCH("ud_gemm_f16 (4-stage ring, K split) launch");
+          return UD_OK;
+        }
+      }
       static bool attr4_set = false;
       if (!attr4_set) {
         if (hipFuncSetAttribute((const void*)gemm_kernel<C, EPI, AMODE, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4) != hipSuccess) {

@@ -58,7 +58,7 @@ __device__ __forceinline__ float ud_wave_sum(float v) {
 }
 
 void ud_set_error(const char* msg);
-int ud_debug_flags_host();   // bisect switches (api.cpp): bit0 attention: no deferred max; bit1 GELU via erff; bit2 no LDS-staged stores; bit3 128x128 tiles only; bit4 plain 128x128 kernel at low tile counts (no 4-stage ring)
+int ud_debug_flags_host();   // bisect switches (api.cpp): bit0 attention: no deferred max; bit1 GELU via erff; bit2 no LDS-staged stores; bit3 128x128 tiles only; bit4 plain 128x128 kernel at low tile counts (no 4-stage ring); bit5 no K split across CUs
 #define UD_CHECK_LAUNCH(name)                          \
   do {                                                 \
     hipError_t e_ = hipGetLastError();                 \

@@ -59,6 +59,7 @@ class Program:
             raise MemoryError("ud_program_create")
         self.keep = []          # keep tensors referenced by raw pointers alive
         self.meta = []          # per op: (kernel class, tag, algorithmic flops, algorithmic bytes) for bench / profiling
+        self._splitk = None     # scratch of the two-way K split (UdGemm.splitk_ws / splitk_cnt), one per program = per stream
 
     def __del__(self):
         try:
@@ -79,6 +80,14 @@ class Program:
         g = max(1, kw.get("groups", 0))
         n = kw["N"]
         tag, flops = kw.pop("tag", None), kw.pop("flops", 2.0 * kw["M"] * n * kw["K"] * g)
+        tiles = -(-kw["M"] // 128) * -(-n // 128)
+        if (g == 1 and kw.get("amode", 0) == UD_A_DENSE and kw.get("epi", 0) in (UD_EPI_F16, UD_EPI_F32) and tiles <= 128
+                and kw["K"] >= 1024 and kw["K"] % 128 == 0 and "splitk_ws" not in kw):
+            if self._splitk is None:           # small problems (small batches): see UdGemm.splitk_ws in include/unidepth_hip.h
+                dev = kw["A"].device
+                self._splitk = (torch.empty(256 * 16384, dtype=torch.float32, device=dev), torch.zeros(128, dtype=torch.int32, device=dev))
+                self.keep += list(self._splitk)
+            kw["splitk_ws"], kw["splitk_cnt"] = self._splitk
         d = mk(UdGemm, **kw)
         pick, epi, amode = lib.ud_gemm_pick(C.byref(d)), kw.get("epi", 0), kw.get("amode", 0)
         if pick <= 2:       # names as rocprofv3 prints them (template arguments), so profiles and bench lines can be joined
