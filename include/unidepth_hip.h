@@ -88,7 +88,8 @@ typedef struct UdGemm {
 } UdGemm;
 
 int ud_gemm_f16(const UdGemm* desc, void* stream);
-/* kernel the call above would pick (profiling labels): 0/1/2 = 128-row tiles with BN 128/64/32, 3 = 192x256, 4 = 256x256, 5 = halo-tile conv */
+/* kernel the call above would pick (profiling labels): 0/1/2 = 128-row tiles with BN 128/64/32, 3 = 192x256, 4 = 256x256, 5 = halo-tile conv,
+ * 6 / 7 = 128x128 tiles, 4-stage pipelined ring without / with the two-way K split */
 int ud_gemm_pick(const UdGemm* desc);
 
 /* ---- LayerNorm (statistics only; the affine is folded into the consumer's weights at load time) ----

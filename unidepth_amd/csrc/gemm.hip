@@ -1270,21 +1270,31 @@ inline bool conv_tile_ok(const UdGemm& d) {
          (d.epi == UD_EPI_HEAD || (d.epi == UD_EPI_F16 && d.act != UD_ACT_GELU && d.rows_in == 0 && d.add == nullptr && (d.ldc & 3) == 0));
 }
 
+// Variant of the dense 128 x 128 kernel (N > 64; F16 / F32 / QKV epilogues): 0 = plain 2-stage ring, 1 = 4-stage pipelined ring,
+// 2 = ring + two-way K split across CUs.  With at most one workgroup per CU anyway (tile count <= CU count: small batches) the
+// plain kernel, tuned for two co-resident workgroups hiding each other's stalls, leaves the CU idle through every DMA / LDS round
+// trip.  tile_hint 5 keeps the plain kernel, 6 forces the ring without the split, 7 the split (when the scratch is there).
+inline int ring_variant(const UdGemm& d) {
+  const int tiles = ((d.N + 127) / 128) * ((d.M + 127) / 128);
+  const int nkt = d.K >> 6;
+  if (d.amode != UD_A_DENSE || d.N <= 64 || (d.epi != UD_EPI_F16 && d.epi != UD_EPI_F32 && d.epi != UD_EPI_QKV)) return 0;
+  if (!(d.groups <= 1 && nkt >= 4 && d.tile_hint != 5 && ((tiles <= 256 && nkt >= 8) || d.tile_hint >= 6) && !(ud_debug_flags_host() & 16))) return 0;
+  if (d.epi != UD_EPI_QKV && d.splitk_ws && d.splitk_cnt && tiles <= 128 && (nkt & 1) == 0 && (nkt >= 16 || (d.tile_hint == 7 && nkt >= 8)) &&
+      d.tile_hint != 6 && !(ud_debug_flags_host() & 32))
+    return 2;
+  return 1;
+}
+
 template <class C, int EPI, int AMODE>
 int launch(const UdGemm& d, hipStream_t s) {
   const int tiles_n = (d.N + C::BN - 1) / C::BN;
   const int tiles_m = (d.M + C::BM - 1) / C::BM;
   if constexpr (C::BN == 128 && AMODE == UD_A_DENSE && (EPI == UD_EPI_F16 || EPI == UD_EPI_F32 || EPI == UD_EPI_QKV)) {
-    // At most one workgroup per CU anyway (small batches): the plain kernel, tuned for two co-resident workgroups hiding each
-    // other's stalls, leaves the CU idle through every DMA / LDS round trip -> 4-stage ring, software-pipelined over K-tiles
-    // (gemm_body, NST = 4).  tile_hint 5 keeps the plain kernel, 6 forces the ring.
-    const int nkt = d.K >> 6;
-    if (d.groups <= 1 && nkt >= 4 && d.tile_hint != 5 && ((tiles_m * tiles_n <= 256 && nkt >= 8) || d.tile_hint >= 6) && !(ud_debug_flags_host() & 16)) {
+    const int variant = ring_variant(d);
+    if (variant) {
       const int lds4 = 4 * C::STAGE_BYTES;
       if constexpr (EPI == UD_EPI_F16 || EPI == UD_EPI_F32) {
-        // two-way K split across CUs (see UdGemm.splitk_ws): twice the workgroups, i.e. twice the DMA bytes in flight
-        if (d.splitk_ws && d.splitk_cnt && tiles_m * tiles_n <= 128 && (nkt & 1) == 0 && (nkt >= 16 || (d.tile_hint == 7 && nkt >= 8)) &&
-            d.tile_hint != 6 && !(ud_debug_flags_host() & 32)) {
+        if (variant == 2) {              // two-way K split across CUs: twice the workgroups, i.e. twice the DMA bytes in flight
           static bool attrs_set = false;
           if (!attrs_set) {
             if (hipFuncSetAttribute((const void*)gemm_kernel<C, EPI, AMODE, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4) != hipSuccess) {
@@ -1398,13 +1408,17 @@ extern "C" int ud_trace_set(void* buf) {
 #endif
 
 // Which kernel ud_gemm_f16 would launch for this descriptor (for profiling labels): 0/1/2 = 128-row kernels with BN 128/64/32,
-// 3 = 192x256 tiles, 4 = 256x256 tiles, 5 = halo-tile conv.
+// 3 = 192x256 tiles, 4 = 256x256 tiles, 5 = halo-tile conv, 6 / 7 = 128x128 pipelined ring without / with the K split.
 extern "C" int ud_gemm_pick(const UdGemm* desc) {
   const UdGemm& d = *desc;
   if (conv_tile_ok(d) && (d.epi == UD_EPI_HEAD || d.epi == UD_EPI_F16)) return 5;
   if (d.epi != UD_EPI_HEAD) {
     const int bt = pick_tiles(d);
     if (bt) return bt;
+  }
+  if (d.N > 64 && d.epi != UD_EPI_D2S) {
+    const int v = ring_variant(d);
+    if (v) return 5 + v;
   }
   return d.N > 64 ? 0 : (d.N > 32 ? 1 : 2);
 }
