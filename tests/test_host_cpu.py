@@ -141,6 +141,19 @@ def test_camera_bookkeeping_matches_oracle():
     assert torch.allclose(r.norm(dim=1), torch.ones(1, 304, 760), atol=1e-6) and r[0, 2, 152, 380] > 0.99
 
 
+def test_hubconf_at_repo_root():
+    """torch.hub layout: hubconf.py at the repo root exposes UniDepth and its dependency list (reference hubconf.py:1,25)."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hubconf.py")
+    spec = importlib.util.spec_from_file_location("ud_hubconf", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert callable(mod.UniDepth) and "torch" in mod.dependencies
+    m = mod.UniDepth(version="v2", backbone="vitb14", pretrained=False)
+    assert type(m).__name__ == "UniDepthV2"
+
+
 def test_hub_entry_point_surface():
     """hubconf.UniDepth(version, backbone, pretrained) signature (reference hubconf.py:25-41): V2 configs resolve, V1 fails loudly."""
     import pytest
