@@ -132,3 +132,37 @@ def test_plan_mixed_balance_and_single_process():
         ref = _FakeShapeModel().infer(im[None])
         assert torch.equal(o["depth"], ref["depth"][0])
     assert sorted(model.calls) == sorted([(4, 3, 6, 5), (2, 3, 4, 7), (1, 3, 8, 8)])
+
+
+def test_infer_mixed_camera_objects_run_alone():
+    """K tensors are batched per shape bucket; an image with a camera OBJECT gets its own call (one camera per infer() call for
+    the object models, as in the reference) and receives that object."""
+    from unidepth_amd.dist import infer_mixed, plan_mixed
+
+    class _Cam:                                       # stands in for a unidepth_amd.cameras / reference camera object
+        pass
+
+    class _Model(_FakeShapeModel):
+        def __init__(self):
+            super().__init__()
+            self.cams = []
+
+        def infer(self, rgb, camera=None):
+            self.cams.append(camera)
+            return super().infer(rgb)
+
+    imgs = _mixed_images()                            # shapes: (6,5) x4, (4,7) x2, (8,8) x1
+    K = torch.eye(3)
+    obj = _Cam()
+    cams = [K, None, K, obj, None, None, K]           # image 3 has an object; image 1 (no camera) keeps bucket (4,7) camera-free
+    model = _Model()
+    out = infer_mixed(model, imgs, cameras=cams, keys=("depth",), max_batch=8)
+    assert len(out) == len(imgs) and all(o["depth"].shape[-2:] == im.shape[-2:] for o, im in zip(out, imgs))
+    assert sum(1 for c in model.cams if c is obj) == 1
+    solo_calls = [c for c, sh in zip(model.cams, model.calls) if c is obj]
+    assert len(solo_calls) == 1 and (1, 3, 6, 5) in model.calls
+    # bucket (6,5) minus the solo image = images 0, 2, 6: all carry K -> stacked [3,3,3]; bucket (4,7) has no cameras
+    stacked = [c for c in model.cams if isinstance(c, torch.Tensor)]
+    assert len(stacked) == 1 and stacked[0].shape == (3, 3, 3)
+    micro, owner = plan_mixed([(6, 5)] * 3, [1.0] * 3, 2, 8, solo=[1])
+    assert sorted(map(tuple, (idx for _, idx in micro))) == [(0, 2), (1,)] or sorted(len(idx) for _, idx in micro) == [1, 1, 1]

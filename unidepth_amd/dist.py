@@ -92,13 +92,16 @@ def image_cost(model, H: int, W: int) -> float:
     return enc + dec
 
 
-def plan_mixed(shapes: List[Tuple[int, int]], costs: List[float], world: int, max_batch: int = 8):
+def plan_mixed(shapes: List[Tuple[int, int]], costs: List[float], world: int, max_batch: int = 8, solo: Iterable[int] = ()):
     """Deterministic plan (identical on every rank): bucket image indices by (H, W), cut buckets into micro-batches of at most
     `max_batch` images, assign micro-batches to ranks longest-first onto the least-loaded rank (ties -> lowest rank).
-    Returns (micro_batches, owner): micro_batches[j] = (shape, [image indices]); owner[j] = rank."""
+    Images listed in `solo` (those with a camera OBJECT: one camera per infer() call, as in the reference) get a micro-batch
+    of their own.  Returns (micro_batches, owner): micro_batches[j] = (shape, [image indices]); owner[j] = rank."""
+    solo = set(solo)
     buckets: Dict[Tuple[int, int], List[int]] = {}
     for i, s in enumerate(shapes):
-        buckets.setdefault(tuple(s), []).append(i)
+        if i not in solo:
+            buckets.setdefault(tuple(s), []).append(i)
     micro = []
     # micro-batch granularity: about three micro-batches per rank (a third of the per-rank cost share each) keeps the greedy
     # assignment within a few % of even, while micro-batches stay as large as that allows (larger batches run faster per image)
@@ -109,6 +112,7 @@ def plan_mixed(shapes: List[Tuple[int, int]], costs: List[float], world: int, ma
         nmb = -(-len(idx) // cap)
         per = -(-len(idx) // nmb)                      # even micro-batches rather than full ones + a small remainder
         micro += [(s, idx[k:k + per]) for k in range(0, len(idx), per)]
+    micro += [(tuple(shapes[i]), [i]) for i in sorted(solo)]
     order = sorted(range(len(micro)), key=lambda j: (-sum(costs[i] for i in micro[j][1]), j))
     load = [0.0] * world
     owner = [0] * len(micro)
@@ -122,8 +126,9 @@ def plan_mixed(shapes: List[Tuple[int, int]], costs: List[float], world: int, ma
 def infer_mixed(model, images: List[torch.Tensor], cameras: Optional[List[Optional[torch.Tensor]]] = None,
                 keys: Iterable[str] = ("depth", "confidence", "intrinsics"), max_batch: int = 8, group=None, inflight: int = 2,
                 **kw) -> List[Dict[str, torch.Tensor]]:
-    """infer() over a list of [3,H,W] images of arbitrary, mixed shapes.  Single process (no initialised process group): the
-    micro-batches run back to back on this GPU.  Under torch.distributed every rank passes the SAME list, runs the micro-batches
+    """infer() over a list of [3,H,W] images of arbitrary, mixed shapes; `cameras[i]` is None, a [3,3] K tensor (batched with
+    the other K tensors of its shape bucket) or a camera object (unidepth_amd.cameras / the reference's classes: that image then
+    runs as its own call).  Single process (no initialised process group): the micro-batches run back to back on this GPU.  Under torch.distributed every rank passes the SAME list, runs the micro-batches
     the plan gives it and all ranks return the complete, ordered result list; one all-gather per shape bucket (the outputs of a
     bucket have one shape, so all requested keys travel packed in one message)."""
     keys = list(keys)
@@ -131,7 +136,8 @@ def infer_mixed(model, images: List[torch.Tensor], cameras: Optional[List[Option
     world, rank = (dist.get_world_size(group), dist.get_rank(group)) if distributed else (1, 0)
     shapes = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
     costs = [image_cost(model, h, w) for h, w in shapes]
-    micro, owner = plan_mixed(shapes, costs, world, max_batch)
+    solo = [i for i, c in enumerate(cameras or []) if c is not None and not isinstance(c, torch.Tensor)]
+    micro, owner = plan_mixed(shapes, costs, world, max_batch, solo)
     results: List[Optional[Dict[str, torch.Tensor]]] = [None] * len(images)
     mine: Dict[Tuple[int, int], List[Tuple[List[int], Dict[str, torch.Tensor]]]] = {}
     # consecutive micro-batches of a rank overlap on separate HIP streams (pipeline.py) when the engine supports buffer slots
@@ -145,7 +151,9 @@ def infer_mixed(model, images: List[torch.Tensor], cameras: Optional[List[Option
             continue
         rgb = torch.stack([images[i] for i in idx])
         cam = None
-        if cameras is not None and all(cameras[i] is not None for i in idx):
+        if cameras is not None and len(idx) == 1 and idx[0] in solo:
+            cam = cameras[idx[0]]
+        elif cameras is not None and all(isinstance(cameras[i], torch.Tensor) for i in idx):
             cam = torch.stack([cameras[i] for i in idx])
         if pipe is not None:
             out = pipe.submit(rgb, cam, **kw)
