@@ -1,29 +1,40 @@
 #!/usr/bin/env python
 """bench.py -- throughput of the UniDepthV2 infer() hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run, one rank/GPU)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+`--gpus N` with N > 1 and no torch.distributed environment: bench.py re-launches itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one rank per GPU, RCCL); when the
+driver already launched it that way (RANK / WORLD_SIZE set) it checks that the world size equals N.  The JSON line's
+`n_gpus` is `dist.get_world_size()` -- never the flag.
 
 Workload (BASELINE.json metric / configs[1]): UniDepthV2 ViT-L/14, 518x518, batch 8 per GPU, synthetic uint8 RGB already
 resident in HBM, seeded random-init ("sensitised") weights of the exact architecture; a step = one full infer()
 (pre-process -> 24-block encoder -> decoder -> all 7 outputs on device).  With N GPUs every rank runs its own batch
 (weak scaling, images are independent) and the per-step outputs `depth`, `confidence`, `intrinsics` are all-gathered
-over RCCL; value = N * 8 images * K / max-over-ranks wall time.
+over RCCL (one packed collective per step, issued on the step's own HIP stream so it overlaps the next step's compute);
+value = N * 8 images * K / max-over-ranks wall time.
 
 One JSON line on rank 0 with the driver contract fields plus
+  value_one_call / p50_latency_ms -- the same workload with ONE infer() in flight (the headline `value` keeps `--inflight`
+                  (default 2) independent calls in flight per GPU: throughput mode for a stream of requests);
   roofline     -- the dominant kernel class of the step (an MFMA GEMM instantiation, named as rocprofv3 prints it): algorithmic
                   FLOP per launch / average launch duration measured live with HIP events on the launch stream, against the
-                  2.5 PFLOP/s dense fp16 peak; `traffic` = HBM bytes per launch from the committed PMC passes (profiles/);
-  cpu_baseline -- the CPU oracle (fp32 restatement of the reference, oracle/restate.py) timed on this box's host cores on
-                  a bounded sample (one bs=8 pass of the same workload, ~15 s), rank 0 / N=1 only.
+                  2.5 PFLOP/s dense fp16 peak; algorithmic bytes per launch (operands + outputs once); `traffic` = HBM bytes per
+                  launch from the committed PMC passes (profiles/);
+  rccl         -- N > 1: ranks seen, bytes gathered per rank and step, the collective's own duration, and how much of it the
+                  timed region hides behind compute;
+  cpu_baseline -- the CPU oracle (fp32 restatement of the reference, oracle/restate.py) timed on this box's host cores on a
+                  bounded sample (>= 3 timed bs=8 passes of the same workload + 5 passes of BASELINE configs[0]), rank 0 / N=1 only.
 """
 import argparse
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -39,7 +50,7 @@ def flops_per_image(D=1024, depth=24, N=1370, C=512, hw=1369):
     return dict(enc_gemm=enc_gemm, enc_attn=enc_attn, enc=enc_gemm + enc_attn, total=1366.8e9)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -52,14 +63,45 @@ def main():
     ap.add_argument("--gather", default="depth,confidence,intrinsics")
     ap.add_argument("--dump-ops", default="", help="write per-launch timings (tsv) to this file")
     ap.add_argument("--inflight", type=int, default=2, help="infer() calls in flight per GPU during the timed steps (1 = one call at a time)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` outside torch.distributed: become the launcher of N ranks of this very script."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus and not os.environ.get("UD_BENCH_SHARE_GPU"):
+        print(json.dumps({"error": f"--gpus {args.gpus} requested but only {have} GPU(s) visible", "n_gpus": have}))
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("UD_BENCH_BACKEND", "nccl")      # "gloo": functional check of the N > 1 path on a box with one GPU
     if os.environ.get("UD_BENCH_SHARE_GPU"):                 # (all ranks on cuda:0; never a measurement)
         local_rank = 0
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -68,6 +110,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))      # "nccl" is RCCL on ROCm
         else:
             dist.init_process_group(backend)
+        world = dist.get_world_size()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s)")
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
@@ -97,10 +142,10 @@ def main():
             dist.all_gather(list(gathered.chunk(world)), packed)
         return gathered
 
-    def step():
+    def step(with_gather=True):
         """One full infer() of the batch; up to --inflight steps overlap on separate HIP streams (independent batches of a
         stream of requests).  The all-gather of a step is issued on that step's stream, right behind its outputs."""
-        return pipe.submit(rgb, post=gather if world > 1 else None)
+        return pipe.submit(rgb, post=gather if (world > 1 and with_gather) else None)
 
     def step_single():
         out = model.infer(rgb)
@@ -108,22 +153,30 @@ def main():
             gather(out)
         return out
 
+    def timed(n, with_gather=True):
+        pipe.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step(with_gather)
+        pipe.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = tt.item()
+        return dt
+
     for _ in range(args.warmup):
         step()
-    pipe.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    pipe.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed(args.steps)                      # THE timed region: exactly K steps, barrier + synchronize on both sides, max over ranks
     # latency of ONE call with nothing else in flight (outside the timed region)
     lat = []
     for _ in range(min(args.steps, 20)):
@@ -131,39 +184,78 @@ def main():
         step_single()
         torch.cuda.synchronize()
         lat.append((time.perf_counter() - ts) * 1e3)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = tt.item()
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
+    p50 = statistics.median(lat)
 
     result = {
         "metric": "images/sec (whole node) + p50 latency, ViT-L/14 518x518 bs=8",
         "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "p50_latency_ms": round(statistics.median(lat), 4),
+        "ms_per_step": round(ms_per_step, 4), "p50_latency_ms": round(p50, 4),
+        "value_one_call": round(world * B / (p50 * 1e-3), 3),
         "inflight": max(1, args.inflight),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
         "data": "synthetic uint8 RGB (seeded) resident in HBM; seeded random-init weights of the named architecture",
         "config": {"workload": f"UniDepthV2 {args.arch} infer(), {H}x{W}, bs={B} per GPU, all 7 outputs on device; "
-                               f"{max(1, args.inflight)} independent infer() calls in flight per GPU (HIP streams), p50_latency_ms = one call alone",
+                               f"value = {max(1, args.inflight)} independent infer() calls in flight per GPU (HIP streams); "
+                               f"value_one_call / p50_latency_ms = one call at a time",
                    "global_batch": world * B, "parallelism": f"dp{world}" + (f" + RCCL all-gather({','.join(gather_keys)})" if world > 1 else "")},
     }
 
+    if world > 1:
+        result["rccl"] = rccl_report(torch, dist, model, rgb, gather, timed, args, world, rank, dev, backend, B, ms_per_step)
     if rank == 0:
         fl = flops_per_image()
         result["model_tflops_per_s"] = round(value * fl["total"] / 1e12 / world, 2)
         if not args.no_kernel_timing:
-            result.update(kernel_timing(model, fl, B, args.dump_ops))
+            result.update(kernel_timing(torch, model, fl, B, args.dump_ops))
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(cfg, sd, H, W)
+            result["cpu_baseline"] = cpu_baseline(torch, cfg, sd, H, W)
         print(json.dumps(result))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def kernel_timing(model, fl, B, dump=""):
+def rccl_report(torch, dist, model, rgb, gather, timed, args, world, rank, dev, backend, B, ms_with):
+    """Evidence that the exchange step ran over RCCL on `world` ranks, what it moved, what it cost alone and inside the pipeline."""
+    ranks = torch.empty(world, dtype=torch.int64, device=dev)
+    mine = torch.tensor([rank], dtype=torch.int64, device=dev)
+    if backend == "nccl":
+        dist.all_gather_into_tensor(ranks, mine)
+    else:
+        dist.all_gather(list(ranks.chunk(world)), mine)
+    out = model.infer(rgb)
+    torch.cuda.synchronize()
+    g = gather(out)
+    torch.cuda.synchronize()
+    ok = True
+    for r in range(world):                                   # every rank's block of the gathered outputs must be finite and non-zero
+        blk = g[r * B:(r + 1) * B]
+        ok = ok and bool(torch.isfinite(blk).all()) and bool((blk.abs().sum(dim=1) > 0).all())
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    dist.barrier()
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(reps):
+        gather(out)
+    ev1.record()
+    torch.cuda.synchronize()
+    gather_ms = ev0.elapsed_time(ev1) / reps
+    n2 = max(4, args.steps // 2)
+    ms_without = timed(n2, with_gather=False) / n2 * 1e3
+    exposed = max(0.0, ms_with - ms_without)
+    per_rank = int(g.shape[1]) * B * g.element_size()
+    return {"backend": "rccl (torch.distributed 'nccl')" if backend == "nccl" else backend, "world_size": world,
+            "ranks_seen": [int(x) for x in ranks.tolist()], "all_blocks_valid": ok,
+            "gathered_bytes_per_rank_per_step": per_rank, "gather_alone_ms": round(gather_ms, 4),
+            "gather_alone_GBps_per_rank_in": round(per_rank * (world - 1) / (gather_ms * 1e-3) / 1e9, 2),
+            "ms_per_step_without_gather": round(ms_without, 4), "exposed_gather_ms_per_step": round(exposed, 4),
+            "overlap_frac": round(1.0 - min(1.0, exposed / gather_ms), 3) if gather_ms > 0 else None}
+
+
+def kernel_timing(torch, model, fl, B, dump=""):
     """Per-launch durations with HIP events on the launch stream (torch's current stream is the one every kernel of the
     program is enqueued on); aggregated per kernel class.  Returns the roofline object for the dominant kernel."""
     plan = next(reversed(model._plans.values()))
@@ -187,13 +279,13 @@ def kernel_timing(model, fl, B, dump=""):
             d["launches"] += 1
             if tag.startswith("enc."):
                 e = tot.setdefault(tag, {"ms": 0.0, "flops": 0.0, "launches": 0, "bytes": 0.0})
-                e["ms"] += evs[i].elapsed_time(evs[i + 1]); e["flops"] += flops; e["launches"] += 1
+                e["ms"] += evs[i].elapsed_time(evs[i + 1]); e["flops"] += flops; e["launches"] += 1; e["bytes"] += nbytes
     if dump:
         with open(dump, "w") as f:
             for i in range(n):
                 cls, tag, flops, nbytes = P.meta[i]
                 us = evs[i].elapsed_time(evs[i + 1]) * 1e3
-                f.write(f"{i}\t{cls}\t{tag}\t{us:.1f}\t{flops / us / 1e6 if flops else 0:.1f}\n")
+                f.write(f"{i}\t{cls}\t{tag}\t{us:.1f}\t{flops / us / 1e6 if flops else 0:.1f}\t{nbytes / us / 1e3 if nbytes else 0:.1f}\n")
     classes = {k: v for k, v in tot.items() if not k.startswith("enc.")}
     dom = max(classes, key=lambda k: classes[k]["ms"])
     d = classes[dom]
@@ -205,20 +297,21 @@ def kernel_timing(model, fl, B, dump=""):
                      "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
                  for k, v in sorted(tot.items(), key=lambda kv: -kv[1]["ms"])}
     # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the json)
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    if os.path.exists(tpath):
-        short = dom.replace("Cfg<", "(anonymous namespace)::Cfg<")
-        for name, rec in json.load(open(tpath))["kernels"].items():
-            if short in name:
-                traffic = rec["hbm_total_bytes"]
+    traffic, traffic_src = None, None
+    for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", name)
+        if traffic is None and os.path.exists(tpath):
+            short = dom.replace("Cfg<", "(anonymous namespace)::Cfg<")
+            for kname, rec in json.load(open(tpath))["kernels"].items():
+                if short in kname:
+                    traffic, traffic_src = rec["hbm_total_bytes"], "profiles/" + name
     return {
         "roofline": {"bound": "mfma", "kernel": dom + " (v_mfma_f32_16x16x32_f16)",
                      "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                     "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "flop_per_launch": round(d["flops"] / d["launches"], 1),
                      "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 3),
-                     "algorithmic_bytes_per_launch": None},
+                     "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"], 1)},
         "roofline_enc_attention_mlp": {"achieved": round(enc_fl / (enc_ms * 1e-3) / 1e12, 2), "peak": MFMA_PEAK_TFLOPS,
                                        "unit": "TFLOP/s", "frac": round(enc_fl / (enc_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
                                        "ms_per_step": round(enc_ms, 4)},
@@ -226,20 +319,64 @@ def kernel_timing(model, fl, B, dump=""):
     }
 
 
-def cpu_baseline(cfg, sd, H, W):
-    """CPU oracle (port of the reference's fp32 CPU path) on this host: bounded sample = one bs=8 pass of the same workload."""
-    from oracle import restate
-    n = min(os.cpu_count() or 1, int(os.environ.get("UD_CPU_BASELINE_THREADS", "32")))   # >32 threads oversubscribes this op mix
+def host_cpu():
+    """CPU model and physical core count of this box (Linux /proc/cpuinfo)."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    return model, (len(cores) or logical), logical
+
+
+def cpu_baseline(torch, cfg, sd, H, W):
+    """CPU oracle (port of the reference's fp32 CPU path, oracle/restate.py) on this host: >= 3 timed bs=8 passes of the bench workload
+     + BASELINE configs[0] (ViT-S/14, 462x616, bs=1; 5 passes).  UD_CPU_BASELINE_REPS / _THREADS override."""
+    from oracle import restate, synth
+    model, phys, logical = host_cpu()
+    cap = int(os.environ.get("UD_CPU_BASELINE_THREADS", "0"))
+    # the op mix (addmm, direct convolutions, SDPA) stops scaling at ~32 threads on these hosts; more threads were measured slower
+    n = cap if cap > 0 else min(phys, 32)
     torch.set_num_threads(n)
+    reps = max(1, int(os.environ.get("UD_CPU_BASELINE_REPS", "3")))
     orc = restate.OracleV2(cfg, sd)
     nimg = 8
     x = torch.randint(0, 256, (nimg, 3, H, W), dtype=torch.uint8, generator=torch.Generator().manual_seed(7))
     orc.infer(x[:1])                                   # warm-up (thread pool, allocator)
-    t0 = time.perf_counter()
-    orc.infer(x)
-    dt = time.perf_counter() - t0
-    return {"value": round(nimg / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/restate.py fp32, {H}x{W}, bs={nimg} (the bench workload), 1 timed pass after a bs=1 warm-up ({dt:.1f} s)"}
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        orc.infer(x)
+        ts.append(time.perf_counter() - t0)
+    p50 = statistics.median(ts)
+    # BASELINE configs[0]: the reference's own CPU-runnable case
+    cfg_s = synth.load_config("vits14")
+    orc_s = restate.OracleV2(cfg_s, synth.make_synthetic_checkpoint(cfg_s, 123))
+    xs = torch.randint(0, 256, (1, 3, 462, 616), dtype=torch.uint8, generator=torch.Generator().manual_seed(1))
+    orc_s.infer(xs)
+    t1 = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        orc_s.infer(xs)
+        t1.append(time.perf_counter() - t0)
+    return {"value": round(nimg / p50, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "p50_s": round(p50, 3), "passes_s": [round(t, 3) for t in ts],
+            "cpu_model": model, "host_physical_cores": phys, "host_logical_cpus": logical,
+            "sample": f"oracle/restate.py fp32, {H}x{W}, bs={nimg} (the bench workload): {reps} timed passes after a bs=1 warm-up, p50",
+            "config0_vits_462x616_bs1": {"value": round(1.0 / statistics.median(t1), 3), "unit": "images/s", "p50_s": round(statistics.median(t1), 4),
+                                         "passes": 5}}
 
 
 if __name__ == "__main__":

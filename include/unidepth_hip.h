@@ -212,8 +212,8 @@ typedef struct UdResizeAC {
 } UdResizeAC;
 int ud_resize_ac_nhwc_f16(const UdResizeAC* desc, void* stream);
 
-/* output assembly (decoder.py:456-462, unidepthv2.py:375-377, :310-339) for the no-resample case and generic
- * fp32 NCHW bilinear(align_corners=False) resize + crop used by _postprocess (unidepthv2.py:80-89). */
+/* output assembly (decoder.py:456-462, unidepthv2.py:375-377, :310-339): fp32 NCHW resize (F.interpolate align_corners=False,
+ * bilinear or bicubic = the two modes the reference's `interpolation_mode` accepts) + crop of _postprocess (unidepthv2.py:80-89). */
 typedef struct UdFinalize {
   const float* radius_net;  /* [B,Hn,Wn] */
   const float* conf_net;    /* [B,Hn,Wn] */
@@ -222,6 +222,7 @@ typedef struct UdFinalize {
   int B, nb_rays, Hn, Wn;
   int Hp, Wp;               /* padded (pre-crop) size the network maps are resized to */
   int pad_l, pad_t, Ho, Wo; /* crop */
+  int mode;                 /* resampling of _postprocess (unidepthv2.py:80-89, `interpolation_mode`): 0 bilinear, 1 bicubic; align_corners=False */
 } UdFinalize;
 int ud_finalize_outputs(const UdFinalize* desc, void* stream);
 

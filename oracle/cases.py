@@ -18,6 +18,8 @@ CASES = {
     "vitb_518x518_b1": dict(arch="vitb14", H=518, W=518, B=1, camera=False, ckpt_seed=124, img_seed=4),
     # BASELINE.json configs[1] at bs=1 (same network shape as the headline bs=8 workload)
     "vitl_518x518_b1": dict(arch="vitl14", H=518, W=518, B=1, camera=False, ckpt_seed=125, img_seed=5),
+    # ViT-L with the resolution_level knob set (unidepthv2.py:252-260): level 3 -> pixel bounds [320k, 360k] -> 644x966 runs at 490x728
+    "vitl_644x966_b1_lvl3": dict(arch="vitl14", H=644, W=966, B=1, camera=False, ckpt_seed=125, img_seed=12, resolution_level=3),
     # non-pinhole GT cameras: EUCM fisheye-like, and an equirectangular strip wide enough to be aspect-padded
     "vits_300x400_eucm": dict(arch="vits14", H=300, W=400, B=1, camera=("EUCM", [190.0, 192.0, 203.0, 148.0, 0.62, 1.08]),
                               ckpt_seed=123, img_seed=6),

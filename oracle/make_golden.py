@@ -34,6 +34,8 @@ def main(names=None):
             cam_ref = getattr(refcam, cam[0])(params=cam[1].clone())
         else:
             cam_ref = cam.clone() if cam is not None else None
+        if case.get("resolution_level") is not None:
+            ref.resolution_level = case["resolution_level"]
         with torch.no_grad():
             out = ref.infer(rgb, cam_ref)
         d = cases.digest({k: v.detach() for k, v in out.items()})

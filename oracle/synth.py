@@ -168,3 +168,36 @@ def make_synthetic_checkpoint(config: dict, seed: int = 123) -> "OrderedDict[str
             raise KeyError(k)
         sd[k] = t.contiguous()
     return sd
+
+
+def make_outlier_checkpoint(config: dict, seed: int = 321) -> "OrderedDict[str, torch.Tensor]":
+    """Sensitised checkpoint with the activation statistics that real DINOv2 checkpoints have and randn * fan_in^-1/2 ones lack
+    (no real checkpoint is reachable offline): (a) two "massive activation" channels that sit at about +-300 in EVERY token of the
+    residual stream from block depth/6 on (fc2 bias), (b) two heavy-tailed channels whose per-token values reach a few hundred
+    from block depth/3 on (fc2 rows x 40), (c) one block whose attention logits are 16 x larger (q and k rows x 4: near one-hot
+    softmax rows, scores in the hundreds).  Stresses the engine's fp16 storage of LayerNorm outputs, q/k, attention outputs and
+    GELU(fc1), its fp32 softmax statistics (deferred max rescale) and the fp32 residual stream."""
+    a = arch_of(config)
+    D, depth = a["D"], a["depth"]
+    sd = make_synthetic_checkpoint(config, seed)
+    pe = "pixel_encoder."
+    b1, b2, b3 = max(1, depth // 6), max(2, depth // 3), max(3, depth // 2)
+    ch_const, ch_heavy = [7, D // 3 + 1], [D // 2 + 5, D - 9]
+    for j, ch in enumerate(ch_const):
+        sd[f"{pe}blocks.{b1}.mlp.fc2.bias"][ch] += (300.0 if j == 0 else -300.0) / sd[f"{pe}blocks.{b1}.ls2.gamma"][ch]
+    for ch in ch_heavy:
+        sd[f"{pe}blocks.{b2}.mlp.fc2.weight"][ch] *= 40.0
+    qkv_w, qkv_b = sd[f"{pe}blocks.{b3}.attn.qkv.weight"], sd[f"{pe}blocks.{b3}.attn.qkv.bias"]
+    qkv_w[: 2 * D] *= 4.0
+    qkv_b[: 2 * D] *= 4.0
+    return sd
+
+
+def outlier_image(B: int, H: int, W: int, seed: int = 5) -> torch.Tensor:
+    """uint8 image with saturated flat regions (0 / 255 blocks) next to noise: flat patches make many identical tokens, i.e. tied
+    attention scores and zero-variance neighbourhoods for the convolutions."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randint(0, 256, (B, 3, H, W), dtype=torch.uint8, generator=g)
+    x[:, :, : H // 3, : W // 2] = 255
+    x[:, :, H // 2:, W // 3: 2 * W // 3] = 0
+    return x

@@ -166,3 +166,55 @@ def test_hub_entry_point_surface():
         unidepth_amd.UniDepth(version="v1", backbone="cnvnxtl", pretrained=False)
     with pytest.raises(NotImplementedError):
         unidepth_amd.UniDepthV1({})
+
+
+def test_plan_cache_is_an_lru_and_state_resets(monkeypatch):
+    """The per-(batch, shape, camera, slot) plan cache is bounded and load_state_dict / to() drop every derived cache."""
+    import collections
+    from unidepth_amd.unidepthv2 import UniDepthV2
+    from oracle import synth
+    cfg = synth.load_config("vits14")
+    m = UniDepthV2(cfg)
+    m.resolution_level = 0
+    m.max_plans = 3
+    import unidepth_amd.unidepthv2 as U
+    made = []
+
+    class _P:
+        def __init__(self, model, B, H, W, *a):
+            made.append((B, H, W))
+    monkeypatch.setattr(U, "_Plan", _P)
+    monkeypatch.setattr(U.torch.cuda, "device", lambda d: __import__("contextlib").nullcontext())
+    for hw in [(10, 10), (20, 20), (30, 30), (10, 10), (40, 40), (20, 20)]:
+        m._plan(1, hw[0], hw[1], 0, True, True)
+    assert isinstance(m._plans, collections.OrderedDict) and len(m._plans) == 3
+    # (10,10) was refreshed before (40,40) evicted the oldest -> (20,20) had to be rebuilt, (10,10) not
+    assert made == [(1, 10, 10), (1, 20, 20), (1, 30, 30), (1, 40, 40), (1, 20, 20)]
+    m._pos_cache[(3, 3)] = torch.zeros(1)
+    m.load_state_dict({"module.x": torch.zeros(1)})
+    assert len(m._plans) == 0 and len(m._pos_cache) == 0
+    m.clear_plans()
+
+
+def test_arch_of_rejects_unsupported_encoder_settings():
+    import copy
+    from unidepth_amd.weights import arch_of
+    from oracle import synth
+    cfg = synth.load_config("vits14")
+    arch_of(cfg)
+    bad = copy.deepcopy(cfg)
+    bad["model"]["pixel_encoder"]["use_norm"] = False
+    with pytest.raises(NotImplementedError):
+        arch_of(bad)
+    bad = copy.deepcopy(cfg)
+    bad["model"]["pixel_encoder"]["stacking_fn"] = "sum"
+    with pytest.raises(NotImplementedError):
+        arch_of(bad)
+
+
+def test_product_library_has_no_debug_switches():
+    """ud_set_debug_flags changed product numerics in round 1; it now exists only in instrumented tools builds (-DUD_TOOLS)."""
+    import ctypes
+    from unidepth_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    assert not hasattr(lib, "ud_set_debug_flags")

@@ -67,8 +67,11 @@ def test_infer_matches_oracle_and_golden(engine_cls, name, golden_dir):
     cfg = synth.load_config(case["arch"])
     sd = synth.make_synthetic_checkpoint(cfg, case["ckpt_seed"])
     rgb, cam = cases.case_inputs(case)
-    ref = restate.OracleV2(cfg, sd).infer(rgb, cam)
+    orc = restate.OracleV2(cfg, sd)
     model = engine_cls(cfg).load_state_dict(sd).to("cuda").eval()
+    if case.get("resolution_level") is not None:
+        orc.resolution_level = model.resolution_level = case["resolution_level"]
+    ref = orc.infer(rgb, cam)
     out = model.infer(rgb.cuda(), _engine_camera(cam))
     torch.cuda.synchronize()
     stats = _check(out, ref, name)

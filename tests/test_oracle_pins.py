@@ -19,6 +19,8 @@ def _run_oracle(case):
     cfg = synth.load_config(case["arch"])
     sd = synth.make_synthetic_checkpoint(cfg, case["ckpt_seed"])
     orc = restate.OracleV2(cfg, sd)
+    if case.get("resolution_level") is not None:
+        orc.resolution_level = case["resolution_level"]
     rgb, cam = cases.case_inputs(case)
     return orc.infer(rgb, cam), sd
 

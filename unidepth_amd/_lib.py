@@ -76,7 +76,7 @@ class UdResizeAC(C.Structure):
 class UdFinalize(C.Structure):
     _fields_ = [("radius_net", fp), ("conf_net", fp), ("rays_net", fp), ("confidence", fp), ("radius", fp),
                 ("depth", fp), ("points", fp), ("rays", fp), ("B", i32), ("nb_rays", i32), ("Hn", i32), ("Wn", i32),
-                ("Hp", i32), ("Wp", i32), ("pad_l", i32), ("pad_t", i32), ("Ho", i32), ("Wo", i32)]
+                ("Hp", i32), ("Wp", i32), ("pad_l", i32), ("pad_t", i32), ("Ho", i32), ("Wo", i32), ("mode", i32)]
 
 
 def _load():

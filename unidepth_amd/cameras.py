@@ -118,6 +118,8 @@ def as_camera(obj) -> Camera:
         return obj
     name = type(obj).__name__
     if name == "BatchCamera" and getattr(obj, "cameras", None):
+        if len(obj.cameras) != 1:
+            raise NotImplementedError("BatchCamera with several cameras: pass a [B,3,3] K tensor, or one camera object per infer() call")
         return as_camera(obj.cameras[0])
     cls = _BY_NAME.get(name)
     if cls is None or not hasattr(obj, "params"):

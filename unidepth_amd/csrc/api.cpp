@@ -1,6 +1,6 @@
 // Error plumbing + library info for the C-ABI (include/unidepth_hip.h).
 #include <string.h>
-#include "../../include/unidepth_hip.h"
+#include "ud_common.h"
 
 static thread_local char g_err[256] = "";
 
@@ -28,7 +28,19 @@ extern "C" int ud_struct_size(int which) {
   }
 }
 
-// numerics bisect switches (not part of the product surface; used by tools/ only)
+// numerics bisect / ablation switches: compiled in ONLY for the instrumented tools builds (csrc/build.sh -DUD_TOOLS, used by tools/);
+// the product library neither exports ud_set_debug_flags nor reads any switch (ud_debug_flags_host() is a constant 0 there).
+#ifdef UD_TOOLS
 static int g_debug_flags = 0;
 int ud_debug_flags_host() { return g_debug_flags; }
 extern "C" void ud_set_debug_flags(int f) { g_debug_flags = f; }
+#endif
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is cached per (kernel, device): one process may drive several GPUs.
+bool ud_attr_once(bool (&done)[UD_MAX_DEVICES]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= UD_MAX_DEVICES) return false;   // unknown device: set the attribute again
+  if (done[dev]) return true;
+  done[dev] = true;
+  return false;
+}

@@ -128,13 +128,12 @@ extern "C" int ud_linear_f32(const UdLinearF32* desc, void* stream) {
     ud_set_error("ud_linear_f32: bad argument (K, ldx, ldw % 4 == 0)");
     return UD_ERR_BAD_ARG;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[UD_MAX_DEVICES];
+  if (!ud_attr_once(attr_set)) {
     if (hipFuncSetAttribute((const void*)linear_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LF_STAGE) != hipSuccess) {
       ud_set_error("ud_linear_f32: cannot reserve the LDS staging ring");
       return UD_ERR_LAUNCH;
     }
-    attr_set = true;
   }
   hipLaunchKernelGGL(linear_f32_kernel, dim3((d.N + 7) / 8, (d.M + 31) / 32), dim3(256), 2 * LF_STAGE, (hipStream_t)stream, d);
   UD_CHECK_LAUNCH("ud_linear_f32 launch");

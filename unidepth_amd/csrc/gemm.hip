@@ -1063,13 +1063,12 @@ int launch256(const UdGemm& d, hipStream_t s) {
   constexpr int BM = BigCfg<MH>::BM;
   const int tiles = ((d.N + 255) >> 8) * ((d.M + BM - 1) / BM);
   const int lds = 2 * BigCfg<MH>::STAGE;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[UD_MAX_DEVICES];
+  if (!ud_attr_once(attr_set)) {
     if (hipFuncSetAttribute((const void*)gemm256_kernel<MH, EPI, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       ud_set_error("ud_gemm_f16: cannot reserve the LDS ring of the large-tile kernel");
       return UD_ERR_LAUNCH;
     }
-    attr_set = true;
   }
   hipLaunchKernelGGL((gemm256_kernel<MH, EPI, AMODE>), dim3(tiles < 256 ? tiles : 256), dim3(512), lds, s, d);
   UD_CHECK_LAUNCH("ud_gemm_f16 (large tile) launch");
@@ -1295,26 +1294,24 @@ int launch(const UdGemm& d, hipStream_t s) {
       const int lds4 = 4 * C::STAGE_BYTES;
       if constexpr (EPI == UD_EPI_F16 || EPI == UD_EPI_F32) {
         if (variant == 2) {              // two-way K split across CUs: twice the workgroups, i.e. twice the DMA bytes in flight
-          static bool attrs_set = false;
-          if (!attrs_set) {
+          static bool attrs_set[UD_MAX_DEVICES];
+          if (!ud_attr_once(attrs_set)) {
             if (hipFuncSetAttribute((const void*)gemm_kernel<C, EPI, AMODE, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4) != hipSuccess) {
               ud_set_error("ud_gemm_f16: cannot reserve the 4-stage LDS ring");
               return UD_ERR_LAUNCH;
             }
-            attrs_set = true;
           }
           hipLaunchKernelGGL((gemm_kernel<C, EPI, AMODE, 4, true>), dim3(2 * tiles_m * tiles_n), dim3(256), lds4, s, d);
           UD_CHECK_LAUNCH("ud_gemm_f16 (4-stage ring, K split) launch");
           return UD_OK;
         }
       }
-      static bool attr4_set = false;
-      if (!attr4_set) {
+      static bool attr4_set[UD_MAX_DEVICES];
+      if (!ud_attr_once(attr4_set)) {
         if (hipFuncSetAttribute((const void*)gemm_kernel<C, EPI, AMODE, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4) != hipSuccess) {
           ud_set_error("ud_gemm_f16: cannot reserve the 4-stage LDS ring");
           return UD_ERR_LAUNCH;
         }
-        attr4_set = true;
       }
       hipLaunchKernelGGL((gemm_kernel<C, EPI, AMODE, 4>), dim3(tiles_m * tiles_n), dim3(256), lds4, s, d);
       UD_CHECK_LAUNCH("ud_gemm_f16 (4-stage ring) launch");
@@ -1322,11 +1319,8 @@ int launch(const UdGemm& d, hipStream_t s) {
     }
   }
   const int lds = 2 * C::STAGE_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<C, EPI, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
+  static bool attr_set[UD_MAX_DEVICES];
+  if (!ud_attr_once(attr_set)) (void)hipFuncSetAttribute((const void*)gemm_kernel<C, EPI, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   dim3 grid(tiles_m * tiles_n, 1, d.groups > 0 ? d.groups : 1);
   hipLaunchKernelGGL((gemm_kernel<C, EPI, AMODE>), grid, dim3(256), lds, s, d);
   UD_CHECK_LAUNCH("ud_gemm_f16 launch");

@@ -445,6 +445,19 @@ __global__ __launch_bounds__(256) void resize_ac_kernel(const UdResizeAC p) {
 }
 
 // ------------------------------------------------------------------------------------------------ output assembly
+// MODE 0: bilinear, MODE 1: bicubic (both align_corners=False, as F.interpolate in unidepthv2.py:80-89 computes them: bicubic with
+// A = -0.75, un-clamped source coordinate, border-clamped taps).  points = resample(rays_net * radius_net), rays = resample(rays_net)
+// renormalised, radius = |points|, depth = points_z (unidepthv2.py:318-338).
+__device__ __forceinline__ void ud_cubic_w(float t, float (&w)[4]) {
+  const float A = -0.75f;
+  const float x0 = t + 1.0f, x2 = 1.0f - t, x3 = 2.0f - t;
+  w[0] = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+  w[1] = ((A + 2.0f) * t - (A + 3.0f)) * t * t + 1.0f;
+  w[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+  w[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+}
+
+template <int MODE>
 __global__ __launch_bounds__(256) void finalize_kernel(const UdFinalize p) {
   const long long total = (long long)p.B * p.Ho * p.Wo;
   const float sy = (float)p.Hn / (float)p.Hp, sx = (float)p.Wn / (float)p.Wp;
@@ -453,25 +466,58 @@ __global__ __launch_bounds__(256) void finalize_kernel(const UdFinalize p) {
     const int ox = (int)(idx % p.Wo);
     const int oy = (int)((idx / p.Wo) % p.Ho);
     const int b = (int)(idx / ((long long)p.Wo * p.Ho));
-    float fy = sy * ((float)(oy + p.pad_t) + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
-    float fx = sx * ((float)(ox + p.pad_l) + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
-    const int y0 = (int)fy, x0 = (int)fx;
-    const int y1 = y0 + (y0 < p.Hn - 1), x1 = x0 + (x0 < p.Wn - 1);
-    const float ly = fy - (float)y0, lx = fx - (float)x0;
-    const float w00 = (1.0f - ly) * (1.0f - lx), w01 = (1.0f - ly) * lx, w10 = ly * (1.0f - lx), w11 = ly * lx;
-    const size_t o00 = (size_t)y0 * p.Wn + x0, o01 = (size_t)y0 * p.Wn + x1, o10 = (size_t)y1 * p.Wn + x0, o11 = (size_t)y1 * p.Wn + x1;
     const float* rad = p.radius_net + (size_t)b * HWn;
     const float* cf = p.conf_net + (size_t)b * HWn;
     const float* ry = p.rays_net + (size_t)(p.nb_rays == 1 ? 0 : b) * 3 * HWn;
-    const float r00 = rad[o00], r01 = rad[o01], r10 = rad[o10], r11 = rad[o11];
-    const float conf = w00 * cf[o00] + w01 * cf[o01] + w10 * cf[o10] + w11 * cf[o11];
-    float pt[3], rr[3];
+    float conf = 0.f, pt[3] = {0.f, 0.f, 0.f}, rr[3] = {0.f, 0.f, 0.f};
+    float fy = sy * ((float)(oy + p.pad_t) + 0.5f) - 0.5f;
+    float fx = sx * ((float)(ox + p.pad_l) + 0.5f) - 0.5f;
+    if constexpr (MODE == 0) {
+      fy = fy < 0.f ? 0.f : fy;
+      fx = fx < 0.f ? 0.f : fx;
+      const int y0 = (int)fy, x0 = (int)fx;
+      const int y1 = y0 + (y0 < p.Hn - 1), x1 = x0 + (x0 < p.Wn - 1);
+      const float ly = fy - (float)y0, lx = fx - (float)x0;
+      const float w00 = (1.0f - ly) * (1.0f - lx), w01 = (1.0f - ly) * lx, w10 = ly * (1.0f - lx), w11 = ly * lx;
+      const size_t o00 = (size_t)y0 * p.Wn + x0, o01 = (size_t)y0 * p.Wn + x1, o10 = (size_t)y1 * p.Wn + x0, o11 = (size_t)y1 * p.Wn + x1;
+      const float r00 = rad[o00], r01 = rad[o01], r10 = rad[o10], r11 = rad[o11];
+      conf = w00 * cf[o00] + w01 * cf[o01] + w10 * cf[o10] + w11 * cf[o11];
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      const float* rc = ry + ch * HWn;
-      const float a = rc[o00], bq = rc[o01], cq = rc[o10], d = rc[o11];
-      rr[ch] = w00 * a + w01 * bq + w10 * cq + w11 * d;
-      pt[ch] = w00 * (a * r00) + w01 * (bq * r01) + w10 * (cq * r10) + w11 * (d * r11);
+      for (int ch = 0; ch < 3; ++ch) {
+        const float* rc = ry + ch * HWn;
+        const float a = rc[o00], bq = rc[o01], cq = rc[o10], d = rc[o11];
+        rr[ch] = w00 * a + w01 * bq + w10 * cq + w11 * d;
+        pt[ch] = w00 * (a * r00) + w01 * (bq * r01) + w10 * (cq * r10) + w11 * (d * r11);
+      }
+    } else {
+      const float ffy = floorf(fy), ffx = floorf(fx);
+      float wy[4], wx[4];
+      ud_cubic_w(fy - ffy, wy);
+      ud_cubic_w(fx - ffx, wx);
+      const int iy = (int)ffy, ix = (int)ffx;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int yy = iy - 1 + i;
+        yy = yy < 0 ? 0 : (yy > p.Hn - 1 ? p.Hn - 1 : yy);
+        float cacc = 0.f, pacc[3] = {0.f, 0.f, 0.f}, racc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int xx = ix - 1 + j;
+          xx = xx < 0 ? 0 : (xx > p.Wn - 1 ? p.Wn - 1 : xx);
+          const size_t o = (size_t)yy * p.Wn + xx;
+          const float r = rad[o];
+          cacc += wx[j] * cf[o];
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) {
+            const float a = ry[ch * HWn + o];
+            racc[ch] += wx[j] * a;
+            pacc[ch] += wx[j] * (a * r);
+          }
+        }
+        conf += wy[i] * cacc;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) { rr[ch] += wy[i] * racc[ch]; pt[ch] += wy[i] * pacc[ch]; }
+      }
     }
     const size_t po = (size_t)oy * p.Wo + ox;
     p.confidence[(size_t)b * HWo + po] = conf;
@@ -619,11 +665,13 @@ extern "C" int ud_resize_ac_nhwc_f16(const UdResizeAC* desc, void* stream) {
 extern "C" int ud_finalize_outputs(const UdFinalize* desc, void* stream) {
   const UdFinalize& d = *desc;
   if (!d.radius_net || !d.conf_net || !d.rays_net || !d.confidence || !d.radius || !d.depth || !d.points || !d.rays || d.B <= 0 ||
-      d.Ho + d.pad_t > d.Hp || d.Wo + d.pad_l > d.Wp) {
-    ud_set_error("ud_finalize_outputs: bad argument");
+      d.Ho + d.pad_t > d.Hp || d.Wo + d.pad_l > d.Wp || d.mode < 0 || d.mode > 1) {
+    ud_set_error("ud_finalize_outputs: bad argument (mode: 0 bilinear, 1 bicubic)");
     return UD_ERR_BAD_ARG;
   }
-  hipLaunchKernelGGL(finalize_kernel, dim3(grid_for((long long)d.B * d.Ho * d.Wo, 256, 256 * 32)), dim3(256), 0, (hipStream_t)stream, d);
+  const dim3 grid(grid_for((long long)d.B * d.Ho * d.Wo, 256, 256 * 32));
+  if (d.mode == 1) hipLaunchKernelGGL(finalize_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, d);
+  else hipLaunchKernelGGL(finalize_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, d);
   UD_CHECK_LAUNCH("ud_finalize_outputs launch");
   return UD_OK;
 }

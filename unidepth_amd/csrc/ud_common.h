@@ -58,7 +58,13 @@ __device__ __forceinline__ float ud_wave_sum(float v) {
 }
 
 void ud_set_error(const char* msg);
-int ud_debug_flags_host();   // bisect switches (api.cpp): bit0 attention: no deferred max; bit1 GELU via erff; bit2 no LDS-staged stores; bit3 128x128 tiles only; bit4 plain 128x128 kernel at low tile counts (no 4-stage ring); bit5 no K split across CUs
+#define UD_MAX_DEVICES 64
+bool ud_attr_once(bool (&done)[UD_MAX_DEVICES]);   // true if the calling kernel's launch attribute was already set on the current device
+#ifdef UD_TOOLS
+int ud_debug_flags_host();   // tools builds only -- bisect switches (api.cpp): bit0 attention: no deferred max; bit1 GELU via erff; bit2 no LDS-staged stores; bit3 128x128 tiles only; bit4 plain 128x128 kernel at low tile counts (no 4-stage ring); bit5 no K split across CUs
+#else
+static inline int ud_debug_flags_host() { return 0; }
+#endif
 #define UD_CHECK_LAUNCH(name)                          \
   do {                                                 \
     hipError_t e_ = hipGetLastError();                 \

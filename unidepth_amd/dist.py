@@ -31,6 +31,19 @@ def all_gather_batch(t: torch.Tensor, counts: List[int], group=None) -> torch.Te
     return torch.cat([buf[r * mx: r * mx + counts[r]] for r in range(world)], dim=0)
 
 
+def _camera_count(camera) -> int:
+    """Number of cameras an infer() `camera` argument carries: 0 = none, K tensor [..., 3, 3] -> its batch, camera object -> rows
+    of `.params` (a BatchCamera-like wrapper -> its `.cameras`)."""
+    if camera is None:
+        return 0
+    if isinstance(camera, torch.Tensor):
+        return int(camera.reshape(-1, 3, 3).shape[0])
+    if getattr(camera, "cameras", None):
+        return len(camera.cameras)
+    params = getattr(camera, "params", None)
+    return int(params.shape[0]) if params is not None and getattr(params, "ndim", 1) > 1 else 1
+
+
 def infer_data_parallel(model, rgb: torch.Tensor, camera=None, keys: Optional[Iterable[str]] = ("depth", "confidence", "intrinsics"),
                         group=None, **kw) -> Dict[str, torch.Tensor]:
     """Every rank passes the SAME global batch `rgb` [B,3,H,W] (any device); rank r runs infer() on its contiguous shard and
@@ -50,7 +63,12 @@ def infer_data_parallel(model, rgb: torch.Tensor, camera=None, keys: Optional[It
         out = {k: v[:0] for k, v in model.infer(rgb[:1], camera if cam is camera else camera[:1], **kw).items()}
     keys = list(out.keys()) if keys is None else list(keys)
     res = {}
-    packable = [k for k in keys if not (k == "rays" and out[k].shape[0] == 1 and B > 1 and counts[rank] != 1)]
+    # a single GT camera (one K / one camera object for B > 1 images) yields ONE ray map, identical on every rank: it is not
+    # exchanged.  The decision must be the same on every rank (it changes the packed width and the number of collectives), so it
+    # is taken from the call's arguments, never from the local shard size.
+    n_cam = _camera_count(camera)
+    rays_shared = n_cam == 1 and B > 1
+    packable = [k for k in keys if not (k == "rays" and rays_shared)]
     if len(packable) > 1 and all(out[k].dtype == out[packable[0]].dtype for k in packable):
         # ONE collective for all requested outputs: per-image rows are concatenated, gathered, and split again
         widths = [int(torch.Size(out[k].shape[1:]).numel()) for k in packable]
@@ -63,8 +81,8 @@ def infer_data_parallel(model, rgb: torch.Tensor, camera=None, keys: Optional[It
         keys = [k for k in keys if k not in packable]
     for k in keys:
         t = out[k]
-        if k == "rays" and t.shape[0] == 1 and B > 1 and counts[rank] != 1:
-            res[k] = t                     # single GT camera: identical on every rank, nothing to exchange
+        if k == "rays" and rays_shared:
+            res[k] = t[:1] if t.shape[0] else model.infer(rgb[:1], camera, **kw)["rays"][:1]   # identical on every rank, nothing to exchange
             continue
         res[k] = all_gather_batch(t.contiguous(), counts, group)
     return res
@@ -92,16 +110,20 @@ def image_cost(model, H: int, W: int) -> float:
     return enc + dec
 
 
-def plan_mixed(shapes: List[Tuple[int, int]], costs: List[float], world: int, max_batch: int = 8, solo: Iterable[int] = ()):
+def plan_mixed(shapes: List[Tuple[int, int]], costs: List[float], world: int, max_batch: int = 8, solo: Iterable[int] = (),
+               with_k: Iterable[int] = ()):
     """Deterministic plan (identical on every rank): bucket image indices by (H, W), cut buckets into micro-batches of at most
     `max_batch` images, assign micro-batches to ranks longest-first onto the least-loaded rank (ties -> lowest rank).
     Images listed in `solo` (those with a camera OBJECT: one camera per infer() call, as in the reference) get a micro-batch
-    of their own.  Returns (micro_batches, owner): micro_batches[j] = (shape, [image indices]); owner[j] = rank."""
+    of their own; images listed in `with_k` (a [3,3] K tensor each) are bucketed apart from the camera-less images of the same
+    shape, because one infer() call either takes intrinsics for all of its images or predicts them for all.
+    Returns (micro_batches, owner): micro_batches[j] = (shape, [image indices]); owner[j] = rank."""
     solo = set(solo)
-    buckets: Dict[Tuple[int, int], List[int]] = {}
+    with_k = set(with_k)
+    buckets: Dict[Tuple[int, int, int], List[int]] = {}
     for i, s in enumerate(shapes):
         if i not in solo:
-            buckets.setdefault(tuple(s), []).append(i)
+            buckets.setdefault((int(s[0]), int(s[1]), int(i in with_k)), []).append(i)
     micro = []
     # micro-batch granularity: about three micro-batches per rank (a third of the per-rank cost share each) keeps the greedy
     # assignment within a few % of even, while micro-batches stay as large as that allows (larger batches run faster per image)
@@ -111,7 +133,7 @@ def plan_mixed(shapes: List[Tuple[int, int]], costs: List[float], world: int, ma
         cap = max(1, min(max_batch, int(share / max(costs[idx[0]], 1e-30)))) if world > 1 else max_batch
         nmb = -(-len(idx) // cap)
         per = -(-len(idx) // nmb)                      # even micro-batches rather than full ones + a small remainder
-        micro += [(s, idx[k:k + per]) for k in range(0, len(idx), per)]
+        micro += [((s[0], s[1]), idx[k:k + per]) for k in range(0, len(idx), per)]
     micro += [(tuple(shapes[i]), [i]) for i in sorted(solo)]
     order = sorted(range(len(micro)), key=lambda j: (-sum(costs[i] for i in micro[j][1]), j))
     load = [0.0] * world
@@ -136,8 +158,11 @@ def infer_mixed(model, images: List[torch.Tensor], cameras: Optional[List[Option
     world, rank = (dist.get_world_size(group), dist.get_rank(group)) if distributed else (1, 0)
     shapes = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
     costs = [image_cost(model, h, w) for h, w in shapes]
+    if cameras is not None and len(cameras) != len(images):
+        raise ValueError(f"infer_mixed: {len(cameras)} cameras for {len(images)} images (pass None for images without intrinsics)")
     solo = [i for i, c in enumerate(cameras or []) if c is not None and not isinstance(c, torch.Tensor)]
-    micro, owner = plan_mixed(shapes, costs, world, max_batch, solo)
+    with_k = [i for i, c in enumerate(cameras or []) if isinstance(c, torch.Tensor)]
+    micro, owner = plan_mixed(shapes, costs, world, max_batch, solo, with_k)
     results: List[Optional[Dict[str, torch.Tensor]]] = [None] * len(images)
     mine: Dict[Tuple[int, int], List[Tuple[List[int], Dict[str, torch.Tensor]]]] = {}
     # consecutive micro-batches of a rank overlap on separate HIP streams (pipeline.py) when the engine supports buffer slots
@@ -153,8 +178,9 @@ def infer_mixed(model, images: List[torch.Tensor], cameras: Optional[List[Option
         cam = None
         if cameras is not None and len(idx) == 1 and idx[0] in solo:
             cam = cameras[idx[0]]
-        elif cameras is not None and all(isinstance(cameras[i], torch.Tensor) for i in idx):
-            cam = torch.stack([cameras[i] for i in idx])
+        elif cameras is not None and any(isinstance(cameras[i], torch.Tensor) for i in idx):
+            assert all(isinstance(cameras[i], torch.Tensor) for i in idx), "plan_mixed keeps K and camera-less images apart"
+            cam = torch.stack([cameras[i].reshape(3, 3) for i in idx])
         if pipe is not None:
             out = pipe.submit(rgb, cam, **kw)
             submitted.append(out)

@@ -99,7 +99,16 @@ class Program:
         else:
             cls = "conv_tile_kernel<%d, %d, %s>" % (n // 16, epi, "true" if amode == 2 else "false")
         self.keep.extend(v for v in kw.values() if isinstance(v, torch.Tensor))
-        self.meta.append((cls, tag or cls, float(flops), 0.0))
+        # algorithmic HBM bytes (every operand element once): A (conv modes: the image, not the 9x gathered rows), W, outputs,
+        # + the old fp32 values of an accumulating epilogue
+        m, k = kw["M"], kw["K"]
+        a_bytes = 2.0 * m * (kw["Cin"] if amode else k) * (1 if kw.get("gA", 1) else 1.0 / g)
+        o_bytes = {UD_EPI_F16: 2.0, UD_EPI_QKV: 2.0, UD_EPI_F32: 4.0, UD_EPI_D2S: 4.0, UD_EPI_HEAD: 4.0 / max(n, 1)}[epi] * m * n
+        if epi in (UD_EPI_F32, UD_EPI_D2S):
+            o_bytes = (0.0 if kw.get("accumulate", 0) == 2 else 4.0 * m * n) + (4.0 * m * n if kw.get("accumulate", 0) or epi == UD_EPI_D2S else 0.0)
+            o_bytes += 2.0 * m * n if kw.get("out2") is not None else 0.0
+        nbytes = g * (a_bytes + 2.0 * n * k + o_bytes)
+        self.meta.append((cls, tag or cls, float(flops), float(nbytes)))
         return check(lib.ud_program_add_gemm(self.h, C.byref(d)))
 
     def layernorm(self, **kw):

@@ -39,6 +39,11 @@ class InferPipeline:
         self._n += 1
         st = self.streams[i]
         st.wait_stream(torch.cuda.current_stream(self.model.device))      # inputs produced on the caller's stream
+        # the inputs were allocated on the caller's stream but are read on `st` (infer() copies them into the plan's buffers there):
+        # tell the caching allocator, or a temporary dropped by the caller could be recycled while the copy is still queued
+        for t in (rgb, camera):
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(st)
         with torch.cuda.stream(st):
             out = self.model.infer(rgb, camera, normalize, slot=i)
             if post is not None:

@@ -13,6 +13,7 @@ assembly kernel is issued per call because it writes into fresh caller-owned ten
 """
 from __future__ import annotations
 
+import collections
 import json
 import math
 import os
@@ -25,6 +26,8 @@ from . import ops
 from .ops import (UD_A_CONV3_REFLECT, UD_A_CONV3_ZERO, UD_ACT_GELU, UD_ACT_LRELU, UD_ACT_NONE, UD_EPI_D2S, UD_EPI_F16,
                   UD_EPI_F32, UD_EPI_HEAD, UD_EPI_QKV)
 from .cameras import GT_OPENCV, GT_PINHOLE, as_camera
+
+GT_GIVEN_RAYS = 15          # plan tag: the ray map itself is supplied (pixel_decoder seam, decoder.py:400 `rays_gt`)
 from .weights import arch_of, pack
 
 IMAGENET_DATASET_MEAN = (0.485, 0.456, 0.406)      # unidepth/utils/constants.py:12
@@ -64,15 +67,24 @@ def _rup(x, m):
 class _Plan:
     """Device buffers + recorded launch program for one (batch, image shape, camera batch, dtype) signature."""
 
-    def __init__(self, model: "UniDepthV2", B, H, W, cam_nb, is_u8, normalize, pixels_bounds, gt_mode=1):
+    def __init__(self, model: "UniDepthV2", B, H, W, cam_nb, is_u8, normalize, pixels_bounds, gt_mode=1, net=False):
         w, a, dev = model._w, model._arch, model.device
         meta = w["meta"]
         D, C, heads, Hd = a["D"], a["C"], a["heads"], a["dec_heads"]
         sc = model.shape_constraints
         self.B, self.H, self.W = B, H, W
-        self.paddings, (self.Hp, self.Wp) = get_paddings((H, W), sc["ratio_bounds"])
+        if net:                            # module-seam plans (pixel_encoder / pixel_decoder): the input IS the network image
+            assert H % 14 == 0 and W % 14 == 0, "network-resolution image: H and W must be multiples of the patch size (14)"
+            self.paddings, (self.Hp, self.Wp) = (0, 0, 0, 0), (H, W)
+            self.rf, (Hn, Wn) = 1.0, (H, W)
+        else:
+            self.paddings, (self.Hp, self.Wp) = get_paddings((H, W), sc["ratio_bounds"])
+            self.rf, (Hn, Wn) = get_resize_factor((self.Hp, self.Wp), pixels_bounds)
         pl, pr, pt, pb = self.paddings
-        self.rf, (Hn, Wn) = get_resize_factor((self.Hp, self.Wp), pixels_bounds)
+        self.tap_points = []               # (name, number of ops after which it is valid, getter -> tensor in the reference's layout)
+
+        def tap(name, fn):
+            self.tap_points.append((name, len(self.prog), fn))
         self.Hn, self.Wn = Hn, Wn
         h, wg = Hn // 14, Wn // 14
         self.h, self.w = h, wg
@@ -114,6 +126,7 @@ class _Plan:
         P.gemm(A=patches, W=w["patch.w"], bias=w["patch.b"], out=x, add=pos, M=B * hw, N=D, K=640, lda=640, ldw=640, ldc=D,
                ldadd=D, epi=UD_EPI_F32, rows_in=hw, rows_out=Np, row_off=1, add_row_off=1)
         P.fill_rows(x, cls_row, B, Np, 0, D, D)
+        tap("tokens0", lambda: x.view(B, Np, D)[:, :N].clone())                 # cls + patches + pos_embed (dinov2.py:306-322)
         xn = z(M, D)
         qk = z(M, 2 * D)
         vt = z(B, heads, 64, Nkp)
@@ -129,6 +142,12 @@ class _Plan:
             P.gemm(A=xn, W=w[f"enc.{i}.qkv.w"], bias=w[f"enc.{i}.qkv.b"], out=qk, out2=vt, M=M, N=3 * D, K=D, lda=D, ldw=D,
                    ldc=2 * D, epi=UD_EPI_QKV, vsplit=2 * D, tok_per_img=Np, kv_ld=Nkp, heads_v=heads, tag="enc.qkv",
                    flops=2.0 * B * N * 3 * D * D)
+            if i == 0:
+                def _qkv0():                                                    # [B, N, 3D] = Q | K | V (attention.py:53-55 layout)
+                    cols = ((torch.arange(N) & ~15) | ((torch.arange(N) & 4) << 1) | ((torch.arange(N) & 8) >> 1) | (torch.arange(N) & 3)).to(dev)
+                    v = vt[:, :, :, cols].permute(0, 3, 1, 2).reshape(B, N, D)
+                    return torch.cat([qk.view(B, Np, 2 * D)[:, :N], v], dim=2).float()
+                tap("blocks.0.attn.qkv", _qkv0)
             P.attention(Q=qk, K=qk.data_ptr() + D * 2, Vt=vt, O=ao, B=B, H=heads, Nq=N, Nk=N, ldq=2 * D, ldk=2 * D, ldo=D,
                         kv_ld=Nkp, q_rows_per_img=Np, k_rows_per_img=Np, scale=(D // heads) ** -0.5, tag="enc.attn")
             P.gemm(A=ao, W=w[f"enc.{i}.proj.w"], bias=w[f"enc.{i}.proj.b"], out=x, M=M, N=D, K=D, lda=D, ldw=D, ldc=D,
@@ -138,6 +157,8 @@ class _Plan:
                    epi=UD_EPI_F16, act=UD_ACT_GELU, tag="enc.fc1", flops=8.0 * B * N * D * D)
             P.gemm(A=hid, W=w[f"enc.{i}.fc2.w"], bias=w[f"enc.{i}.fc2.b"], out=x, M=M, N=D, K=4 * D, lda=4 * D, ldw=4 * D, ldc=D,
                    epi=UD_EPI_F32, accumulate=1, tag="enc.fc2", flops=8.0 * B * N * D * D)
+            if i in (0, 5, 11, 17, 23) or i == a["depth"] - 1:
+                tap(f"block{i}", lambda: x.view(B, Np, D)[:, :N].clone())      # residual stream after block i
             if (i + 1) in a["output_idx"]:
                 # final LayerNorm (eps 1e-5, dinov2.py:254) only on the 4 consumed outputs; patch rows and cls row separately
                 P.layernorm(x=x, y=featn[lvl], rows=B * hw, D=D, ldx=D, ldy=D, eps=1e-5, rows_per_img=hw, in_rows_per_img=Np,
@@ -154,6 +175,9 @@ class _Plan:
         ct = z(B * 4, C, dtype=f32)
         P.gemm(A=featn_all, W=w["dec.adapterg.w"], bias=w["dec.adapterg.b"], out=feat_all, M=Md, N=C, K=D, lda=D, ldw=D, ldc=C,
                epi=UD_EPI_F32, groups=4, gA=Md * D, gW=C * D, gBias=C, gOut=Md * C, tag="dec.adapters(x4)")
+        self.dec_first = self.enc_last
+        for j in range(4):
+            tap(f"input_adapter.{j}", lambda j=j: feat_all[j].view(B, hwp, C)[:, :hw].clone())
         for j in range(4):
             P.linear_f32(x=clsn[j], W=w[f"dec.camadapter.{j}.w"], bias=w[f"dec.camadapter.{j}.b"], out=ct.data_ptr() + j * C * 4,
                          M=B, N=C, K=D, ldx=D, ldw=D, ldc=4 * C, tag="cam.adapter")
@@ -202,9 +226,12 @@ class _Plan:
 
         self.intr4 = z(B, 4, dtype=f32); self.K33 = z(B, 9, dtype=f32); kinv = z(B, 9, dtype=f32); self.Kpost = z(B, 9, dtype=f32)
         P.camera_intrinsics(raw, 1, self.intr4, self.K33, kinv, self.Kpost, B, Hn, Wn, float(self.rf), pl, pt)
+        tap("intrinsics4", lambda: self.intr4.clone())
         # ---------------- rays (decoder.py:361-403 / GT camera: unidepthv2.py:299-303,361-362)
         self.rays = z(nb, 3, Hn, Wn, dtype=f32)
-        if cam_nb and gt_mode >= GT_OPENCV:                                 # iterative models: OPENCV, Fisheye624, MEI (one camera)
+        if cam_nb and gt_mode == GT_GIVEN_RAYS:                             # pixel_decoder(inputs={"rays": ...}): the caller fills self.rays
+            pass
+        elif cam_nb and gt_mode >= GT_OPENCV:                               # iterative models: OPENCV, Fisheye624, MEI (one camera)
             self.kinv_gt = z(1, 16, dtype=f32)
             self.cam_scratch = z(4 * Hn * Wn + 16, dtype=f32)
             P.rays_camera(self.kinv_gt, self.rays, self.cam_scratch, Hn, Wn, gt_mode)
@@ -218,6 +245,7 @@ class _Plan:
         scales = (2.0 ** torch.linspace(0.0, math.log2(max(h, wg) // 2), steps=nbands)).to(dev)
         emb = z(nb * hwp, C)
         P.ray_embed(rays=self.rays, scales=scales, xhat=emb, nb=nb, Hn=Hn, Wn=Wn, h=h, w=wg, C=C, ldy=C, rows_per_img=hwp, eps=1e-5)
+        tap("rays_embedding_normed", lambda: emb.view(nb, hwp, C)[:, :hw].float())   # the embedding after LayerNorm statistics (eps 1e-5)
         # the 4 blocks (one per encoder level) are independent: every step is ONE grouped launch (blockIdx.z = level)
         HC = Hd * 64
         Mk = nb * hwp
@@ -242,6 +270,8 @@ class _Plan:
         P.gemm(A=hidd, W=w["dhg.fc2.w"], bias=w["dhg.fc2.b"], out=feat_all, out2=c16_all, M=Md, N=C, K=4 * C, lda=4 * C, ldw=4 * C,
                ldc=C, ldc2=C, epi=UD_EPI_F32, accumulate=1, gA=Md * 4 * C, gW=C * 4 * C, gBias=C, gOut=Md * C, gOut2=Md * C,
                tag="dh.fc2(x4)", **G4)
+        for j in range(4):
+            tap(f"prompt_camera.{j}", lambda j=j: feat_all[j].view(B, hwp, C)[:, :hw].clone())
         # ---------------- latents + 3 x (ConvT inject, 2 RCU, 1x1 + x2 up) (decoder.py:262-282; upsample.py:137-223)
         lat = z(Md, C, dtype=f32)
         P.gemm(A=c16[0], W=w["dh.to_latents.w"], bias=w["dh.to_latents.b"], out=lat, M=Md, N=C, K=C, lda=C, ldw=C, ldc=C, epi=UD_EPI_F32)
@@ -272,10 +302,12 @@ class _Plan:
                 nlat = z(B * 4 * gh * gw, outd, dtype=f32)
                 P.upsample2x(in_=u, out=nlat, B=B, H=gh, W=gw, C=outd, ldin=outd, ldy=outd, mode=0, in_img_rows=rows_img)
                 lat = nlat
+                tap(f"ups.{i}", lambda t=nlat, gh=gh, gw=gw, outd=outd: t.view(B, 2 * gh, 2 * gw, outd).permute(0, 3, 1, 2).clone())
             else:
                 ldx = _rup(outd, 64)
                 xh = z(B * 4 * gh * gw, ldx)
                 P.upsample2x(in_=u, out=xh, B=B, H=gh, W=gw, C=outd, ldin=outd, ldy=ldx, mode=1, eps=1e-5, in_img_rows=rows_img)
+                tap(f"ups.{i}_normed", lambda t=xh, gh=gh, gw=gw, outd=outd: t.view(B, 2 * gh, 2 * gw, -1)[..., :outd].permute(0, 3, 1, 2).float())
             gh, gw = 2 * gh, 2 * gw
             rows_img = gh * gw
         # ---------------- heads (decoder.py:284-318): LN+Linear (both branches), 3x3 reflect, AC resize, 3x3 reflect + 1x1 + exp
@@ -298,16 +330,18 @@ class _Plan:
                amode=UD_A_CONV3_REFLECT, epi=UD_EPI_HEAD, Himg=Hn, Wimg=Wn, Cin=o2, cstride=o2, coff=0, rows_img=Hn * Wn,
                img_stride=Hn * Wn * o2, b2=b2[0], post_add=2.0, b2_g1=b2[1], post_add_g1=0.0, groups=2, gA=B * Hn * Wn * o2,
                gW=32 * kp, gBias=32, gOut=B * Hn * Wn, gW2=32)
+        tap("logdepth", lambda: (torch.log(self.net[0]) - 2.0).view(B, 1, Hn, Wn))     # pre-exp head output (valid while |log| < 8: no clip)
+        tap("logconf", lambda: torch.log(self.net[1]).view(B, 1, Hn, Wn))
         self.nb = nb
         self.Ho, self.Wo = self.Hp - pt - pb, self.Wp - pl - pr
         self.graph = None
 
-    def finalize(self, out: dict):
+    def finalize(self, out: dict, mode: int = 0):
         import ctypes as C
         pl, _, pt, _ = self.paddings
         d = ops.mk(ops.UdFinalize, radius_net=self.net[0], conf_net=self.net[1], rays_net=self.rays, confidence=out["confidence"],
                    radius=out["radius"], depth=out["depth"], points=out["points"], rays=out["rays"], B=self.B, nb_rays=self.nb,
-                   Hn=self.Hn, Wn=self.Wn, Hp=self.Hp, Wp=self.Wp, pad_l=pl, pad_t=pt, Ho=self.Ho, Wo=self.Wo)
+                   Hn=self.Hn, Wn=self.Wn, Hp=self.Hp, Wp=self.Wp, pad_l=pl, pad_t=pt, Ho=self.Ho, Wo=self.Wo, mode=mode)
         ops.check(ops.lib.ud_finalize_outputs(C.byref(d), ops.cur_stream()), "ud_finalize_outputs")
 
 
@@ -323,7 +357,8 @@ class UniDepthV2:
         self._sd = None
         self._w = None
         self._device = torch.device("cpu")
-        self._plans: dict = {}
+        self._plans: "collections.OrderedDict" = collections.OrderedDict()
+        self.max_plans = int(os.environ.get("UNIDEPTH_MAX_PLANS", "6"))   # LRU bound on cached (batch, shape, camera, slot) plans
         self._pos_cache: dict = {}
         self.use_graph = False
         self.training = False
@@ -360,7 +395,12 @@ class UniDepthV2:
         self._sd = {k.replace("module.", ""): v.detach().float().cpu() for k, v in state_dict.items()}
         self._w = None
         self._plans.clear()
+        self._pos_cache.clear()          # the resampled position embeddings are a function of the weights
         return self
+
+    def clear_plans(self):
+        """Drop every cached launch plan (device activation buffers of all (batch, shape, camera, slot) signatures seen so far)."""
+        self._plans.clear()
 
     def state_dict(self):
         return dict(self._sd)
@@ -381,6 +421,7 @@ class UniDepthV2:
             self._device = device
             self._w = None
             self._plans.clear()
+            self._pos_cache.clear()
         return self
 
     def cuda(self):
@@ -424,14 +465,20 @@ class UniDepthV2:
         warnings.warn("!! self.resolution_level not set, using default bounds !!")
         return (lo, hi)
 
-    def _plan(self, B, H, W, cam_nb, is_u8, normalize, slot=0, gt_mode=0) -> _Plan:
-        bounds = self._pixels_bounds()
-        key = (B, H, W, cam_nb, is_u8, normalize, bounds, slot, gt_mode)
+    def _plan(self, B, H, W, cam_nb, is_u8, normalize, slot=0, gt_mode=0, net=False) -> _Plan:
+        bounds = (0.0, 0.0) if net else self._pixels_bounds()
+        key = (B, H, W, cam_nb, is_u8, normalize, bounds, slot, gt_mode, net)
         plan = self._plans.get(key)
         if plan is None:
+            # a plan owns the full activation set of its signature (~2.6 GB for ViT-L at bs=8): the cache is an LRU of `max_plans`
+            # entries, so a stream of many image shapes (KITTI / nuScenes style) cannot grow device memory without bound
+            while len(self._plans) >= max(1, self.max_plans):
+                self._plans.popitem(last=False)
             with torch.cuda.device(self._device):
-                plan = _Plan(self, B, H, W, cam_nb, is_u8, normalize, bounds, gt_mode)
+                plan = _Plan(self, B, H, W, cam_nb, is_u8, normalize, bounds, gt_mode, net)
             self._plans[key] = plan
+        else:
+            self._plans.move_to_end(key)
         return plan
 
     # ---- the hot path ----
@@ -440,8 +487,21 @@ class UniDepthV2:
         """Same contract as the reference infer() (unidepthv2.py:239-339).  `slot` (engine extension, keyword only) selects an
         independent set of activation buffers: calls with different slots may be in flight at the same time on different HIP
         streams (unidepth_amd/pipeline.py); calls with the same slot must be stream-ordered, as with the reference module."""
-        if self.interpolation_mode != "bilinear":
-            raise NotImplementedError("only interpolation_mode='bilinear' (the reference default) is implemented")
+        return self._infer(rgb, camera, normalize, slot, None)
+
+    @torch.no_grad()
+    def infer_with_taps(self, rgb: torch.Tensor, camera=None, normalize: bool = True, names=None):
+        """infer() that also returns intermediate tensors (SURVEY.md 8c tap list) in the reference's layouts: the launch program is
+        replayed in segments and the tapped buffers are copied out between segments (buffers are reused along the network).
+        Returns (outputs, {tap name: tensor}).  Parity tooling -- the product path is infer()."""
+        taps: dict = {}
+        out = self._infer(rgb, camera, normalize, 0, (taps, None if names is None else set(names)))
+        return out, taps
+
+    def _infer(self, rgb, camera, normalize, slot, taps):
+        # F.interpolate(..., align_corners=False) in the reference's _postprocess (unidepthv2.py:80-89) accepts exactly these two for 4-D input
+        if self.interpolation_mode not in ("bilinear", "bicubic"):
+            raise ValueError(f"interpolation_mode {self.interpolation_mode!r}: 'bilinear' or 'bicubic' (align_corners=False) expected")
         self._ensure_packed()
         if rgb.ndim == 3:
             rgb = rgb.unsqueeze(0)
@@ -461,6 +521,8 @@ class UniDepthV2:
         is_u8 = rgb.dtype == torch.uint8
         with torch.cuda.device(self._device):
             cam_nb = 0 if camera is None else (Kc.shape[0] if Kc is not None else cam_obj.params.shape[0])
+            # one camera broadcasts over the batch, otherwise one per image (the reference fails with a shape error here too)
+            assert cam_nb in (0, 1, B), f"camera batch {cam_nb} does not match the image batch {B} (one camera, or one per image)"
             gt_mode = 0 if camera is None else (GT_PINHOLE if Kc is not None else cam_obj.gt_mode)
             plan = self._plan(B, H, W, cam_nb, is_u8, bool(normalize), int(slot), gt_mode)
             plan.rgb.copy_(rgb if is_u8 else rgb.float(), non_blocking=True)
@@ -476,30 +538,128 @@ class UniDepthV2:
                 Kn[:, 1, 2] += pt
                 Kn[:, :2, :] *= plan.rf
                 plan.kinv_gt.copy_(torch.inverse(Kn).reshape(-1, 9))
-            plan.prog.run()
-            dev, f32 = self._device, torch.float32
-            out = {
-                "confidence": torch.empty(B, 1, plan.Ho, plan.Wo, dtype=f32, device=dev),
-                "radius": torch.empty(B, 1, plan.Ho, plan.Wo, dtype=f32, device=dev),
-                "depth": torch.empty(B, 1, plan.Ho, plan.Wo, dtype=f32, device=dev),
-                "points": torch.empty(B, 3, plan.Ho, plan.Wo, dtype=f32, device=dev),
-                "rays": torch.empty(plan.nb, 3, plan.Ho, plan.Wo, dtype=f32, device=dev),
-            }
-            plan.finalize(out)
-            out["intrinsics"] = plan.Kpost.view(B, 3, 3).clone()
-            out["depth_features"] = plan.depth_features.clone()
+            self._run(plan, 0, len(plan.prog), taps)
+            return self._collect(plan, B)
+
+    @staticmethod
+    def _run(plan: _Plan, first: int, last: int, taps=None):
+        """Replay ops [first, last) of the plan; with `taps` = (dict, names or None) the replay stops at every tap point in range."""
+        if taps is None:
+            plan.prog.run(first, last)
+            return
+        store, names = taps
+        pos = first
+        for name, at, fn in sorted(plan.tap_points, key=lambda t: t[1]):
+            if at < first or at > last or (names is not None and name not in names):
+                continue
+            if at > pos:
+                plan.prog.run(pos, at)
+                pos = at
+            store[name] = fn()
+        if last > pos:
+            plan.prog.run(pos, last)
+
+    def _collect(self, plan: _Plan, B: int):
+        dev, f32 = self._device, torch.float32
+        out = {
+            "confidence": torch.empty(B, 1, plan.Ho, plan.Wo, dtype=f32, device=dev),
+            "radius": torch.empty(B, 1, plan.Ho, plan.Wo, dtype=f32, device=dev),
+            "depth": torch.empty(B, 1, plan.Ho, plan.Wo, dtype=f32, device=dev),
+            "points": torch.empty(B, 3, plan.Ho, plan.Wo, dtype=f32, device=dev),
+            "rays": torch.empty(plan.nb, 3, plan.Ho, plan.Wo, dtype=f32, device=dev),
+        }
+        plan.finalize(out, 1 if self.interpolation_mode == "bicubic" else 0)
+        out["intrinsics"] = plan.Kpost.view(B, 3, 3).clone()
+        out["depth_features"] = plan.depth_features.clone()
         return {k: out[k] for k in ("confidence", "intrinsics", "radius", "depth", "points", "rays", "depth_features")}
 
     __call__ = infer
 
-    @torch.no_grad()
-    def forward_export(self, rgbs: torch.Tensor):
-        """Pure-tensor entry with the signature of the reference's ONNX wrapper (unidepthv2/export.py:27-45):
-        rgbs [B,3,H,W] -> (points [B,3,H,W], confidence [B,1,H,W], intrinsics [B,3,3])."""
-        out = self.infer(rgbs)
-        return out["points"], out["confidence"], out["intrinsics"]
+    # ---- module seams (SURVEY.md 8b/B2): the two halves of encode_decode() (unidepthv2.py:341-379) with the reference's signatures,
+    # each a sub-range of the launch program of a network-resolution plan, so either half can be swapped for the reference's /
+    # the oracle's during parity bisection.
+    @property
+    def embed_dim(self):
+        return self._arch["D"]
 
-    # ---- module seams for A/B bisection against the oracle (SURVEY.md 8b/B2) ----
+    @property
+    def embed_dims(self):
+        return [self._arch["D"]] * self._arch["depth"]
+
+    @property
+    def depths(self):
+        return list(self._arch["output_idx"])
+
+    patch_size = 14
+
+    @torch.no_grad()
+    def pixel_encoder(self, image: torch.Tensor, *, slot: int = 0):
+        """image [B,3,Hn,Wn] (normalised, network resolution, multiples of 14) -> (outputs, class_tokens) like the reference's
+        DINOv2 wrapper (backbones/dinov2.py:324-347): lists indexed by block, entries [B,h,w,D] / [B,1,D] after the final LayerNorm.
+        Only the blocks the decoder consumes (stacking_fn 'last' over the `depths` ranges: blocks output_idx - 1) are filled; the
+        other entries are None -- the reference computes and discards them."""
+        self._ensure_packed()
+        B, _, Hn, Wn = image.shape
+        with torch.cuda.device(self._device):
+            plan = self._plan(B, Hn, Wn, 0, False, False, int(slot), 0, net=True)
+            plan.rgb.copy_(image.float(), non_blocking=True)
+            plan.prog.run(0, plan.enc_last)
+            D, hw = self._arch["D"], plan.h * plan.w
+            hwp = _rup(hw, 8)
+            outs, cls = [None] * self._arch["depth"], [None] * self._arch["depth"]
+            for j, li in enumerate(self._arch["output_idx"]):
+                outs[li - 1] = plan.featn[j].view(B, hwp, D)[:, :hw].float().reshape(B, plan.h, plan.w, D)
+                cls[li - 1] = plan.clsn[j][:B].clone().view(B, 1, D)
+        return outs, cls
+
+    @torch.no_grad()
+    def encode(self, image: torch.Tensor):
+        """The 4 feature maps / class tokens encode_decode() hands to the decoder (unidepthv2.py:365-372)."""
+        outs, cls = self.pixel_encoder(image)
+        idx = [i - 1 for i in self._arch["output_idx"]]
+        return [outs[i] for i in idx], [cls[i] for i in idx]
+
+    @torch.no_grad()
+    def pixel_decoder(self, inputs: dict, image_metas=None, *, slot: int = 0):
+        """Decoder.forward (unidepthv2/decoder.py:405-462): inputs = {image [B,3,H,W] (shape only), features: 4 x [B,h,w,D],
+        tokens: 4 x [B,1,D], optional rays [B|1,3,H,W] (GT rays replace the predicted ones, decoder.py:400)} ->
+        {radius [B,1,H,W], depth_features [B,C,h,w], confidence [B,1,H,W], intrinsics [B,3,3], rays [B|1,H*W,3]}."""
+        self._ensure_packed()
+        B, _, H, W = inputs["image"].shape
+        feats, toks, rays = inputs["features"], inputs["tokens"], inputs.get("rays", None)
+        assert len(feats) == 4 and len(toks) == 4
+        with torch.cuda.device(self._device):
+            nb = 0 if rays is None else int(rays.shape[0])
+            assert nb in (0, 1, B)
+            plan = self._plan(B, H, W, nb, False, False, int(slot), GT_GIVEN_RAYS if nb else 0, net=True)
+            D, hw = self._arch["D"], plan.h * plan.w
+            hwp = _rup(hw, 8)
+            for j in range(4):
+                assert tuple(feats[j].shape) == (B, plan.h, plan.w, D), (tuple(feats[j].shape), (B, plan.h, plan.w, D))
+                plan.featn[j].view(B, hwp, D)[:, :hw].copy_(feats[j].reshape(B, hw, D))
+                plan.clsn[j][:B].copy_(toks[j].reshape(B, D))
+            if nb:
+                plan.rays.copy_(rays.reshape(nb, 3, H, W))
+            plan.prog.run(plan.dec_first, len(plan.prog))
+            return {"radius": plan.net[0].view(B, 1, H, W).clone(), "depth_features": plan.depth_features.clone(),
+                    "confidence": plan.net[1].view(B, 1, H, W).clone(), "intrinsics": plan.K33.view(B, 3, 3).clone(),
+                    "rays": plan.rays.reshape(plan.nb, 3, H * W).permute(0, 2, 1).contiguous()}
+
+    @torch.no_grad()
+    def forward_export(self, rgbs: torch.Tensor, rays: Optional[torch.Tensor] = None):
+        """Pure-tensor entries of the reference's ONNX wrappers (unidepthv2/export.py:27-45 `forward(rgbs)` and :57-76
+        `forward(rgbs, rays)`): rgbs is the NETWORK image [B,3,H,W] (normalised, multiples of 14; no pre-/post-processing) ->
+        (pts_3d [B,3,H,W], confidence [B,1,H,W], intrinsics [B,3,3] at network resolution)."""
+        B, _, H, W = rgbs.shape
+        features, tokens = self.encode(rgbs)
+        inputs = {"image": rgbs, "features": features, "tokens": tokens}
+        if rays is not None:
+            inputs["rays"] = rays
+        out = self.pixel_decoder(inputs, [])
+        r = out["rays"].permute(0, 2, 1).reshape(-1, 3, H, W)
+        return r * out["radius"], out["confidence"], out["intrinsics"]
+
+    # ---- quick look at the last call's network-resolution tensors (kept from round 1; infer_with_taps() is the full tap list) ----
     @torch.no_grad()
     def debug_taps(self, plan: Optional[_Plan] = None):
         """Tensors of the last infer() in reference layout: final-normed features/cls tokens, network-res maps."""

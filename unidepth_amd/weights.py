@@ -25,6 +25,10 @@ def arch_of(config: dict) -> dict:
     if enc["name"] not in ARCH:
         raise NotImplementedError(f"pixel_encoder {enc['name']!r}: only the DINOv2 ViT-S/B/L backbones of UniDepthV2 are implemented")
     D, depth, heads, out_idx = ARCH[enc["name"]]
+    # pack() folds the encoder's final LayerNorm into the adapters and takes each level's last block output: the only setting the
+    # released V2 configs use (encoder.py:139-193 builds the backbone with use_norm / stacking from these keys)
+    if not enc.get("use_norm", False) or enc.get("stacking_fn", "last") != "last":   # reference default: use_norm=False (encoder.py:150)
+        raise NotImplementedError("pixel_encoder: only use_norm=true, stacking_fn='last' (all released V2 configs) is implemented")
     dec = config["model"]["pixel_decoder"]
     if dec.get("kernel_size", 7) != 3 or list(dec["depths"]) != [2, 2, 2]:
         raise NotImplementedError("pixel_decoder: only kernel_size=3, depths=[2,2,2] (all released V2 configs) is implemented")
