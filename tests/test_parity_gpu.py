@@ -119,7 +119,10 @@ def test_taps_vs_oracle(engine_cls, arch, H, W, B, seed):
     res["ups.2_normed"] = _rel(taps["ups.2_normed"], F.layer_norm(u2.permute(0, 2, 3, 1), (u2.shape[1],), eps=1e-5).permute(0, 3, 1, 2))
     print(arch, {k: f"{v:.1e}" for k, v in res.items()})
     for name, v in res.items():
-        bar = 4e-3 if name in ("ups.2_normed",) else 3e-3
+        # the ray embedding holds sin(angle * 2^k * pi) up to k = log2(max(h, w) / 2): an intrinsics error of 7e-4 (inside its 2e-3 bar)
+        # moves the top band's phase by ~1e-2, so this tap inherits the camera head's error times the band frequency (the kernel
+        # itself is held to 1e-3 on identical rays in tests/test_kernels_gpu.py::test_camera_rays_embed)
+        bar = 1.5e-2 if name == "rays_embedding_normed" else 3e-3
         assert v <= bar, (name, v)
     kk = ((taps["intrinsics4"].cpu() - rt["intrinsics4"]).abs() / rt["intrinsics4"].abs()).max().item()
     assert kk <= 2e-3, kk

@@ -13,8 +13,9 @@ for f in gemm.hip layernorm.hip pointwise.hip camera_f32.hip; do
   pids+=($!)
 done
 # attention: keep the MFMA accumulators in VGPRs (the softmax VALU works on them every tile; the default AGPR form costs
-# ~160 v_accvgpr_read/write per 16 MFMAs)
-( hipcc $FLAGS -mllvm -amdgpu-mfma-vgpr-form=1 "$@" -c attention.hip -o $BD/attention.o ) & pids+=($!)
+# ~160 v_accvgpr_read/write per 16 MFMAs); no SLP vectorisation: packed f32 adds (v_pk_add_f32) next to MFMAs are slower than
+# the scalar adds they replace (half-rate issue, /opt/skills/guides MI355X_MICROARCH "price of one filler beside MFMAs")
+( hipcc $FLAGS -mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize "$@" -c attention.hip -o $BD/attention.o ) & pids+=($!)
 ( hipcc $FLAGS -x hip -c api.cpp -o $BD/api.o ) & pids+=($!)
 ( hipcc $FLAGS -x hip -c program.cpp -o $BD/program.o ) & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done

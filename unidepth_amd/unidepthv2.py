@@ -607,9 +607,11 @@ class UniDepthV2:
             D, hw = self._arch["D"], plan.h * plan.w
             hwp = _rup(hw, 8)
             outs, cls = [None] * self._arch["depth"], [None] * self._arch["depth"]
+            # the engine's final LayerNorm stores statistics only (its affine is folded into the adapters' weights): apply it here
+            gn, bn = self._w["enc.norm.g"], self._w["enc.norm.b"]
             for j, li in enumerate(self._arch["output_idx"]):
-                outs[li - 1] = plan.featn[j].view(B, hwp, D)[:, :hw].float().reshape(B, plan.h, plan.w, D)
-                cls[li - 1] = plan.clsn[j][:B].clone().view(B, 1, D)
+                outs[li - 1] = (plan.featn[j].view(B, hwp, D)[:, :hw].float() * gn + bn).reshape(B, plan.h, plan.w, D)
+                cls[li - 1] = (plan.clsn[j][:B] * gn + bn).view(B, 1, D)
         return outs, cls
 
     @torch.no_grad()
@@ -634,10 +636,15 @@ class UniDepthV2:
             plan = self._plan(B, H, W, nb, False, False, int(slot), GT_GIVEN_RAYS if nb else 0, net=True)
             D, hw = self._arch["D"], plan.h * plan.w
             hwp = _rup(hw, 8)
+            # the decoder program consumes LayerNorm STATISTICS (the affine of the encoder's final norm is folded into the adapters):
+            # undo the affine of the reference-semantics inputs.  Seam / bisection path only -- infer() never does this.
+            gn, bn = self._w["enc.norm.g"], self._w["enc.norm.b"]
+            if float(gn.abs().min()) < 1e-6:
+                raise NotImplementedError("pixel_decoder seam: the encoder's final LayerNorm has a zero scale, its affine cannot be undone")
             for j in range(4):
                 assert tuple(feats[j].shape) == (B, plan.h, plan.w, D), (tuple(feats[j].shape), (B, plan.h, plan.w, D))
-                plan.featn[j].view(B, hwp, D)[:, :hw].copy_(feats[j].reshape(B, hw, D))
-                plan.clsn[j][:B].copy_(toks[j].reshape(B, D))
+                plan.featn[j].view(B, hwp, D)[:, :hw].copy_((feats[j].reshape(B, hw, D).to(self._device, torch.float32) - bn) / gn)
+                plan.clsn[j][:B].copy_((toks[j].reshape(B, D).to(self._device, torch.float32) - bn) / gn)
             if nb:
                 plan.rays.copy_(rays.reshape(nb, 3, H, W))
             plan.prog.run(plan.dec_first, len(plan.prog))
@@ -667,7 +674,8 @@ class UniDepthV2:
         hw = plan.h * plan.w
         hwp = _rup(hw, 8)
         D = self._arch["D"]
-        feats = [f.view(plan.B, hwp, D)[:, :hw].float().view(plan.B, plan.h, plan.w, D) for f in plan.featn]
-        cls = [c[: plan.B].float().view(plan.B, 1, D) for c in plan.clsn]
+        gn, bn = self._w["enc.norm.g"], self._w["enc.norm.b"]          # reference semantics: final LayerNorm WITH its affine
+        feats = [(f.view(plan.B, hwp, D)[:, :hw].float() * gn + bn).view(plan.B, plan.h, plan.w, D) for f in plan.featn]
+        cls = [(c[: plan.B].float() * gn + bn).view(plan.B, 1, D) for c in plan.clsn]
         return dict(features=feats, tokens=cls, radius_net=plan.net[0], confidence_net=plan.net[1], rays_net=plan.rays,
                     intrinsics_net=plan.K33.view(-1, 3, 3), intr4=plan.intr4)

@@ -104,6 +104,7 @@ def pack(config: dict, sd: dict, device) -> dict:
         g2 = f[b + "ls2.gamma"]
         put16(f"enc.{i}.fc2.w", f[b + "mlp.fc2.weight"] * g2[:, None]); put32(f"enc.{i}.fc2.b", f[b + "mlp.fc2.bias"] * g2)
     gn, bn = f[pe + "norm.weight"], f[pe + "norm.bias"]
+    put32("enc.norm.g", gn); put32("enc.norm.b", bn)     # only the module seams need the affine itself (it is folded into the adapters)
 
     pd = "pixel_decoder."
     for j in range(4):
