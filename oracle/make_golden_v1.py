@@ -1,0 +1,44 @@
+"""TEST INFRASTRUCTURE ONLY -- golden vectors for the V1 components from the REAL reference (/root/reference, CPU fp32, restated timm
+layers of oracle/stubs/timm).  Authoring container:  PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden_v1"""
+from __future__ import annotations
+
+import contextlib
+import io
+import json
+import os
+import warnings
+
+import numpy as np
+import torch
+
+from . import ref_loader, synth_v1
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def main():
+    assert ref_loader.available()
+    warnings.simplefilter("ignore")
+    ref_loader._prepare()
+    with contextlib.redirect_stdout(io.StringIO()):
+        from unidepth.models import UniDepthV1  # type: ignore
+        from unidepth.utils.misc import max_stack  # type: ignore
+        cfg_ref = json.load(open(os.path.join(ref_loader.REF_ROOT, "configs", "config_v1_cnvnxtl.json")))
+        model = UniDepthV1(cfg_ref).eval()
+    cfg = synth_v1.load_config_v1()
+    sd = synth_v1.make_synthetic_checkpoint_v1(cfg, 211)
+    model.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 3, 128, 160, generator=g)
+    with torch.no_grad():
+        outs, cls = model.pixel_encoder(x)
+    d = {}
+    for j, (a, b) in enumerate(model.pixel_decoder.slices_encoder_range):
+        d[f"stage{j}"] = max_stack(outs[a:b])[:, ::3, ::3, ::7].contiguous().numpy()
+    d["cls_last4"] = torch.cat([cls[-i - 1] for i in range(4)], dim=-1).numpy()
+    np.savez_compressed(os.path.join(OUT, "v1_convnext_128x160.npz"), **d)
+    print({k: v.shape for k, v in d.items()})
+
+
+if __name__ == "__main__":
+    main()
