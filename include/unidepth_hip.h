@@ -104,6 +104,8 @@ typedef struct UdLayerNorm {
   float eps;
   int rows_per_img, in_rows_per_img, in_row_off, out_rows_per_img, out_row_off;
   int out_f32;            /* 0: y is fp16 (MFMA operand); 1: y is fp32 (the fp32 camera head) */
+  const float* gamma;     /* optional affine [D] applied here (NULL = statistics only, the default: affines are folded into the consumer).  */
+  const float* beta;      /* Needed where no linear consumer follows: the ConvNeXt stem's LayerNorm2d feeds a zero-padded depth-wise conv.  */
 } UdLayerNorm;
 int ud_layernorm_f32_f16(const UdLayerNorm* desc, void* stream);
 
@@ -229,6 +231,27 @@ int ud_finalize_outputs(const UdFinalize* desc, void* stream);
 /* NHWC fp32 (row stride ld, rows_per_img rows per image) -> NCHW fp32 [B,C,h*w]  (depth_features, decoder.py:265-267) */
 int ud_nhwc_to_nchw_f32(const float* in, float* out, int B, int hw, int C, int ld, int rows_per_img, void* stream);
 
+/* ---- ConvNeXt-side ops of the UniDepthV1 path (reference backbones/convnext.py; decoder blocks layers/convnext.py) ---------------
+ * Depth-wise 7x7 convolution, zero padding 3 (convnext.py:171-179 conv_dw via timm create_conv2d(depthwise=True); layers/convnext.py:16-24):
+ * y[b,y,x,c] = bias[c] + sum_{ky,kx} w[(ky*7+kx)*C + c] * x[b, y+ky-3, x+kx-3, c];  NHWC fp32 in / out, pixel strides ldx / ldy (floats);
+ * w is TAP-major [49][C] (repacked from the reference's [C,1,7,7] at load time). */
+typedef struct UdDwConv7 {
+  const float* x; const float* w; const float* bias; float* y;
+  int B, H, W, C, ldx, ldy;
+} UdDwConv7;
+int ud_dwconv7_nhwc_f32(const UdDwConv7* desc, void* stream);
+/* LayerNorm2d statistics (eps; affine folded into the conv weights) of every pixel of x fp32 NHWC [B,H,W,C], written as fp16 into the
+ * im2col image of the following Conv2d(k=2, s=2, pad 0) (convnext.py:245-266 ConvNeXtStage.downsample): row (b, y/2, x/2), columns
+ * ((y&1)*2 + (x&1))*C + c, row stride ldo >= 4C; an odd last row / column of x is dropped like the convolution drops it. */
+int ud_layernorm_patchify2(const float* x, void* out, int B, int H, int W, int C, int ldo, float eps, void* stream);
+/* im2col of the 4x4 stride-4 stem convolution (convnext.py:370-383): img fp32 NCHW [B,3,H,W] -> fp16 [B*(H/4)*(W/4), ldo], column
+ * c*16 + ky*4 + kx (48 used; the caller zero-fills the pad columns once). */
+int ud_patchify4_nchw(const float* img, void* out, int B, int H, int W, int ldo, void* stream);
+/* dst = init ? src : max(dst, src), element-wise over n fp32 values (utils/misc.py:18-21 max_stack over a stage's block outputs). */
+int ud_max_f32(float* dst, const float* src, long long n, int init, void* stream);
+/* out[b*ldo + c] = mean over the HW pixels of x[b, :, c] (x fp32 [B,HW,C]): the "class tokens" of the ConvNeXt wrapper (convnext.py:458). */
+int ud_spatial_mean_f32(const float* x, float* out, int B, int HW, int C, int ldo, void* stream);
+
 /* ---- launch programs: a recorded list of the ops above replayed with one call (host-side runtime) ---- */
 typedef struct UdProgram UdProgram;
 UdProgram* ud_program_create(void);
@@ -250,10 +273,15 @@ int ud_program_add_upsample2x(UdProgram*, const UdUpsample2x*);
 int ud_program_add_resize_ac(UdProgram*, const UdResizeAC*);
 int ud_program_add_finalize(UdProgram*, const UdFinalize*);
 int ud_program_add_nhwc_to_nchw(UdProgram*, const float* in, float* out, int B, int hw, int C, int ld, int rows_per_img);
+int ud_program_add_dwconv7(UdProgram*, const UdDwConv7*);
+int ud_program_add_layernorm_patchify2(UdProgram*, const float* x, void* out, int B, int H, int W, int C, int ldo, float eps);
+int ud_program_add_patchify4(UdProgram*, const float* img, void* out, int B, int H, int W, int ldo);
+int ud_program_add_max(UdProgram*, float* dst, const float* src, long long n, int init);
+int ud_program_add_spatial_mean(UdProgram*, const float* x, float* out, int B, int HW, int C, int ldo);
 /* run ops [first, last) on `stream`; returns 0 or the first failing op's error code */
 int ud_program_run(const UdProgram*, int first, int last, void* stream);
 
-/* library info; ud_struct_size(i): sizeof the i-th descriptor struct in declaration order (UdGemm = 0 ...) */
+/* library info; ud_struct_size(i): sizeof the i-th descriptor struct in declaration order (UdGemm = 0 ... UdLinearF32 = 8, UdDwConv7 = 9) */
 int ud_version(void);
 int ud_struct_size(int which);
 const char* ud_last_error(void);

@@ -38,12 +38,16 @@ class UdGemm(C.Structure):
 class UdLayerNorm(C.Structure):
     _fields_ = [("x", fp), ("y", vp), ("rows", i32), ("D", i32), ("ldx", i32), ("ldy", i32), ("eps", f32),
                 ("rows_per_img", i32), ("in_rows_per_img", i32), ("in_row_off", i32), ("out_rows_per_img", i32),
-                ("out_row_off", i32), ("out_f32", i32)]
+                ("out_row_off", i32), ("out_f32", i32), ("gamma", fp), ("beta", fp)]
 
 
 class UdLinearF32(C.Structure):
     _fields_ = [("x", fp), ("W", fp), ("bias", fp), ("add", fp), ("out", fp), ("M", i32), ("N", i32), ("K", i32), ("ldx", i32),
                 ("ldw", i32), ("ldc", i32), ("ldadd", i32), ("add_mod", i32), ("act", i32), ("accumulate", i32)]
+
+
+class UdDwConv7(C.Structure):
+    _fields_ = [("x", fp), ("w", fp), ("bias", fp), ("y", fp), ("B", i32), ("H", i32), ("W", i32), ("C", i32), ("ldx", i32), ("ldy", i32)]
 
 
 class UdAttention(C.Structure):
@@ -120,6 +124,16 @@ def _load():
         "ud_program_add_resize_ac": [vp, P(UdResizeAC)],
         "ud_program_add_finalize": [vp, P(UdFinalize)],
         "ud_program_add_nhwc_to_nchw": [vp, vp, vp, i32, i32, i32, i32, i32],
+        "ud_dwconv7_nhwc_f32": [P(UdDwConv7), vp],
+        "ud_layernorm_patchify2": [vp, vp, i32, i32, i32, i32, i32, f32, vp],
+        "ud_patchify4_nchw": [vp, vp, i32, i32, i32, i32, vp],
+        "ud_max_f32": [vp, vp, i64, i32, vp],
+        "ud_spatial_mean_f32": [vp, vp, i32, i32, i32, i32, vp],
+        "ud_program_add_dwconv7": [vp, P(UdDwConv7)],
+        "ud_program_add_layernorm_patchify2": [vp, vp, vp, i32, i32, i32, i32, i32, f32],
+        "ud_program_add_patchify4": [vp, vp, vp, i32, i32, i32, i32],
+        "ud_program_add_max": [vp, vp, vp, i64, i32],
+        "ud_program_add_spatial_mean": [vp, vp, vp, i32, i32, i32, i32],
         "ud_program_run": [vp, i32, i32, vp],
         "ud_version": [],
         "ud_struct_size": [i32],
@@ -132,7 +146,7 @@ def _load():
     lib.ud_program_create.restype = vp
     lib.ud_last_error.argtypes = []
     lib.ud_last_error.restype = C.c_char_p
-    for i, st in enumerate([UdGemm, UdLayerNorm, UdAttention, UdPreprocess, UdRayEmbed, UdUpsample2x, UdResizeAC, UdFinalize, UdLinearF32]):
+    for i, st in enumerate([UdGemm, UdLayerNorm, UdAttention, UdPreprocess, UdRayEmbed, UdUpsample2x, UdResizeAC, UdFinalize, UdLinearF32, UdDwConv7]):
         if lib.ud_struct_size(i) != C.sizeof(st):
             raise ImportError(f"ctypes mirror of {st.__name__} is out of sync with include/unidepth_hip.h "
                               f"({C.sizeof(st)} vs {lib.ud_struct_size(i)} bytes)")

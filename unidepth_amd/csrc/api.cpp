@@ -24,6 +24,7 @@ extern "C" int ud_struct_size(int which) {
     case 6: return (int)sizeof(UdResizeAC);
     case 7: return (int)sizeof(UdFinalize);
     case 8: return (int)sizeof(UdLinearF32);
+    case 9: return (int)sizeof(UdDwConv7);
     default: return -1;
   }
 }

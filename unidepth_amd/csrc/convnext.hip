@@ -1,0 +1,209 @@
+// ConvNeXt-side kernels of the UniDepthV1 path (reference unidepth/models/backbones/convnext.py:130-223,245-266,370-383,447-458 and
+// layers/convnext.py:5-44): everything that is not a GEMM.  All HBM / L2-bound, NHWC (channels contiguous), wave64.
+//   dwconv7_kernel        depth-wise 7x7 convolution, zero padding 3, fp32 in / fp32 out (+ bias)
+//   ln_patchify2_kernel   LayerNorm2d statistics (affine folded into the following conv) + im2col of the 2x2 stride-2 down-sampling conv
+//   patchify4_kernel      im2col of the 4x4 stride-4 stem conv from the NCHW network image
+//   max_kernel            running element-wise max over a stage's block outputs (utils/misc.py:18-21 max_stack)
+//   spatial_mean_kernel   per-image mean over all pixels ("class tokens" of the ConvNeXt wrapper, convnext.py:458)
+#include "ud_common.h"
+
+namespace {
+
+// One wave = 8 consecutive output pixels of one image row x 256 channels (4 per lane, 16-byte accesses).  Per filter row the wave
+// loads the 14 input pixels its 8 outputs touch once and feeds each to the (up to 7) outputs it belongs to: 98 loads for 392
+// multiply-adds per lane-channel instead of 392.  Weights are stored tap-major [49][C] so a tap is one coalesced 16-byte load.
+__global__ __launch_bounds__(256) void dwconv7_kernel(const UdDwConv7 p) {
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  const int xt = (p.W + 7) >> 3;                       // x tiles per row
+  const int tile = blockIdx.x * 4 + wv;
+  const int total = p.B * p.H * xt;
+  if (tile >= total) return;
+  const int x0 = (tile % xt) << 3;
+  const int y = (tile / xt) % p.H;
+  const int b = tile / (xt * p.H);
+  const int c = blockIdx.y * 256 + lane * 4;
+  if (c >= p.C) return;
+  const float* img = p.x + (size_t)b * p.H * p.W * p.ldx;
+  f32x4 acc[8];
+  const f32x4 bv = p.bias ? *(const f32x4*)(p.bias + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = bv;
+  for (int ky = 0; ky < 7; ++ky) {
+    const int iy = y + ky - 3;
+    if ((unsigned)iy >= (unsigned)p.H) continue;        // wave-uniform
+    f32x4 wr[7];
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) wr[kx] = *(const f32x4*)(p.w + (size_t)(ky * 7 + kx) * p.C + c);
+    const float* row = img + (size_t)iy * p.W * p.ldx + c;
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+      const int ix = x0 + j - 3;
+      if ((unsigned)ix >= (unsigned)p.W) continue;      // wave-uniform
+      const f32x4 v = *(const f32x4*)(row + (size_t)ix * p.ldx);
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        const int kx = j - o;
+        if (kx >= 0 && kx < 7) acc[o] += v * wr[kx];
+      }
+    }
+  }
+  float* out = p.y + (((size_t)b * p.H + y) * p.W + x0) * p.ldy + c;
+#pragma unroll
+  for (int o = 0; o < 8; ++o)
+    if (x0 + o < p.W) *(f32x4*)(out + (size_t)o * p.ldy) = acc[o];
+}
+
+// LayerNorm2d (eps) over the C channels of every pixel, statistics only, written as fp16 straight into the im2col image of the
+// following Conv2d(k = 2, s = 2, padding 0): pixel (y, x) -> row (b, y / 2, x / 2), columns ((y & 1) * 2 + (x & 1)) * C + c.
+// An odd last row / column is dropped, as the convolution drops it.  One wave per pixel, C <= 2048.
+template <int NIT>
+__global__ __launch_bounds__(256) void ln_patchify2_kernel(const float* x, half_t* out, int B, int H, int W, int C, int ldo, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int Ho = H >> 1, Wo = W >> 1;
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= (long long)B * Ho * 2 * Wo * 2) return;
+  const int xx = (int)(r % (2 * Wo));
+  const int yy = (int)((r / (2 * Wo)) % (2 * Ho));
+  const int b = (int)(r / ((long long)4 * Wo * Ho));
+  const float* src = x + (((size_t)b * H + yy) * W + xx) * C;
+  f32x4 v[NIT];
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 256 + lane * 4;
+    if (c < C) {
+      v[it] = *(const f32x4*)(src + c);
+      s += (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]);
+    } else {
+      v[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const float mean = ud_wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 256 + lane * 4;
+    if (c < C) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) q += (v[it][e] - mean) * (v[it][e] - mean);
+    }
+  }
+  const float rstd = rsqrtf(ud_wave_sum(q) / (float)C + eps);
+  half_t* dst = out + (((size_t)b * Ho + (yy >> 1)) * Wo + (xx >> 1)) * ldo + (size_t)((yy & 1) * 2 + (xx & 1)) * C;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = it * 256 + lane * 4;
+    if (c < C) {
+      half4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = (half_t)((v[it][e] - mean) * rstd);
+      *(half4*)(dst + c) = h;
+    }
+  }
+}
+
+// stem im2col: image fp32 NCHW [B,3,H,W] -> fp16 [B*(H/4)*(W/4), ldo], column = c*16 + ky*4 + kx (the order of Conv2d's [Cout,3,4,4] rows)
+__global__ __launch_bounds__(256) void patchify4_kernel(const float* img, half_t* out, int B, int H, int W, int ldo) {
+  const int Ho = H >> 2, Wo = W >> 2;
+  const long long total = (long long)B * Ho * Wo * 48;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int k = (int)(idx % 48);
+    const long long m = idx / 48;
+    const int xo = (int)(m % Wo);
+    const int yo = (int)((m / Wo) % Ho);
+    const int b = (int)(m / ((long long)Wo * Ho));
+    const int c = k >> 4, ky = (k >> 2) & 3, kx = k & 3;
+    out[m * ldo + k] = (half_t)img[(((size_t)b * 3 + c) * H + yo * 4 + ky) * W + xo * 4 + kx];
+  }
+}
+
+__global__ __launch_bounds__(256) void max_kernel(float* dst, const float* src, long long n4, int init) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const f32x4 s = ((const f32x4*)src)[i];
+    if (init) {
+      ((f32x4*)dst)[i] = s;
+    } else {
+      f32x4 d = ((f32x4*)dst)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = fmaxf(d[e], s[e]);
+      ((f32x4*)dst)[i] = d;
+    }
+  }
+}
+
+// out[b, c] = mean over the HW pixels of x[b, :, c].  Block = (image, 256-channel chunk); 4 waves split the pixels, LDS combine.
+__global__ __launch_bounds__(256) void spatial_mean_kernel(const float* x, float* out, int HW, int C, int ldo) {
+  __shared__ f32x4 part[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int b = blockIdx.x;
+  const int c = blockIdx.y * 256 + lane * 4;
+  f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    const float* src = x + (size_t)b * HW * C + c;
+    for (int p = wv; p < HW; p += 4) s += *(const f32x4*)(src + (size_t)p * C);
+  }
+  part[wv][lane] = s;
+  __syncthreads();
+  if (wv == 0 && c < C) {
+    const f32x4 t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    *(f32x4*)(out + (size_t)b * ldo + c) = t * (1.0f / (float)HW);
+  }
+}
+
+}  // namespace
+
+extern "C" int ud_dwconv7_nhwc_f32(const UdDwConv7* desc, void* stream) {
+  const UdDwConv7& d = *desc;
+  if (!d.x || !d.w || !d.y || d.B <= 0 || d.H <= 0 || d.W <= 0 || d.C <= 0 || (d.C & 3) || (d.ldx & 3) || (d.ldy & 3) || d.ldx < d.C || d.ldy < d.C) {
+    ud_set_error("ud_dwconv7_nhwc_f32: bad argument (C, ldx, ldy % 4 == 0)");
+    return UD_ERR_BAD_ARG;
+  }
+  const long long tiles = (long long)d.B * d.H * ((d.W + 7) >> 3);
+  dim3 grid((unsigned)((tiles + 3) / 4), (d.C + 255) / 256);
+  hipLaunchKernelGGL(dwconv7_kernel, grid, dim3(256), 0, (hipStream_t)stream, d);
+  UD_CHECK_LAUNCH("ud_dwconv7_nhwc_f32 launch");
+  return UD_OK;
+}
+
+extern "C" int ud_layernorm_patchify2(const float* x, void* out, int B, int H, int W, int C, int ldo, float eps, void* stream) {
+  if (!x || !out || B <= 0 || H < 2 || W < 2 || C <= 0 || (C & 3) || C > 2048 || ldo < 4 * C || (ldo & 3)) {
+    ud_set_error("ud_layernorm_patchify2: bad argument (C % 4 == 0, C <= 2048, ldo >= 4 C)");
+    return UD_ERR_BAD_ARG;
+  }
+  const long long rows = (long long)B * (H >> 1) * 2 * (W >> 1) * 2;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  hipStream_t s = (hipStream_t)stream;
+  if (C <= 256) hipLaunchKernelGGL((ln_patchify2_kernel<1>), grid, dim3(256), 0, s, x, (half_t*)out, B, H, W, C, ldo, eps);
+  else if (C <= 512) hipLaunchKernelGGL((ln_patchify2_kernel<2>), grid, dim3(256), 0, s, x, (half_t*)out, B, H, W, C, ldo, eps);
+  else if (C <= 1024) hipLaunchKernelGGL((ln_patchify2_kernel<4>), grid, dim3(256), 0, s, x, (half_t*)out, B, H, W, C, ldo, eps);
+  else hipLaunchKernelGGL((ln_patchify2_kernel<8>), grid, dim3(256), 0, s, x, (half_t*)out, B, H, W, C, ldo, eps);
+  UD_CHECK_LAUNCH("ud_layernorm_patchify2 launch");
+  return UD_OK;
+}
+
+extern "C" int ud_patchify4_nchw(const float* img, void* out, int B, int H, int W, int ldo, void* stream) {
+  if (!img || !out || B <= 0 || H < 4 || W < 4 || ldo < 48) { ud_set_error("ud_patchify4_nchw: bad argument"); return UD_ERR_BAD_ARG; }
+  const long long total = (long long)B * (H >> 2) * (W >> 2) * 48;
+  long long g = (total + 255) / 256;
+  if (g > 256 * 16) g = 256 * 16;
+  hipLaunchKernelGGL(patchify4_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, img, (half_t*)out, B, H, W, ldo);
+  UD_CHECK_LAUNCH("ud_patchify4_nchw launch");
+  return UD_OK;
+}
+
+extern "C" int ud_max_f32(float* dst, const float* src, long long n, int init, void* stream) {
+  if (!dst || !src || n <= 0 || (n & 3)) { ud_set_error("ud_max_f32: bad argument (n % 4 == 0)"); return UD_ERR_BAD_ARG; }
+  long long g = (n / 4 + 255) / 256;
+  if (g > 256 * 16) g = 256 * 16;
+  hipLaunchKernelGGL(max_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, dst, src, n / 4, init);
+  UD_CHECK_LAUNCH("ud_max_f32 launch");
+  return UD_OK;
+}
+
+extern "C" int ud_spatial_mean_f32(const float* x, float* out, int B, int HW, int C, int ldo, void* stream) {
+  if (!x || !out || B <= 0 || HW <= 0 || C <= 0 || (C & 3) || (ldo & 3)) { ud_set_error("ud_spatial_mean_f32: bad argument"); return UD_ERR_BAD_ARG; }
+  hipLaunchKernelGGL(spatial_mean_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, out, HW, C, ldo);
+  UD_CHECK_LAUNCH("ud_spatial_mean_f32 launch");
+  return UD_OK;
+}

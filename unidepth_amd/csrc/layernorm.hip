@@ -47,15 +47,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const UdLayerNorm p) {
   for (int it = 0; it < NIT; ++it) {
     const int c = it * 256 + lane * 4;
     if (c < p.D) {
-      if constexpr (F32OUT) {
-        f32x4 o;
+      f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (v[it][e] - mean) * rstd;
+      for (int e = 0; e < 4; ++e) o[e] = (v[it][e] - mean) * rstd;
+      if (p.gamma) o = o * *(const f32x4*)(p.gamma + c) + (p.beta ? *(const f32x4*)(p.beta + c) : (f32x4){0.f, 0.f, 0.f, 0.f});
+      if constexpr (F32OUT) {
         *(f32x4*)(yf + c) = o;
       } else {
         half4 h;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) h[e] = (half_t)((v[it][e] - mean) * rstd);
+        for (int e = 0; e < 4; ++e) h[e] = (half_t)o[e];
         *(half4*)(y + c) = h;
       }
     }

@@ -9,18 +9,23 @@
 void ud_set_error(const char* msg);
 
 namespace {
-enum Kind { K_LIN32, K_ATTS, K_GEMM, K_LN, K_ATTN, K_PRE, K_FILL, K_CAM, K_RAYS, K_RAYS_CAM, K_EMBED, K_UP2, K_RESIZE, K_FINAL, K_T };
+enum Kind { K_LIN32, K_ATTS, K_GEMM, K_LN, K_ATTN, K_PRE, K_FILL, K_CAM, K_RAYS, K_RAYS_CAM, K_EMBED, K_UP2, K_RESIZE, K_FINAL, K_T, K_DW7, K_LNP2, K_PATCH4, K_MAX, K_MEAN };
 struct FillArgs { float* dst; const float* src; int n_img, rows_per_img, row_off, D, ld; };
 struct CamArgs { const float* raw; int raw_stride; float* intr4; float* K33; float* Kinv33; float* Kpost33; int B, Hn, Wn; float rf; int pad_l, pad_t; };
 struct RaysArgs { const float* Kinv33; float* rays; int nb, Hn, Wn, gt_mode; };
 struct RaysCamArgs { const float* params; float* rays; float* scratch; int Hn, Wn, model; };
 struct AttSArgs { const float* q; const float* kv; float* out; int B, T, H, C; float scale; };
 struct TArgs { const float* in; float* out; int B, hw, C, ld, rows_per_img; };
+struct LnP2Args { const float* x; void* out; int B, H, W, C, ldo; float eps; };
+struct Patch4Args { const float* img; void* out; int B, H, W, ldo; };
+struct MaxArgs { float* dst; const float* src; long long n; int init; };
+struct MeanArgs { const float* x; float* out; int B, HW, C, ldo; };
 struct Op {
   Kind kind;
   union {
     UdGemm gemm; UdLayerNorm ln; UdAttention attn; UdPreprocess pre; FillArgs fill; CamArgs cam; RaysArgs rays; RaysCamArgs rays_cam;
     UdRayEmbed embed; UdUpsample2x up2; UdResizeAC resize; UdFinalize fin; TArgs t; UdLinearF32 lin32; AttSArgs atts;
+    UdDwConv7 dw7; LnP2Args lnp2; Patch4Args patch4; MaxArgs mx; MeanArgs mean;
   };
   Op() {}
 };
@@ -72,6 +77,24 @@ int ud_program_add_nhwc_to_nchw(UdProgram* p, const float* in, float* out, int B
   ADD(K_T, t, a)
 }
 
+int ud_program_add_dwconv7(UdProgram* p, const UdDwConv7* d) { ADD(K_DW7, dw7, *d) }
+int ud_program_add_layernorm_patchify2(UdProgram* p, const float* x, void* out, int B, int H, int W, int C, int ldo, float eps) {
+  LnP2Args a = {x, out, B, H, W, C, ldo, eps};
+  ADD(K_LNP2, lnp2, a)
+}
+int ud_program_add_patchify4(UdProgram* p, const float* img, void* out, int B, int H, int W, int ldo) {
+  Patch4Args a = {img, out, B, H, W, ldo};
+  ADD(K_PATCH4, patch4, a)
+}
+int ud_program_add_max(UdProgram* p, float* dst, const float* src, long long n, int init) {
+  MaxArgs a = {dst, src, n, init};
+  ADD(K_MAX, mx, a)
+}
+int ud_program_add_spatial_mean(UdProgram* p, const float* x, float* out, int B, int HW, int C, int ldo) {
+  MeanArgs a = {x, out, B, HW, C, ldo};
+  ADD(K_MEAN, mean, a)
+}
+
 int ud_program_run(const UdProgram* p, int first, int last, void* stream) {
   if (!p || first < 0 || last > (int)p->ops.size() || first > last) { ud_set_error("ud_program_run: bad range"); return UD_ERR_BAD_ARG; }
   for (int i = first; i < last; ++i) {
@@ -92,6 +115,11 @@ int ud_program_run(const UdProgram* p, int first, int last, void* stream) {
       case K_UP2: rc = ud_upsample2x_nhwc(&op.up2, stream); break;
       case K_RESIZE: rc = ud_resize_ac_nhwc_f16(&op.resize, stream); break;
       case K_FINAL: rc = ud_finalize_outputs(&op.fin, stream); break;
+      case K_DW7: rc = ud_dwconv7_nhwc_f32(&op.dw7, stream); break;
+      case K_LNP2: rc = ud_layernorm_patchify2(op.lnp2.x, op.lnp2.out, op.lnp2.B, op.lnp2.H, op.lnp2.W, op.lnp2.C, op.lnp2.ldo, op.lnp2.eps, stream); break;
+      case K_PATCH4: rc = ud_patchify4_nchw(op.patch4.img, op.patch4.out, op.patch4.B, op.patch4.H, op.patch4.W, op.patch4.ldo, stream); break;
+      case K_MAX: rc = ud_max_f32(op.mx.dst, op.mx.src, op.mx.n, op.mx.init, stream); break;
+      case K_MEAN: rc = ud_spatial_mean_f32(op.mean.x, op.mean.out, op.mean.B, op.mean.HW, op.mean.C, op.mean.ldo, stream); break;
       case K_T: rc = ud_nhwc_to_nchw_f32(op.t.in, op.t.out, op.t.B, op.t.hw, op.t.C, op.t.ld, op.t.rows_per_img, stream); break;
     }
     if (rc != UD_OK) return rc;

@@ -9,7 +9,7 @@ import torch
 from . import _lib
 from ._lib import (UD_A_CONV3_REFLECT, UD_A_CONV3_ZERO, UD_A_DENSE, UD_ACT_GELU, UD_ACT_LRELU, UD_ACT_NONE,  # noqa: F401
                    UD_EPI_D2S, UD_EPI_F16, UD_EPI_F32, UD_EPI_HEAD, UD_EPI_QKV, UdAttention, UdFinalize, UdGemm,
-                   UdLayerNorm, UdLinearF32, UdPreprocess, UdRayEmbed, UdResizeAC, UdUpsample2x, check, lib)
+                   UdDwConv7, UdLayerNorm, UdLinearF32, UdPreprocess, UdRayEmbed, UdResizeAC, UdUpsample2x, check, lib)
 
 
 def ptr(t):
@@ -168,6 +168,31 @@ class Program:
         self.keep += [src, dst]
         self.meta.append(("misc", "nhwc_to_nchw", 0.0, 8.0 * B * hw * Cc))
         return check(lib.ud_program_add_nhwc_to_nchw(self.h, ptr(src), ptr(dst), B, hw, Cc, ld, rows_per_img))
+
+    # ---- ConvNeXt-side ops (UniDepthV1)
+    def dwconv7(self, **kw):
+        self._k(kw, "dwconv7", 98.0 * kw["B"] * kw["H"] * kw["W"] * kw["C"], 8.0 * kw["B"] * kw["H"] * kw["W"] * kw["C"])
+        return check(lib.ud_program_add_dwconv7(self.h, C.byref(mk(UdDwConv7, **kw))))
+
+    def layernorm_patchify2(self, x, out, B, H, W, Cc, ldo, eps):
+        self.keep += [x, out]
+        self.meta.append(("ln_patchify2", "ln_patchify2", 0.0, 6.0 * B * H * W * Cc))
+        return check(lib.ud_program_add_layernorm_patchify2(self.h, ptr(x), ptr(out), B, H, W, Cc, ldo, eps))
+
+    def patchify4(self, img, out, B, H, W, ldo):
+        self.keep += [img, out]
+        self.meta.append(("misc", "patchify4", 0.0, 0.0))
+        return check(lib.ud_program_add_patchify4(self.h, ptr(img), ptr(out), B, H, W, ldo))
+
+    def max_(self, dst, src, n, init):
+        self.keep += [dst, src]
+        self.meta.append(("max", "max_stack", 0.0, (8.0 if init else 12.0) * n))
+        return check(lib.ud_program_add_max(self.h, ptr(dst), ptr(src), n, int(init)))
+
+    def spatial_mean(self, x, out, B, HW, Cc, ldo):
+        self.keep += [x, out]
+        self.meta.append(("misc", "spatial_mean", 0.0, 4.0 * B * HW * Cc))
+        return check(lib.ud_program_add_spatial_mean(self.h, ptr(x), ptr(out), B, HW, Cc, ldo))
 
     def run(self, first=0, last=None, stream=None):
         last = len(self) if last is None else last
