@@ -155,17 +155,22 @@ def test_hubconf_at_repo_root():
 
 
 def test_hub_entry_point_surface():
-    """hubconf.UniDepth(version, backbone, pretrained) signature (reference hubconf.py:25-41): V2 configs resolve, V1 fails loudly."""
+    """hubconf.UniDepth(version, backbone, pretrained) signature (reference hubconf.py:25-41): V2 configs resolve, v1/cnvnxtl builds the
+    engine's UniDepthV1 (encoder half; its infer() names what is missing), everything else fails loudly."""
     import pytest
     import unidepth_amd
     m = unidepth_amd.UniDepth(version="v2", backbone="vits14", pretrained=False)
     assert type(m).__name__ == "UniDepthV2" and m.shape_constraints["pixels_max"] > m.shape_constraints["pixels_min"]
     with pytest.raises(AssertionError):
         unidepth_amd.UniDepth(version="v2", backbone="cnvnxtl", pretrained=False)
+    m1 = unidepth_amd.UniDepth(version="v1", backbone="cnvnxtl", pretrained=False)
+    assert type(m1).__name__ == "UniDepthV1" and m1.image_shape == [462, 616] and len(m1.embed_dims) == 36 and m1.depths == [3, 6, 33, 36]
     with pytest.raises(NotImplementedError):
-        unidepth_amd.UniDepth(version="v1", backbone="cnvnxtl", pretrained=False)
+        unidepth_amd.UniDepth(version="v1", backbone="vitl14", pretrained=False)
     with pytest.raises(NotImplementedError):
-        unidepth_amd.UniDepthV1({})
+        unidepth_amd.UniDepth(version="v2old", backbone="vitl14", pretrained=False)
+    with pytest.raises(RuntimeError):
+        m1.pixel_encoder(torch.zeros(1, 3, 64, 64))           # no weights / not on a GPU: fails loudly, no CPU path
 
 
 def test_plan_cache_is_an_lru_and_state_resets(monkeypatch):
