@@ -38,6 +38,16 @@ def main():
     d["cls_last4"] = torch.cat([cls[-i - 1] for i in range(4)], dim=-1).numpy()
     np.savez_compressed(os.path.join(OUT, "v1_convnext_128x160.npz"), **d)
     print({k: v.shape for k, v in d.items()})
+    # whole infer(): the reference's own decoder / pre- / post-processing with the restated NystromAttention stub (PARITY UNPINNED there)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT)))
+    from test_oracle_v1_pins import V1_CASES, v1_case_inputs, v1_digest
+    for name in V1_CASES:
+        rgb, K, skip = v1_case_inputs(name)
+        with torch.no_grad():
+            out = model.infer(rgb, K, skip_camera=skip)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **v1_digest({k: v.detach() for k, v in out.items()}))
+        print(name, float(out["depth"].mean()))
 
 
 if __name__ == "__main__":
