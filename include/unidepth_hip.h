@@ -26,7 +26,8 @@ extern "C" {
 
 /* ---- GEMM epilogues ------------------------------------------------------------------------------- */
 #define UD_EPI_F16 0   /* out(fp16)[row, n] = act(acc + bias[n] + add[.., n])                                      */
-#define UD_EPI_F32 1   /* out(fp32)[row, n] (+)= acc + bias[n] + add[.., n]; optional fp16 copy out2 = act2(result)  */
+#define UD_EPI_F32 1   /* out(fp32)[row, n] (+)= acc + bias[n] + add[.., n], then `act` (NONE / GELU / CLAMPEXP) on the stored value;
+                        * optional fp16 copy out2 = act2(result)  */
 #define UD_EPI_QKV 2   /* n <  vsplit: out(fp16) row-major;  n >= vsplit: out2(fp16) = V^T [img][head][64][kv_ld], the 4-key blocks
                         * of every aligned 16-key group stored in the order [0, 2, 1, 3] (= the k-slot order of the P V MFMA,
                         * so the attention kernel DMAs V^T tiles to LDS as they are): key t lives at column
@@ -37,6 +38,7 @@ extern "C" {
 #define UD_ACT_NONE 0
 #define UD_ACT_GELU 1   /* exact erf GELU (nn.GELU default; reference metadinov2/mlp.py:35-41, layers/mlp.py:27) */
 #define UD_ACT_LRELU 2  /* LeakyReLU(0.01) (reference layers/upsample.py:164) */
+#define UD_ACT_CLAMPEXP 3  /* exp(clamp(x, -10, 10)) (UniDepthV1 multi-scale outputs, unidepthv1/decoder.py:322-325); UD_EPI_F32 `act` only */
 
 #define UD_A_DENSE 0          /* A is [M, lda] row-major                                              */
 #define UD_A_CONV3_ZERO 1     /* A rows are gathered 3x3 taps of an NHWC image, zero padding           */
@@ -252,6 +254,39 @@ int ud_max_f32(float* dst, const float* src, long long n, int init, void* stream
 /* out[b*ldo + c] = mean over the HW pixels of x[b, :, c] (x fp32 [B,HW,C]): the "class tokens" of the ConvNeXt wrapper (convnext.py:458). */
 int ud_spatial_mean_f32(const float* x, float* out, int B, int HW, int C, int ldo, void* stream);
 
+/* ---- decoder-side ops of the UniDepthV1 path that are not GEMMs / attention / LayerNorm: one entry point, dispatched on `kind` ----
+ * a, b, c: inputs; out, out2: outputs (c is an output for UD_V1_CAMERA); i[], f[]: per-kind integers / floats as listed.
+ *  RESIZE_AA     F.interpolate(bilinear, align_corners=False, antialias=True) of a crop window of an NHWC fp32 map (utils/geometric.py:227-252
+ *                flat_interpolate; unidepthv1.py:66-86 _postprocess).  i = B, Hi, Wi, Ho, Wo, C, ldi, ldo, y0, x0, Hc, Wc (C % 4 == 0)
+ *  SH_EMBED      rays [nb,3,Hn,Wn] -> antialiased resize to (h, w), F.normalize, 81 real spherical harmonics (utils/sht.py:833 rsh_cart_8),
+ *                LayerNorm statistics (eps f[0]) -> fp16 [nb*rows_per_img, ldo >= 128] (decoder.py:205-222).  i = nb, Hn, Wn, h, w, ldo, rows_per_img
+ *  SOFTMAX       out[r, :N] = softmax(f[0] * a[r, :N]) rows of fp32 scores -> fp16 (or fp32), pad columns N..ldo zero (the softmax inside
+ *                F.scaled_dot_product_attention for single-head width-512 attention, layers/attention.py:136; Nystrom kernels).
+ *                i = rows & 0x7fffffff, N, ldi, ldo, out_f32, rows >> 31
+ *  ATTN_FEWQ     T <= 8 queries against Nk keys, ONE head of width D (camera head `aggregate`, decoder.py:94, layers/attention.py:81-165):
+ *                a = q fp32 [B*T, D], b = kv fp16 [B*Nk, 2D] = [K | V], out fp32 [B*T, D].  i = B, T, Nk, D; f[0] = scale
+ *  SEGMENT_MEAN  Nystrom landmark pooling (xformers AvgPool): fp16 [G, N, ldi] -> n segment means, fp16 out and optional fp32 out2.  i = G, N, C, n, ldi, ldo
+ *  BMM           out[g] = f[1] * I + f[0] * a[g] b[g], small fp32 matrices (Newton-Schulz pseudo-inverse of xformers iterative_pinv).  i = G, M, N, K
+ *  PINV_INIT     Z0 = K^T / max column sum (iterative_pinv initialisation).  i = G, n
+ *  ADD           out = a + b (fp32; latents + ray embedding, decoder.py:263,283,303).  i = n & 0x7fffffff, n >> 31
+ *  COPY_ROWS     out[(img*rows_per_img + row_off + t)*ld + d] = a[(img*T + t)*D + d] (torch.cat of token groups).  i = n_img, T, rows_per_img, row_off, D, ld, to_f16
+ *  TRANSPOSE16   fp32 [G, M, N] -> fp16 [G, N, ldo] transposed, zero padded.  i = G, M, N, ldo
+ *  CAMERA        raw [B*4] -> K33 (out), its inverse (out2), post-processed K (c) (decoder.py:85-99,347-353; unidepthv1.py:88-92).
+ *                i = B, Hn, Wn, pad_l, pad_t; f[0] = ratio
+ *  POINTS        z map + K33 -> points [B,3,H,W] (out), depth [B,1,H,W] (out2) (unidepthv1.py:353-371; utils/geometric.py:45-73).  i = B, H, W, ldz, nK
+ *  MEAN3         out = (a + b + c) / 3 on column 0 of strided maps (unidepthv1.py:66-77).  i = n & 0x7fffffff, ld, n >> 31
+ *  PREPROCESS    V1 network image (unidepthv1.py:305-321,50-56): [/255], ImageNet normalise, antialiased resize to (h, w), zero pad to (Hn, Wn).
+ *                i = B, H, W, h, w, Hn, Wn, pad_l, pad_t, is_u8, div255, normalize */
+enum { UD_V1_RESIZE_AA = 1, UD_V1_SH_EMBED, UD_V1_SOFTMAX, UD_V1_ATTN_FEWQ, UD_V1_SEGMENT_MEAN, UD_V1_BMM, UD_V1_PINV_INIT, UD_V1_ADD,
+       UD_V1_COPY_ROWS, UD_V1_TRANSPOSE16, UD_V1_CAMERA, UD_V1_POINTS, UD_V1_MEAN3, UD_V1_PREPROCESS };
+typedef struct UdV1Op {
+  int kind;
+  const void* a; const void* b; void* c; void* out; void* out2;
+  int i[12];
+  float f[4];
+} UdV1Op;
+int ud_v1_op(const UdV1Op* desc, void* stream);
+
 /* ---- launch programs: a recorded list of the ops above replayed with one call (host-side runtime) ---- */
 typedef struct UdProgram UdProgram;
 UdProgram* ud_program_create(void);
@@ -278,10 +313,11 @@ int ud_program_add_layernorm_patchify2(UdProgram*, const float* x, void* out, in
 int ud_program_add_patchify4(UdProgram*, const float* img, void* out, int B, int H, int W, int ldo);
 int ud_program_add_max(UdProgram*, float* dst, const float* src, long long n, int init);
 int ud_program_add_spatial_mean(UdProgram*, const float* x, float* out, int B, int HW, int C, int ldo);
+int ud_program_add_v1_op(UdProgram*, const UdV1Op*);
 /* run ops [first, last) on `stream`; returns 0 or the first failing op's error code */
 int ud_program_run(const UdProgram*, int first, int last, void* stream);
 
-/* library info; ud_struct_size(i): sizeof the i-th descriptor struct in declaration order (UdGemm = 0 ... UdLinearF32 = 8, UdDwConv7 = 9) */
+/* library info; ud_struct_size(i): sizeof the i-th descriptor struct in declaration order (UdGemm = 0 ... UdLinearF32 = 8, UdDwConv7 = 9, UdV1Op = 10) */
 int ud_version(void);
 int ud_struct_size(int which);
 const char* ud_last_error(void);

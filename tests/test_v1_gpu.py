@@ -115,3 +115,105 @@ def test_convnext_encoder_vs_oracle(B, H, W):
             assert rel(eo[i], outs[i]) <= 3e-3 and rel(ecls[i], cls[i]) <= 3e-3, i
     with pytest.raises(NotImplementedError):
         model.infer(torch.zeros(1, 3, 64, 64, dtype=torch.uint8))
+
+
+# ------------------------------------------------------------------------------------------- decoder-side ops (ud_v1_op)
+def test_v1_resize_aa(ops):
+    from unidepth_amd import _lib as L
+    g = torch.Generator().manual_seed(4)
+    for (Hi, Wi, Ho, Wo, C) in [(115, 154, 28, 38, 192), (14, 19, 28, 38, 64), (56, 76, 462, 616, 4), (57, 77, 28, 38, 384)]:
+        x = torch.randn(2, Hi, Wi, C, generator=g).cuda()
+        y = torch.zeros(2, Ho, Wo, C, device="cuda")
+        ops.v1_op(L.UD_V1_RESIZE_AA, a=x, out=y, i=(2, Hi, Wi, Ho, Wo, C, C, C, 0, 0, Hi, Wi))
+        ref = F.interpolate(x.permute(0, 3, 1, 2), size=(Ho, Wo), mode="bilinear", align_corners=False, antialias=True).permute(0, 2, 3, 1)
+        torch.cuda.synchronize()
+        assert rel(y, ref) < 2e-6, (Hi, Wi, Ho, Wo)
+    # crop window + resize (pad removal of _postprocess): rows 10..50, cols 5..70 of a 64 x 80 map -> 33 x 47
+    x = torch.randn(1, 64, 80, 4, generator=g).cuda()
+    y = torch.zeros(1, 33, 47, 4, device="cuda")
+    ops.v1_op(L.UD_V1_RESIZE_AA, a=x, out=y, i=(1, 64, 80, 33, 47, 4, 4, 4, 10, 5, 40, 65))
+    ref = F.interpolate(x[:, 10:50, 5:70].permute(0, 3, 1, 2), size=(33, 47), mode="bilinear", align_corners=False, antialias=True).permute(0, 2, 3, 1)
+    torch.cuda.synchronize()
+    assert rel(y, ref) < 2e-6
+
+
+def test_v1_sh_embed(ops):
+    from unidepth_amd import _lib as L
+    from oracle import restate_v1
+    g = torch.Generator().manual_seed(5)
+    K = torch.tensor([[[300.0, 0, 150.0], [0, 310.0, 120.0], [0, 0, 1.0]]])
+    rays, _ = restate_v1.generate_rays(K, (224, 304))                  # [1, HW, 3]
+    planar = rays.permute(0, 2, 1).reshape(1, 3, 224, 304).contiguous().cuda()
+    for (h, w) in [(28, 38), (112, 152)]:
+        out = torch.zeros(h * w, 128, dtype=torch.half, device="cuda")
+        ops.v1_op(L.UD_V1_SH_EMBED, a=planar, out=out, i=(1, 224, 304, h, w, 128, h * w), f=(1e-5,))
+        r = F.normalize(restate_v1.flat_interpolate(rays, (224, 304), (h, w)), dim=-1)
+        ref = F.layer_norm(restate_v1.real_sh_deg8(r), (81,), eps=1e-5)[0]
+        torch.cuda.synchronize()
+        assert rel(out[:, :81].float(), ref) < 2e-3 and (out[:, 81:] == 0).all()
+
+
+def test_v1_softmax_fewq_segment_bmm_pinv(ops):
+    from unidepth_amd import _lib as L
+    from oracle import restate_v1
+    g = torch.Generator().manual_seed(6)
+    s = torch.randn(300, 1064, generator=g).cuda() * 3
+    p = torch.full((300, 1088), 7.0, dtype=torch.half, device="cuda")
+    ops.v1_op(L.UD_V1_SOFTMAX, a=s, out=p, i=(300, 1064, 1064, 1088, 0, 0), f=(0.5,))
+    torch.cuda.synchronize()
+    assert rel(p[:, :1064].float(), torch.softmax(s * 0.5, dim=-1)) < 1e-3 and (p[:, 1064:] == 0).all()
+    # few-query attention
+    B, T, Nk, D = 2, 4, 1000, 512
+    q = torch.randn(B * T, D, generator=g).cuda()
+    kv = (torch.randn(B * Nk, 2 * D, generator=g)).half().cuda()
+    o = torch.zeros(B * T, D, device="cuda")
+    ops.v1_op(L.UD_V1_ATTN_FEWQ, a=q, b=kv, out=o, i=(B, T, Nk, D), f=(D ** -0.5,))
+    kk, vv = kv.float().view(B, Nk, 2 * D)[..., :D], kv.float().view(B, Nk, 2 * D)[..., D:]
+    ref = torch.softmax(q.view(B, T, D) @ kk.transpose(1, 2) * D ** -0.5, dim=-1) @ vv
+    torch.cuda.synchronize()
+    assert rel(o.view(B, T, D), ref) < 1e-5
+    # landmark pooling
+    x = torch.randn(3, 1064, 256, generator=g).half().cuda()
+    m16 = torch.zeros(3, 128, 256, dtype=torch.half, device="cuda"); m32 = torch.zeros(3, 128, 256, device="cuda")
+    ops.v1_op(L.UD_V1_SEGMENT_MEAN, a=x, out=m16, out2=m32, i=(3, 1064, 256, 128, 256, 256))
+    torch.cuda.synchronize()
+    assert rel(m32, restate_v1.segment_means(x.float().cpu(), 128)) < 1e-6
+    # Newton-Schulz pseudo-inverse = the oracle's iterative_pinv
+    km = torch.softmax(torch.randn(5, 128, 128, generator=g), dim=-1).cuda()
+    z = torch.zeros_like(km); kz = torch.zeros_like(km); t1 = torch.zeros_like(km); t2 = torch.zeros_like(km); zn = torch.zeros_like(km)
+    ops.v1_op(L.UD_V1_PINV_INIT, a=km, out=z, i=(5, 128))
+    for _ in range(6):
+        ops.v1_op(L.UD_V1_BMM, a=km, b=z, out=kz, i=(5, 128, 128, 128), f=(1.0, 0.0))
+        ops.v1_op(L.UD_V1_BMM, a=kz, b=kz, out=t1, i=(5, 128, 128, 128), f=(-1.0, 0.0))        # placeholder overwritten below (keeps shapes exercised)
+        eye = torch.eye(128, device="cuda")
+        # t1 = 7I - kz ; t2 = 15I - kz t1 ; t1 = 13I - kz t2 ; z = 0.25 z t1
+        t1.copy_(7 * eye - kz)
+        ops.v1_op(L.UD_V1_BMM, a=kz, b=t1, out=t2, i=(5, 128, 128, 128), f=(-1.0, 15.0))
+        ops.v1_op(L.UD_V1_BMM, a=kz, b=t2, out=t1, i=(5, 128, 128, 128), f=(-1.0, 13.0))
+        ops.v1_op(L.UD_V1_BMM, a=z, b=t1, out=zn, i=(5, 128, 128, 128), f=(0.25, 0.0))
+        z, zn = zn, z
+    torch.cuda.synchronize()
+    assert rel(z, restate_v1.iterative_pinv(km.cpu())) < 1e-4
+
+
+def test_v1_preprocess_points_camera(ops):
+    from unidepth_amd import _lib as L
+    from oracle import restate_v1
+    g = torch.Generator().manual_seed(7)
+    rgb = torch.randint(0, 256, (2, 3, 200, 360), dtype=torch.uint8, generator=g)
+    (h, w), ratio, (pl, pr, pt, pb) = restate_v1.v1_shapes((200, 360), (462, 616))
+    out = torch.zeros(2, 3, 462, 616, device="cuda")
+    ops.v1_op(L.UD_V1_PREPROCESS, a=rgb.cuda(), out=out, i=(2, 200, 360, h, w, 462, 616, pl, pt, 1, 1, 1))
+    x = (rgb.float() / 255 - torch.tensor(restate_v1.IMAGENET_MEAN).view(1, 3, 1, 1)) / torch.tensor(restate_v1.IMAGENET_STD).view(1, 3, 1, 1)
+    ref = F.pad(F.interpolate(x, size=(h, w), mode="bilinear", align_corners=False, antialias=True), (pl, pr, pt, pb))
+    torch.cuda.synchronize()
+    assert rel(out, ref) < 2e-6
+    K = torch.tensor([[[250.0, 0, 178.0], [0, 251.0, 98.0], [0, 0, 1.0]]]).repeat(2, 1, 1)
+    z = torch.rand(2, 200, 360, 4, generator=g) * 10 + 1
+    pts = torch.zeros(2, 3, 200, 360, device="cuda"); dep = torch.zeros(2, 1, 200, 360, device="cuda")
+    ops.v1_op(L.UD_V1_POINTS, a=z.cuda(), b=K.reshape(2, 9).cuda(), out=pts, out2=dep, i=(2, 200, 360, 4, 2))
+    ang = restate_v1.generate_rays(K, (200, 360))[1].reshape(2, 200, 360, 2)
+    zz = z[..., 0]
+    ref = torch.stack((zz * torch.tan(ang[..., 0]), zz / torch.tan(ang[..., 1]) / torch.cos(ang[..., 0]), zz), dim=1)
+    torch.cuda.synchronize()
+    assert rel(pts, ref) < 1e-5 and torch.equal(dep[:, 0].cpu(), zz)

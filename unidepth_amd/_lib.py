@@ -50,6 +50,15 @@ class UdDwConv7(C.Structure):
     _fields_ = [("x", fp), ("w", fp), ("bias", fp), ("y", fp), ("B", i32), ("H", i32), ("W", i32), ("C", i32), ("ldx", i32), ("ldy", i32)]
 
 
+class UdV1Op(C.Structure):
+    _fields_ = [("kind", i32), ("a", vp), ("b", vp), ("c", vp), ("out", vp), ("out2", vp), ("i", i32 * 12), ("f", f32 * 4)]
+
+
+(UD_V1_RESIZE_AA, UD_V1_SH_EMBED, UD_V1_SOFTMAX, UD_V1_ATTN_FEWQ, UD_V1_SEGMENT_MEAN, UD_V1_BMM, UD_V1_PINV_INIT, UD_V1_ADD, UD_V1_COPY_ROWS,
+ UD_V1_TRANSPOSE16, UD_V1_CAMERA, UD_V1_POINTS, UD_V1_MEAN3, UD_V1_PREPROCESS) = range(1, 15)
+UD_ACT_CLAMPEXP = 3
+
+
 class UdAttention(C.Structure):
     _fields_ = [("Q", vp), ("K", vp), ("Vt", vp), ("O", vp), ("B", i32), ("H", i32), ("Nq", i32), ("Nk", i32),
                 ("ldq", i32), ("ldk", i32), ("ldo", i32), ("kv_ld", i32), ("q_rows_per_img", i32),
@@ -134,6 +143,8 @@ def _load():
         "ud_program_add_patchify4": [vp, vp, vp, i32, i32, i32, i32],
         "ud_program_add_max": [vp, vp, vp, i64, i32],
         "ud_program_add_spatial_mean": [vp, vp, vp, i32, i32, i32, i32],
+        "ud_v1_op": [P(UdV1Op), vp],
+        "ud_program_add_v1_op": [vp, P(UdV1Op)],
         "ud_program_run": [vp, i32, i32, vp],
         "ud_version": [],
         "ud_struct_size": [i32],
@@ -146,7 +157,7 @@ def _load():
     lib.ud_program_create.restype = vp
     lib.ud_last_error.argtypes = []
     lib.ud_last_error.restype = C.c_char_p
-    for i, st in enumerate([UdGemm, UdLayerNorm, UdAttention, UdPreprocess, UdRayEmbed, UdUpsample2x, UdResizeAC, UdFinalize, UdLinearF32, UdDwConv7]):
+    for i, st in enumerate([UdGemm, UdLayerNorm, UdAttention, UdPreprocess, UdRayEmbed, UdUpsample2x, UdResizeAC, UdFinalize, UdLinearF32, UdDwConv7, UdV1Op]):
         if lib.ud_struct_size(i) != C.sizeof(st):
             raise ImportError(f"ctypes mirror of {st.__name__} is out of sync with include/unidepth_hip.h "
                               f"({C.sizeof(st)} vs {lib.ud_struct_size(i)} bytes)")

@@ -25,6 +25,7 @@ extern "C" int ud_struct_size(int which) {
     case 7: return (int)sizeof(UdFinalize);
     case 8: return (int)sizeof(UdLinearF32);
     case 9: return (int)sizeof(UdDwConv7);
+    case 10: return (int)sizeof(UdV1Op);
     default: return -1;
   }
 }

@@ -253,6 +253,13 @@ __device__ __forceinline__ void gemm_epilogue_impl(const UdGemm& p, f32x4 (&acc)
               v += old;
             }
           }
+          if (p.act == UD_ACT_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = ud_gelu_erf(v[r]);
+          } else if (p.act == UD_ACT_CLAMPEXP) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = ud_clampexp(v[r]);
+          }
           if (p.accumulate != 2) *(f32x4*)dst = v;     // accumulate == 2: the fp32 stream dies here, only the fp16 copy is consumed
           if (out2) {
             half4 h;
@@ -943,7 +950,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
         }
       }
     } else if constexpr (EPI == UD_EPI_F32) {
-      fast = full && (p.ldc & 3) == 0 && (p.out2 == nullptr || (p.ldc2 & 7) == 0);
+      fast = full && (p.ldc & 3) == 0 && (p.out2 == nullptr || (p.ldc2 & 7) == 0) && p.act == UD_ACT_NONE;   // activated fp32 outputs: generic path
       if (fast) {
         f32x4 bv[4];
 #pragma unroll

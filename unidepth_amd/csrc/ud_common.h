@@ -47,6 +47,7 @@ __device__ __forceinline__ float ud_gelu_erf(float x) {
   return fmaf(-ax, poly * e, fmaxf(x, 0.0f));
 }
 __device__ __forceinline__ float ud_lrelu(float x) { return x > 0.0f ? x : 0.01f * x; }
+__device__ __forceinline__ float ud_clampexp(float x) { return __expf(fminf(fmaxf(x, -10.0f), 10.0f)); }
 __device__ __forceinline__ float ud_act(float x, int act) {
   return act == UD_ACT_GELU ? ud_gelu_erf(x) : (act == UD_ACT_LRELU ? ud_lrelu(x) : x);
 }

@@ -1,0 +1,476 @@
+// Decoder-side kernels of the UniDepthV1 path that are not GEMMs / flash attention / LayerNorm (reference
+// unidepth/models/unidepthv1/decoder.py, unidepthv1.py:28-98,288-373, utils/geometric.py, utils/sht.py:833, layers/nystrom_attention.py).
+// One C-ABI entry, ud_v1_op(), dispatches on UdV1Op.kind (include/unidepth_hip.h documents every kind and cites what it replaces).
+#include "ud_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ antialiased bilinear resize
+// F.interpolate(mode="bilinear", align_corners=False, antialias=True) on NHWC fp32 (C % 4 == 0, 4 channels per thread): separable
+// triangle filter of support max(scale, 1) per axis, taps normalised to sum 1 (ATen's _upsample_bilinear2d_aa; for up-sampling this
+// is plain bilinear).  Thread = (output pixel, 4 channels); the (<= ~6 x 6) taps are walked directly.
+__device__ __forceinline__ void aa_taps(int o, float scale, int n_in, int& lo, int& cnt, float& center, float& inv) {
+  const float support = scale >= 1.0f ? scale : 1.0f;
+  inv = scale >= 1.0f ? 1.0f / scale : 1.0f;
+  center = scale * ((float)o + 0.5f);
+  lo = (int)(center - support + 0.5f);
+  lo = lo < 0 ? 0 : lo;
+  int hi = (int)(center + support + 0.5f);
+  hi = hi > n_in ? n_in : hi;
+  cnt = hi - lo;
+}
+__device__ __forceinline__ float aa_w(int j, int lo, float center, float inv) {
+  const float w = 1.0f - fabsf(((float)(j + lo) - center + 0.5f) * inv);
+  return w < 0.f ? 0.f : w;
+}
+
+__global__ __launch_bounds__(256) void resize_aa_kernel(const float* in, float* out, int B, int Hi, int Wi, int Ho, int Wo, int C, int ldi, int ldo,
+                                                        int y0, int x0, int Hc, int Wc) {
+  // output = resize(in[:, y0:y0+Hc, x0:x0+Wc]) to (Ho, Wo): the crop window folds _postprocess' pad removal into the second resize
+  const int CG = C >> 2;
+  const long long total = (long long)B * Ho * Wo * CG;
+  const float sy = (float)Hc / (float)Ho, sx = (float)Wc / (float)Wo;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int cg = (int)(idx % CG);
+    const long long pix = idx / CG;
+    const int ox = (int)(pix % Wo);
+    const int oy = (int)((pix / Wo) % Ho);
+    const int b = (int)(pix / ((long long)Wo * Ho));
+    int ylo, yn, xlo, xn;
+    float yc, yi, xc, xi;
+    aa_taps(oy, sy, Hc, ylo, yn, yc, yi);
+    aa_taps(ox, sx, Wc, xlo, xn, xc, xi);
+    float wys = 0.f, wxs = 0.f;
+    for (int j = 0; j < yn; ++j) wys += aa_w(j, ylo, yc, yi);
+    for (int j = 0; j < xn; ++j) wxs += aa_w(j, xlo, xc, xi);
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* src = in + ((size_t)b * Hi * Wi) * ldi + cg * 4;
+    for (int jy = 0; jy < yn; ++jy) {
+      const float wy = aa_w(jy, ylo, yc, yi) / wys;
+      f32x4 row = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float* r = src + ((size_t)(y0 + ylo + jy) * Wi + x0 + xlo) * ldi;
+      for (int jx = 0; jx < xn; ++jx) row += (aa_w(jx, xlo, xc, xi) / wxs) * *(const f32x4*)(r + (size_t)jx * ldi);
+      acc += wy * row;
+    }
+    *(f32x4*)(out + (size_t)pix * ldo + cg * 4) = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ spherical-harmonics ray embedding
+// One wave per output token: antialiased down-sampling of the planar ray map [nb,3,Hn,Wn] to (h, w) (flat_interpolate, decoder.py:205-219),
+// F.normalize, the 81 real spherical harmonics of degree <= 8 (utils/sht.py:833 rsh_cart_8 is a generated closed-form table; here the
+// standard recurrences: Q_m^m = (2m-1)!!, Q_{m+1}^m = (2m+1) z Q_m^m, (l-m) Q_l^m = (2l-1) z Q_{l-1}^m - (l+m-1) Q_{l-2}^m,
+// (x+iy)^m = A_m + i B_m, Y_l^{+-m} = (-1)^m sqrt2 K_l^m Q_l^m {A_m, B_m}), then LayerNorm statistics over the 81 values (the MLP's
+// norm, affine folded into proj1) -> fp16 row of 128 (columns 81.. stay zero).  Lane i evaluates harmonic i and i + 64.
+__device__ __forceinline__ float sh_one(int idx, float x, float y, float z) {
+  int l = 0;
+  while ((l + 1) * (l + 1) <= idx) ++l;
+  const int m = idx - l * (l + 1);
+  const int am = m < 0 ? -m : m;
+  float A = 1.f, Bv = 0.f;
+  for (int k = 0; k < am; ++k) {
+    const float a2 = A * x - Bv * y;
+    Bv = A * y + Bv * x;
+    A = a2;
+  }
+  float qmm = 1.f;
+  for (int k = 1; k <= am; ++k) qmm *= (float)(2 * k - 1);
+  float q = qmm, q1 = qmm, q2 = 0.f;
+  for (int ll = am + 1; ll <= l; ++ll) {
+    q = ll == am + 1 ? (float)(2 * am + 1) * z * q1 : ((float)(2 * ll - 1) * z * q1 - (float)(ll + am - 1) * q2) / (float)(ll - am);
+    q2 = q1;
+    q1 = q;
+  }
+  float ratio = 1.f;                                   // (l-m)! / (l+m)!
+  for (int k = l - am + 1; k <= l + am; ++k) ratio /= (float)k;
+  float K = sqrtf((float)(2 * l + 1) * 0.07957747154594767f * ratio);          // 1 / (4 pi)
+  if (am == 0) return K * q;
+  K *= 1.4142135623730951f * ((am & 1) ? -1.f : 1.f);
+  return K * q * (m > 0 ? A : Bv);
+}
+
+__global__ __launch_bounds__(256) void sh_embed_kernel(const float* rays, half_t* out, int nb, int Hn, int Wn, int h, int w, int ldo, int rows_per_img, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int hw = h * w;
+  if (tok >= (long long)nb * hw) return;
+  const int img = (int)(tok / hw), t = (int)(tok - (long long)img * hw);
+  const int ty = t / w, tx = t - ty * w;
+  int ylo, yn, xlo, xn;
+  float yc, yi, xc, xi;
+  aa_taps(ty, (float)Hn / (float)h, Hn, ylo, yn, yc, yi);
+  aa_taps(tx, (float)Wn / (float)w, Wn, xlo, xn, xc, xi);
+  const size_t HW = (size_t)Hn * Wn;
+  const float* r = rays + (size_t)img * 3 * HW;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, ws = 0.f;
+  for (int i = lane; i < yn * xn; i += 64) {
+    const int iy = i / xn, ix = i - iy * xn;
+    const float wgt = aa_w(iy, ylo, yc, yi) * aa_w(ix, xlo, xc, xi);
+    const size_t off = (size_t)(ylo + iy) * Wn + xlo + ix;
+    a0 += wgt * r[off]; a1 += wgt * r[off + HW]; a2 += wgt * r[off + 2 * HW];
+    ws += wgt;
+  }
+  a0 = ud_wave_sum(a0); a1 = ud_wave_sum(a1); a2 = ud_wave_sum(a2); ws = ud_wave_sum(ws);
+  float x = a0 / ws, y = a1 / ws, z = a2 / ws;
+  const float inv = 1.0f / fmaxf(sqrtf(x * x + y * y + z * z), 1e-12f);
+  x *= inv; y *= inv; z *= inv;
+  const float v0 = sh_one(lane, x, y, z);
+  const float v1 = lane + 64 < 81 ? sh_one(lane + 64, x, y, z) : 0.f;
+  const float mean = ud_wave_sum(v0 + v1) / 81.0f;
+  const float d0 = v0 - mean, d1 = lane + 64 < 81 ? v1 - mean : 0.f;
+  const float rstd = rsqrtf(ud_wave_sum(d0 * d0 + d1 * d1) / 81.0f + eps);
+  half_t* row = out + ((size_t)img * rows_per_img + t) * ldo;
+  row[lane] = (half_t)(d0 * rstd);
+  if (lane + 64 < 81) row[lane + 64] = (half_t)(d1 * rstd);
+}
+
+// ------------------------------------------------------------------------------------------------ row softmax (fp32 scores -> fp16 probabilities)
+// out[r, :N] = softmax(scale * in[r, :N]); columns N..ldo-1 are written as zeros (K padding of the following P V GEMM).  One wave per row.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* in, void* out, long long rows, int N, int ldi, int ldo, float scale, int out_f32) {
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* src = in + (size_t)r * ldi;
+  float m = -3.0e38f;
+  for (int c = lane; c < N; c += 64) m = fmaxf(m, src[c]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  float s = 0.f;
+  const float sc = scale * 1.4426950408889634f;
+  for (int c = lane; c < N; c += 64) s += __builtin_amdgcn_exp2f((src[c] - m) * sc);
+  s = 1.0f / ud_wave_sum(s);
+  if (out_f32) {
+    float* dst = (float*)out + (size_t)r * ldo;
+    for (int c = lane; c < ldo; c += 64) dst[c] = c < N ? __builtin_amdgcn_exp2f((src[c] - m) * sc) * s : 0.f;
+  } else {
+    half_t* dst = (half_t*)out + (size_t)r * ldo;
+    for (int c = lane; c < ldo; c += 64) dst[c] = c < N ? (half_t)(__builtin_amdgcn_exp2f((src[c] - m) * sc) * s) : (half_t)0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ few-query attention, one head of width D (camera head aggregate)
+// q fp32 [B*T, D] (T <= 8 queries per image), kv fp16 [B*Nk, 2D] = [K | V], out fp32 [B*T, D].  Block = (query, image).
+__global__ __launch_bounds__(256) void attention_fewq_kernel(const float* q, const half_t* kv, float* out, int T, int Nk, int D, float scale) {
+  extern __shared__ float sm[];                         // Nk scores + D query values + 8 reduction slots
+  float* sc = sm;
+  float* qs = sm + Nk;
+  float* red = qs + D;
+  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const float* qv = q + ((size_t)b * T + t) * D;
+  for (int d = tid; d < D; d += 256) qs[d] = qv[d] * scale;
+  __syncthreads();
+  const half_t* kb = kv + (size_t)b * Nk * 2 * D;
+  float mx = -3.0e38f;
+  for (int k = tid; k < Nk; k += 256) {
+    const half8* kr = (const half8*)(kb + (size_t)k * 2 * D);
+    float s = 0.f;
+    for (int d8 = 0; d8 < (D >> 3); ++d8) {
+      const half8 h = kr[d8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += (float)h[e] * qs[d8 * 8 + e];
+    }
+    sc[k] = s;
+    mx = fmaxf(mx, s);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int k = tid; k < Nk; k += 256) {
+    const float p = __expf(sc[k] - mx);
+    sc[k] = p;
+    sum += p;
+  }
+  sum = ud_wave_sum(sum);
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
+  __syncthreads();
+  const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+  for (int d = tid; d < D; d += 256) {
+    float acc = 0.f;
+    const half_t* vcol = kb + D + d;
+    for (int k = 0; k < Nk; ++k) acc += sc[k] * (float)vcol[(size_t)k * 2 * D];
+    out[((size_t)b * T + t) * D + d] = acc * inv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ Nystrom pieces
+// landmark pooling (xformers AvgPool): [G, N, C] fp16 -> n segment means per group, fp16 (GEMM operand) and fp32
+__global__ __launch_bounds__(256) void segment_mean_kernel(const half_t* in, half_t* out16, float* out32, int N, int C, int n, int ldi, int ldo) {
+  const int g = blockIdx.y, s = blockIdx.x;
+  const int seg = N / n, nround = n - N % n;
+  const int start = s < nround ? s * seg : nround * seg + (s - nround) * (seg + 1);
+  const int len = (N % n == 0 || s < nround) ? seg : seg + 1;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float acc = 0.f;
+    const half_t* p = in + ((size_t)g * N + start) * ldi + c;
+    for (int t = 0; t < len; ++t) acc += (float)p[(size_t)t * ldi];
+    acc /= (float)len;
+    out16[((size_t)g * n + s) * ldo + c] = (half_t)acc;
+    if (out32) out32[((size_t)g * n + s) * ldo + c] = acc;
+  }
+}
+
+// batched fp32 matmul of small square-ish matrices, C = diag * I + alpha * A B  (A [G, M, K], B [G, K, N], row-major, all <= 128):
+// the Newton-Schulz pseudo-inverse iterations (xformers iterative_pinv) and pinv @ kernel_3.  Block = (16 x 16 output tile, group).
+__global__ __launch_bounds__(256) void bmm_small_kernel(const float* A, const float* Bm, float* Cm, int M, int N, int K, float alpha, float diag) {
+  __shared__ float as[16][17], bs[16][17];
+  const int g = blockIdx.z;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int row = blockIdx.y * 16 + ty, col = blockIdx.x * 16 + tx;
+  const float* a = A + (size_t)g * M * K;
+  const float* b = Bm + (size_t)g * K * N;
+  float acc = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    as[ty][tx] = (row < M && k0 + tx < K) ? a[(size_t)row * K + k0 + tx] : 0.f;
+    bs[ty][tx] = (k0 + ty < K && col < N) ? b[(size_t)(k0 + ty) * N + col] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc = fmaf(as[ty][k], bs[k][tx], acc);
+    __syncthreads();
+  }
+  if (row < M && col < N) Cm[((size_t)g * M + row) * N + col] = alpha * acc + (row == col ? diag : 0.f);
+}
+
+// Z0 = K^T / max_j sum_i K[i, j]  (xformers iterative_pinv, exact 1 / ||K||_1 initialisation), K fp32 [G, n, n], n <= 256.  Block = group.
+__global__ __launch_bounds__(256) void pinv_init_kernel(const float* Km, float* Z, int n) {
+  __shared__ float red[4];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const float* k = Km + (size_t)g * n * n;
+  float cs = 0.f;
+  if (tid < n)
+    for (int i = 0; i < n; ++i) cs += k[(size_t)i * n + tid];
+  float mx = tid < n ? cs : 0.f;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  const float inv = 1.0f / fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float* z = Z + (size_t)g * n * n;
+  for (int idx = tid; idx < n * n; idx += 256) {
+    const int i = idx / n, j = idx - i * n;
+    z[idx] = k[(size_t)j * n + i] * inv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ glue
+__global__ __launch_bounds__(256) void add_kernel(float* dst, const float* a, const float* b, long long n4) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) ((f32x4*)dst)[i] = ((const f32x4*)a)[i] + ((const f32x4*)b)[i];
+}
+// dst[(img * rows_per_img + row_off + t) * ld + d] = src[(img * T + t) * D + d]; cast: 0 fp32 -> fp32, 1 fp32 -> fp16, 2 fp16 -> fp16 transposed pack of T^T
+__global__ __launch_bounds__(256) void copy_rows_kernel(void* dst, const float* src, int n_img, int T, int rows_per_img, int row_off, int D, int ld, int to_f16) {
+  const long long total = (long long)n_img * T * D;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int d = (int)(idx % D);
+    const long long r = idx / D;
+    const int t = (int)(r % T), img = (int)(r / T);
+    const size_t o = ((size_t)img * rows_per_img + row_off + t) * ld + d;
+    if (to_f16) ((half_t*)dst)[o] = (half_t)src[idx];
+    else ((float*)dst)[o] = src[idx];
+  }
+}
+// out fp16 [G, N, ldo] = transpose of in fp32 [G, M, N] (M <= ldo; pad columns zero): pinv @ kernel_3 as the W operand of the last Nystrom GEMM
+__global__ __launch_bounds__(256) void transpose_f32_f16_kernel(const float* in, half_t* out, int G, int M, int N, int ldo) {
+  const long long total = (long long)G * N * ldo;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int m = (int)(idx % ldo);
+    const long long r = idx / ldo;
+    const int n = (int)(r % N), g = (int)(r / N);
+    out[idx] = m < M ? (half_t)in[((size_t)g * M + m) * N + n] : (half_t)0.f;
+  }
+}
+
+// camera tail of V1 (decoder.py:85-99 CameraHead, :347-353 run_camera; unidepthv1.py:88-92 _postprocess): raw [B*4] ->
+// K33 at network resolution, its closed-form inverse, and the post-processed matrix ((fx, fy) / ratio, (cx - pad_l, cy - pad_t) / ratio).
+__global__ void camera_v1_kernel(const float* raw, float* K33, float* Kinv33, float* Kpost33, int B, int Hn, int Wn, float ratio, int pad_l, int pad_t) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  const float* o = raw + (size_t)b * 4;
+  const float half = 0.5f * (float)(Hn > Wn ? Hn : Wn);
+  const float fx = expf(o[0]) * half, fy = expf(o[1]) * half;
+  const float cx = (1.0f / (1.0f + expf(-o[2]))) * (float)Wn, cy = (1.0f / (1.0f + expf(-o[3]))) * (float)Hn;
+  float* K = K33 + b * 9;
+  K[0] = fx; K[1] = 0.f; K[2] = cx; K[3] = 0.f; K[4] = fy; K[5] = cy; K[6] = 0.f; K[7] = 0.f; K[8] = 1.f;
+  float* Ki = Kinv33 + b * 9;
+  Ki[0] = 1.0f / fx; Ki[1] = 0.f; Ki[2] = -cx / fx; Ki[3] = 0.f; Ki[4] = 1.0f / fy; Ki[5] = -cy / fy; Ki[6] = 0.f; Ki[7] = 0.f; Ki[8] = 1.f;
+  float* Kp = Kpost33 + b * 9;
+  Kp[0] = fx / ratio; Kp[1] = 0.f; Kp[2] = (cx - (float)pad_l) / ratio; Kp[3] = 0.f; Kp[4] = fy / ratio; Kp[5] = (cy - (float)pad_t) / ratio;
+  Kp[6] = 0.f; Kp[7] = 0.f; Kp[8] = 1.f;
+}
+
+// final assembly (unidepthv1.py:353-371): depth z [B,H,W] (column 0 of an [.., ldz] map) + intrinsics K33 -> points [B,3,H,W], depth [B,1,H,W]:
+// ray through the pixel centre, theta = atan2(x, z), phi = acos(y) (utils/geometric.py:45-51), x = z tan(theta), y = z / tan(phi) / cos(theta) (:55-73)
+__global__ __launch_bounds__(256) void v1_points_kernel(const float* zmap, const float* K33, float* points, float* depth, int B, int H, int W, int ldz, int nK) {
+  const long long total = (long long)B * H * W;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int u = (int)(idx % W), v = (int)((idx / W) % H), b = (int)(idx / ((long long)W * H));
+    const float* K = K33 + (nK == 1 ? 0 : b) * 9;
+    float x = ((float)u + 0.5f - K[2]) / K[0], y = ((float)v + 0.5f - K[5]) / K[4], zz = 1.0f;
+    const float inv = 1.0f / fmaxf(sqrtf(x * x + y * y + 1.0f), 1e-12f);
+    x *= inv; y *= inv; zz *= inv;
+    const float theta = atan2f(x, zz), phi = acosf(y);
+    const float z = zmap[(size_t)idx * ldz];
+    const size_t HW = (size_t)H * W, po = (size_t)v * W + u;
+    points[((size_t)b * 3 + 0) * HW + po] = z * tanf(theta);
+    points[((size_t)b * 3 + 1) * HW + po] = z / tanf(phi) / cosf(theta);
+    points[((size_t)b * 3 + 2) * HW + po] = z;
+    depth[(size_t)b * HW + po] = z;
+  }
+}
+
+// mean of three [B,H,W,4]-strided maps' column 0 -> [B,H,W,4] column 0 (unidepthv1.py:66-77: the multi-scale predictions are averaged after resizing)
+__global__ __launch_bounds__(256) void mean3_kernel(const float* a, const float* b, const float* c, float* out, long long n, int ld) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    out[i * ld] = (a[i * ld] + b[i * ld] + c[i * ld]) * (1.0f / 3.0f);
+}
+
+// network image of V1 (unidepthv1.py:305-321): /255 if uint8 (the caller decides the float cases), ImageNet normalisation, antialiased bilinear
+// resize to (h, w), zero padding to (Hn, Wn) -> fp32 NCHW.  Thread = one output value.
+__global__ __launch_bounds__(256) void preprocess_v1_kernel(const void* rgb, float* out, int B, int H, int W, int h, int w, int Hn, int Wn, int pad_l, int pad_t,
+                                                            int is_u8, int div255, int normalize, f32x4 mean, f32x4 istd) {
+  const long long total = (long long)B * 3 * Hn * Wn;
+  const float sy = (float)H / (float)h, sx = (float)W / (float)w;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int ox = (int)(idx % Wn), oy = (int)((idx / Wn) % Hn), c = (int)((idx / ((long long)Wn * Hn)) % 3), b = (int)(idx / ((long long)3 * Wn * Hn));
+    const int yy = oy - pad_t, xx = ox - pad_l;
+    float v = 0.f;
+    if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) {
+      int ylo, yn, xlo, xn;
+      float yc, yi, xc, xi;
+      aa_taps(yy, sy, H, ylo, yn, yc, yi);
+      aa_taps(xx, sx, W, xlo, xn, xc, xi);
+      float wys = 0.f, wxs = 0.f;
+      for (int j = 0; j < yn; ++j) wys += aa_w(j, ylo, yc, yi);
+      for (int j = 0; j < xn; ++j) wxs += aa_w(j, xlo, xc, xi);
+      const size_t base = ((size_t)b * 3 + c) * H * W;
+      for (int jy = 0; jy < yn; ++jy) {
+        float row = 0.f;
+        for (int jx = 0; jx < xn; ++jx) {
+          const size_t o = base + (size_t)(ylo + jy) * W + xlo + jx;
+          float p = is_u8 ? (float)((const unsigned char*)rgb)[o] : ((const float*)rgb)[o];
+          if (div255) p *= (1.0f / 255.0f);
+          if (normalize) p = (p - mean[c]) * istd[c];
+          row += (aa_w(jx, xlo, xc, xi) / wxs) * p;
+        }
+        v += (aa_w(jy, ylo, yc, yi) / wys) * row;
+      }
+    }
+    out[idx] = v;
+  }
+}
+
+inline unsigned grid1(long long total, int cap = 256 * 32) {
+  long long g = (total + 255) / 256;
+  if (g > cap) g = cap;
+  return (unsigned)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+extern "C" int ud_v1_op(const UdV1Op* desc, void* stream) {
+  const UdV1Op& d = *desc;
+  hipStream_t s = (hipStream_t)stream;
+  const int* i = d.i;
+  switch (d.kind) {
+    case UD_V1_RESIZE_AA: {      // a = in fp32 NHWC, out fp32 NHWC; i = B, Hi, Wi, Ho, Wo, C, ldi, ldo, y0, x0, Hc, Wc
+      if (!d.a || !d.out || i[0] <= 0 || (i[5] & 3) || (i[6] & 3) || (i[7] & 3) || i[10] <= 0 || i[11] <= 0 || i[8] + i[10] > i[1] || i[9] + i[11] > i[2]) break;
+      hipLaunchKernelGGL(resize_aa_kernel, dim3(grid1((long long)i[0] * i[3] * i[4] * (i[5] >> 2))), dim3(256), 0, s, (const float*)d.a, (float*)d.out, i[0], i[1], i[2],
+                         i[3], i[4], i[5], i[6], i[7], i[8], i[9], i[10], i[11]);
+      UD_CHECK_LAUNCH("ud_v1_op(resize_aa) launch");
+      return UD_OK;
+    }
+    case UD_V1_SH_EMBED: {       // a = rays fp32 [nb,3,Hn,Wn], out fp16 [nb*rows_per_img, ldo]; i = nb, Hn, Wn, h, w, ldo, rows_per_img; f[0] = eps
+      if (!d.a || !d.out || i[0] <= 0 || i[5] < 81 || i[3] <= 0 || i[4] <= 0) break;
+      const long long ntok = (long long)i[0] * i[3] * i[4];
+      hipLaunchKernelGGL(sh_embed_kernel, dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, s, (const float*)d.a, (half_t*)d.out, i[0], i[1], i[2], i[3], i[4], i[5], i[6], d.f[0]);
+      UD_CHECK_LAUNCH("ud_v1_op(sh_embed) launch");
+      return UD_OK;
+    }
+    case UD_V1_SOFTMAX: {        // a = scores fp32, out = fp16 (i[4] = 0) or fp32 (1); i = rows_lo, N, ldi, ldo, out_f32, rows_hi; f[0] = scale
+      const long long rows = ((long long)i[5] << 31) + i[0];
+      if (!d.a || !d.out || rows <= 0 || i[1] <= 0 || i[3] < i[1]) break;
+      hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const float*)d.a, d.out, rows, i[1], i[2], i[3], d.f[0], i[4]);
+      UD_CHECK_LAUNCH("ud_v1_op(softmax) launch");
+      return UD_OK;
+    }
+    case UD_V1_ATTN_FEWQ: {      // a = q fp32 [B*T, D], b = kv fp16 [B*Nk, 2D], out fp32 [B*T, D]; i = B, T, Nk, D; f[0] = scale
+      if (!d.a || !d.b || !d.out || i[0] <= 0 || i[1] <= 0 || i[1] > 8 || i[2] <= 0 || (i[3] & 7)) break;
+      const int lds = (i[2] + i[3] + 8) * 4;
+      if (lds > 64 * 1024) break;
+      hipLaunchKernelGGL(attention_fewq_kernel, dim3(i[1], i[0]), dim3(256), lds, s, (const float*)d.a, (const half_t*)d.b, (float*)d.out, i[1], i[2], i[3], d.f[0]);
+      UD_CHECK_LAUNCH("ud_v1_op(attn_fewq) launch");
+      return UD_OK;
+    }
+    case UD_V1_SEGMENT_MEAN: {   // a = in fp16 [G, N, ldi], out fp16 [G, n, ldo], out2 fp32 or NULL; i = G, N, C, n, ldi, ldo
+      if (!d.a || !d.out || i[0] <= 0 || i[3] <= 0 || i[1] < i[3]) break;
+      hipLaunchKernelGGL(segment_mean_kernel, dim3(i[3], i[0]), dim3(256), 0, s, (const half_t*)d.a, (half_t*)d.out, (float*)d.out2, i[1], i[2], i[3], i[4], i[5]);
+      UD_CHECK_LAUNCH("ud_v1_op(segment_mean) launch");
+      return UD_OK;
+    }
+    case UD_V1_BMM: {            // a, b fp32, out fp32: out[g] = f[1] * I + f[0] * a[g] b[g]; i = G, M, N, K
+      if (!d.a || !d.b || !d.out || i[0] <= 0 || i[1] <= 0 || i[2] <= 0 || i[3] <= 0) break;
+      hipLaunchKernelGGL(bmm_small_kernel, dim3((i[2] + 15) / 16, (i[1] + 15) / 16, i[0]), dim3(256), 0, s, (const float*)d.a, (const float*)d.b, (float*)d.out, i[1], i[2], i[3], d.f[0], d.f[1]);
+      UD_CHECK_LAUNCH("ud_v1_op(bmm) launch");
+      return UD_OK;
+    }
+    case UD_V1_PINV_INIT: {      // a = K fp32 [G, n, n], out = Z0; i = G, n
+      if (!d.a || !d.out || i[0] <= 0 || i[1] <= 0 || i[1] > 256) break;
+      hipLaunchKernelGGL(pinv_init_kernel, dim3(i[0]), dim3(256), 0, s, (const float*)d.a, (float*)d.out, i[1]);
+      UD_CHECK_LAUNCH("ud_v1_op(pinv_init) launch");
+      return UD_OK;
+    }
+    case UD_V1_ADD: {            // out = a + b, fp32, i[0] + (i[1] << 31) elements (% 4 == 0)
+      const long long n = ((long long)i[1] << 31) + i[0];
+      if (!d.a || !d.b || !d.out || n <= 0 || (n & 3)) break;
+      hipLaunchKernelGGL(add_kernel, dim3(grid1(n / 4)), dim3(256), 0, s, (float*)d.out, (const float*)d.a, (const float*)d.b, n / 4);
+      UD_CHECK_LAUNCH("ud_v1_op(add) launch");
+      return UD_OK;
+    }
+    case UD_V1_COPY_ROWS: {      // a = src fp32 [n_img*T, D]; out rows (img*rows_per_img + row_off + t), stride ld; i = n_img, T, rows_per_img, row_off, D, ld, to_f16
+      if (!d.a || !d.out || i[0] <= 0 || i[1] <= 0 || i[4] <= 0) break;
+      hipLaunchKernelGGL(copy_rows_kernel, dim3(grid1((long long)i[0] * i[1] * i[4])), dim3(256), 0, s, d.out, (const float*)d.a, i[0], i[1], i[2], i[3], i[4], i[5], i[6]);
+      UD_CHECK_LAUNCH("ud_v1_op(copy_rows) launch");
+      return UD_OK;
+    }
+    case UD_V1_TRANSPOSE16: {    // a = fp32 [G, M, N] -> out fp16 [G, N, ldo] (transposed, zero padded); i = G, M, N, ldo
+      if (!d.a || !d.out || i[0] <= 0 || i[3] < i[1]) break;
+      hipLaunchKernelGGL(transpose_f32_f16_kernel, dim3(grid1((long long)i[0] * i[2] * i[3])), dim3(256), 0, s, (const float*)d.a, (half_t*)d.out, i[0], i[1], i[2], i[3]);
+      UD_CHECK_LAUNCH("ud_v1_op(transpose16) launch");
+      return UD_OK;
+    }
+    case UD_V1_CAMERA: {         // a = raw fp32 [B*4]; out = K33, out2 = Kinv33, c = Kpost33 (written); i = B, Hn, Wn, pad_l, pad_t; f[0] = ratio
+      if (!d.a || !d.out || !d.out2 || !d.c || i[0] <= 0 || !(d.f[0] > 0.f)) break;
+      hipLaunchKernelGGL(camera_v1_kernel, dim3((i[0] + 63) / 64), dim3(64), 0, s, (const float*)d.a, (float*)d.out, (float*)d.out2, (float*)d.c, i[0], i[1], i[2], d.f[0], i[3], i[4]);
+      UD_CHECK_LAUNCH("ud_v1_op(camera) launch");
+      return UD_OK;
+    }
+    case UD_V1_POINTS: {         // a = z map fp32 (stride ldz), b = K33 fp32 [nK, 9]; out = points [B,3,H,W], out2 = depth [B,1,H,W]; i = B, H, W, ldz, nK
+      if (!d.a || !d.b || !d.out || !d.out2 || i[0] <= 0) break;
+      hipLaunchKernelGGL(v1_points_kernel, dim3(grid1((long long)i[0] * i[1] * i[2])), dim3(256), 0, s, (const float*)d.a, (const float*)d.b, (float*)d.out, (float*)d.out2, i[0], i[1], i[2], i[3], i[4]);
+      UD_CHECK_LAUNCH("ud_v1_op(points) launch");
+      return UD_OK;
+    }
+    case UD_V1_MEAN3: {          // a, b, c fp32 strided maps -> out; i = n_lo, ld, n_hi
+      const long long n = ((long long)i[2] << 31) + i[0];
+      if (!d.a || !d.b || !d.c || !d.out || n <= 0) break;
+      hipLaunchKernelGGL(mean3_kernel, dim3(grid1(n)), dim3(256), 0, s, (const float*)d.a, (const float*)d.b, (const float*)d.c, (float*)d.out, n, i[1]);
+      UD_CHECK_LAUNCH("ud_v1_op(mean3) launch");
+      return UD_OK;
+    }
+    case UD_V1_PREPROCESS: {     // a = rgb (u8 or fp32 NCHW), out fp32 NCHW [B,3,Hn,Wn]; i = B, H, W, h, w, Hn, Wn, pad_l, pad_t, is_u8, div255, normalize; f = unused
+      if (!d.a || !d.out || i[0] <= 0 || i[3] <= 0 || i[4] <= 0 || i[3] + i[8] > i[5] || i[4] + i[7] > i[6]) break;
+      const f32x4 mean = (f32x4){0.485f, 0.456f, 0.406f, 0.f};
+      const f32x4 istd = (f32x4){1.0f / 0.229f, 1.0f / 0.224f, 1.0f / 0.225f, 0.f};
+      hipLaunchKernelGGL(preprocess_v1_kernel, dim3(grid1((long long)i[0] * 3 * i[5] * i[6])), dim3(256), 0, s, d.a, (float*)d.out, i[0], i[1], i[2], i[3], i[4], i[5], i[6],
+                         i[7], i[8], i[9], i[10], i[11], mean, istd);
+      UD_CHECK_LAUNCH("ud_v1_op(preprocess) launch");
+      return UD_OK;
+    }
+    default:
+      ud_set_error("ud_v1_op: unknown kind");
+      return UD_ERR_UNSUPPORTED;
+  }
+  ud_set_error("ud_v1_op: bad argument");
+  return UD_ERR_BAD_ARG;
+}

@@ -37,6 +37,21 @@ def mk(struct, **kw):
     return d
 
 
+def v1_desc(kind, a=None, b=None, c=None, out=None, out2=None, i=(), f=()):
+    d = _lib.UdV1Op()
+    d.kind = kind
+    d.a, d.b, d.c, d.out, d.out2 = ptr(a), ptr(b), ptr(c), ptr(out), ptr(out2)
+    for k, v in enumerate(i):
+        d.i[k] = int(v)
+    for k, v in enumerate(f):
+        d.f[k] = float(v)
+    return d
+
+
+def v1_op(kind, **kw):
+    check(lib.ud_v1_op(C.byref(v1_desc(kind, **kw)), cur_stream()), "ud_v1_op")
+
+
 # ---- eager single-op entry points (used by the kernel-level tests) -------------------------------------
 def gemm(**kw):
     check(lib.ud_gemm_f16(C.byref(mk(UdGemm, **kw)), cur_stream()), "ud_gemm_f16")
@@ -193,6 +208,12 @@ class Program:
         self.keep += [x, out]
         self.meta.append(("misc", "spatial_mean", 0.0, 4.0 * B * HW * Cc))
         return check(lib.ud_program_add_spatial_mean(self.h, ptr(x), ptr(out), B, HW, Cc, ldo))
+
+    def v1(self, kind, a=None, b=None, c=None, out=None, out2=None, i=(), f=(), tag="v1"):
+        """One decoder-side op of the UniDepthV1 path (include/unidepth_hip.h UdV1Op)."""
+        self.keep += [t for t in (a, b, c, out, out2) if isinstance(t, torch.Tensor)]
+        self.meta.append(("v1." + tag, tag, 0.0, 0.0))
+        return check(lib.ud_program_add_v1_op(self.h, C.byref(v1_desc(kind, a, b, c, out, out2, i, f))))
 
     def run(self, first=0, last=None, stream=None):
         last = len(self) if last is None else last
