@@ -108,6 +108,8 @@ typedef struct UdLayerNorm {
   int out_f32;            /* 0: y is fp16 (MFMA operand); 1: y is fp32 (the fp32 camera head) */
   const float* gamma;     /* optional affine [D] applied here (NULL = statistics only, the default: affines are folded into the consumer).  */
   const float* beta;      /* Needed where no linear consumer follows: the ConvNeXt stem's LayerNorm2d feeds a zero-padded depth-wise conv.  */
+  const float* add;       /* optional fp32 [*, ldx] added to the input row BEFORE the statistics, indexed by the row's position inside its output
+                           * image (out_row_off + p): `features + pos_embed` ahead of an MLP's norm (unidepthv1/decoder.py:80-83). */
 } UdLayerNorm;
 int ud_layernorm_f32_f16(const UdLayerNorm* desc, void* stream);
 

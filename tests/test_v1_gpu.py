@@ -113,8 +113,6 @@ def test_convnext_encoder_vs_oracle(B, H, W):
         assert len(eo) == 36 and all(o is not None for o in eo)
         for i in (0, 2, 5, 17, 32, 35):
             assert rel(eo[i], outs[i]) <= 3e-3 and rel(ecls[i], cls[i]) <= 3e-3, i
-    with pytest.raises(NotImplementedError):
-        model.infer(torch.zeros(1, 3, 64, 64, dtype=torch.uint8))
 
 
 # ------------------------------------------------------------------------------------------- decoder-side ops (ud_v1_op)
@@ -217,3 +215,36 @@ def test_v1_preprocess_points_camera(ops):
     ref = torch.stack((zz * torch.tan(ang[..., 0]), zz / torch.tan(ang[..., 1]) / torch.cos(ang[..., 0]), zz), dim=1)
     torch.cuda.synchronize()
     assert rel(pts, ref) < 1e-5 and torch.equal(dep[:, 0].cpu(), zz)
+
+
+# ------------------------------------------------------------------------------------------- whole UniDepthV1.infer()
+def _v1_check(out, ref, tag, bar=2e-3):
+    o = {k: v.float().cpu() for k, v in out.items()}
+    st = {"depth": ((o["depth"] - ref["depth"]).abs() / ref["depth"].abs().clamp_min(1e-6)).mean().item(),
+          "K": ((o["intrinsics"] - ref["intrinsics"]).abs() / ref["intrinsics"].abs().clamp_min(1.0)).max().item(),
+          "points": rel(o["points"], ref["points"])}
+    print(tag, {k: f"{v:.2e}" for k, v in st.items()})
+    for k in o:
+        assert o[k].shape == ref[k].shape and torch.isfinite(o[k]).all(), (tag, k)
+    assert st["depth"] <= bar and st["K"] <= bar and st["points"] <= 2 * bar, (tag, st)
+    return st
+
+
+@pytest.mark.parametrize("B,H,W,withK,skip", [(1, 240, 320, False, False), (2, 200, 360, True, False), (2, 200, 360, True, True), (1, 480, 640, False, False)])
+def test_v1_infer_vs_oracle(B, H, W, withK, skip):
+    """UniDepthV1.infer() end to end (BASELINE.json configs[3] shape 640x480 among them) against the oracle: depth ARel and intrinsics."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from unidepth_amd import UniDepthV1
+    cfg = synth_v1.load_config_v1()
+    sd = synth_v1.make_synthetic_checkpoint_v1(cfg, 211)
+    rgb = torch.randint(0, 256, (B, 3, H, W), dtype=torch.uint8, generator=torch.Generator().manual_seed(5))
+    K = torch.tensor([[250.0, 0.0, W / 2 - 2.0], [0.0, 251.0, H / 2 - 2.0], [0.0, 0.0, 1.0]]).repeat(B, 1, 1) if withK else None
+    ref = restate_v1.OracleV1(cfg, sd).infer(rgb, None if K is None else K.clone(), skip_camera=skip)
+    model = UniDepthV1(cfg).load_state_dict(sd).to("cuda").eval()
+    out = model.infer(rgb.cuda(), K, skip_camera=skip)
+    torch.cuda.synchronize()
+    _v1_check(out, ref, f"v1_{B}x{H}x{W}_K{int(withK)}_skip{int(skip)}")
+    out2 = model.infer(rgb.cuda(), K, skip_camera=skip)
+    for k in out:
+        assert torch.equal(out[k], out2[k]), k

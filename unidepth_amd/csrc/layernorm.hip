@@ -15,6 +15,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const UdLayerNorm p) {
   const size_t irow = (size_t)img * p.in_rows_per_img + pp + p.in_row_off;
   const size_t orow = (size_t)img * p.out_rows_per_img + pp + p.out_row_off;
   const float* x = p.x + irow * p.ldx;
+  const float* addp = p.add ? p.add + (size_t)(pp + p.out_row_off) * p.ldx : nullptr;
   half_t* y = (half_t*)p.y + (F32OUT ? 0 : orow * p.ldy);
   float* yf = (float*)p.y + (F32OUT ? orow * p.ldy : 0);
   f32x4 v[NIT];
@@ -24,6 +25,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const UdLayerNorm p) {
     const int c = it * 256 + lane * 4;
     if (c < p.D) {
       v[it] = *(const f32x4*)(x + c);
+      if (addp) v[it] += *(const f32x4*)(addp + c);
       s += (v[it][0] + v[it][1]) + (v[it][2] + v[it][3]);
     } else {
       v[it] = (f32x4){0.f, 0.f, 0.f, 0.f};

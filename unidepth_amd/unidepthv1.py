@@ -2,12 +2,12 @@
 Mirrors the reference class (unidepth/models/unidepthv1/unidepthv1.py:101-450): from_pretrained / to / eval / infer(rgbs, intrinsics,
 skip_camera), attribute `image_shape`; device arithmetic in libunidepth_hip.so.
 
-Status (round 2): the ENCODER half runs on the engine -- `pixel_encoder(image)` = ConvNeXt-L (backbones/convnext.py:301-471) as a
-launch program of hand-written HIP kernels (depth-wise 7x7 conv, LayerNorm, MFMA GEMMs for stem / down-sampling / MLP, max_stack,
-class-token means), parity-tested against the oracle restatement, which is pinned to the reference's own ConvNeXt code.  The
-decoder half (unidepthv1/decoder.py: camera head, spherical-harmonics ray embedding, Nystrom attention blocks whose arithmetic
-lives in the un-vendored xformers package) is not built yet: infer() raises NotImplementedError after naming what is missing --
-it never falls back to another implementation."""
+One launch program per (batch, input shape, camera mode): pre-processing (antialiased resize + pad), ConvNeXt-L encoder
+(backbones/convnext.py:301-471: depth-wise 7x7 conv, LayerNorm, MFMA GEMMs for stem / down-sampling / MLP, max_stack, class-token
+means), V1 decoder (unidepthv1/decoder.py: adapters, fp32 camera head, spherical-harmonics ray embeddings, single-head width-512
+attention as GEMM + softmax + GEMM, 8-head flash attention, ConvUpsample stacks, Nystrom attention blocks), multi-scale merge and
+back-projection.  Parity: against oracle/restate_v1.py, which is pinned to the reference's own code except for the Nystrom attention
+(arithmetic in the un-vendored xformers package: restated from the published algorithm, PARITY UNPINNED -- see the oracle header)."""
 from __future__ import annotations
 
 import json
@@ -69,10 +69,139 @@ def pack_convnext(config: dict, sd: dict, device) -> dict:
     return w
 
 
+def _fold_ln(w, b, g, beta):
+    b0 = b if b is not None else w.new_zeros(w.shape[0])
+    return w * g[None, :], b0 + w @ beta
+
+
+def _conv3_rows(w):                          # [Cout, Cin, 3, 3] -> [Cout, 9*Cin], k = (ky*3 + kx)*Cin + ci
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+
+
+def pack_v1_decoder(config: dict, sd: dict, device) -> dict:
+    """Load-time repack of `pixel_decoder.*` (unidepthv1/decoder.py:468-533): LayerNorm affines folded into the consuming Linear, LayerScale /
+    CvnxtBlock gammas into the producing one, 1/sqrt(d) of the single-head width-512 attentions into their q projection, conv filters as
+    GEMM rows, K padded to 64.  The 4-token camera transformer keeps fp32 weights (fp32 island, as in the V2 engine)."""
+    f = {k: v.detach().to(torch.float32).cpu() for k, v in sd.items() if k.startswith("pixel_decoder.")}
+    C = config["model"]["pixel_decoder"]["hidden_dim"]
+    pd = "pixel_decoder."
+    w = {}
+
+    def p16(name, t):
+        w[name] = _padk16(t).to(device)
+
+    def p32(name, t):
+        w[name] = t.to(torch.float32).contiguous().to(device)
+
+    def lin_ln16(dst, wk, bk, nk):             # LN(nk) -> Linear(wk): fp16 GEMM operand + fp32 bias
+        ww, bb = _fold_ln(f[wk + ".weight"], f.get(wk + ".bias"), f[nk + ".weight"], f[nk + ".bias"])
+        p16(dst + ".w", ww); p32(dst + ".b", bb)
+
+    def lin_ln32(dst, wk, bk, nk):
+        ww, bb = _fold_ln(f[wk + ".weight"], f.get(wk + ".bias"), f[nk + ".weight"], f[nk + ".bias"])
+        p32(dst + ".w", ww); p32(dst + ".b", bb)
+
+    for j in range(4):
+        a = f"{pd}input_adapter.input_adapters.{j}"
+        lin_ln16(f"ad.{j}", a + ".1", None, a + ".0")
+        t = f"{pd}token_adapter.input_adapters.{j}"
+        lin_ln32(f"tok.{j}", t + ".1", None, t + ".0")
+    lv = f[pd + "level_embeds"]
+    lv = torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(lv, f[pd + "level_embed_layer.0.weight"], f[pd + "level_embed_layer.0.bias"])),
+                                    f[pd + "level_embed_layer.2.weight"], f[pd + "level_embed_layer.2.bias"])
+    w["host.level_embed"] = torch.nn.functional.layer_norm(lv, (C,), f[pd + "level_embed_layer.3.weight"], f[pd + "level_embed_layer.3.bias"], 1e-5)   # constant of the weights
+
+    def mlp16(dst, src, ls=None):
+        lin_ln16(dst + "fc1", src + "proj1", None, src + "norm")
+        w2, b2 = f[src + "proj2.weight"], f[src + "proj2.bias"]
+        if ls is not None:
+            w2, b2 = w2 * ls[:, None], b2 * ls
+        p16(dst + "fc2.w", w2); p32(dst + "fc2.b", b2)
+
+    def mlp32(dst, src, ls=None):
+        lin_ln32(dst + "fc1", src + "proj1", None, src + "norm")
+        w2, b2 = f[src + "proj2.weight"], f[src + "proj2.bias"]
+        if ls is not None:
+            w2, b2 = w2 * ls[:, None], b2 * ls
+        p32(dst + "fc2.w", w2); p32(dst + "fc2.b", b2)
+
+    cl = pd + "camera_layer."
+    p32("cam.pos", f[cl + "latents_pos"].reshape(4, C))
+    lin_ln32("cam.cls1", cl + "cls_project.1", None, cl + "cls_project.0")
+    p32("cam.cls2.w", f[cl + "cls_project.3.weight"]); p32("cam.cls2.b", f[cl + "cls_project.3.bias"])
+    mlp16("cam.inf.", cl + "in_features.")
+    a = cl + "aggregate."
+    lin_ln32("cam.agg.q", a + "q", None, a + "norm_attnx")
+    lin_ln16("cam.agg.kv", a + "kv", None, a + "norm_attnctx")
+    p32("cam.agg.out.w", f[a + "out.weight"] * f[a + "ls1.gamma"][:, None]); p32("cam.agg.out.b", f[a + "out.bias"] * f[a + "ls1.gamma"])
+    mlp32("cam.agg.", a + "mlp.", f[a + "ls2.gamma"])
+    for i in range(2):
+        a = f"{cl}layers.{i}."
+        lin_ln32(f"cam.l{i}.q", a + "q", None, a + "norm_attnx")
+        lin_ln32(f"cam.l{i}.kv", a + "kv", None, a + "norm_attnctx")
+        p32(f"cam.l{i}.out.w", f[a + "out.weight"] * f[a + "ls1.gamma"][:, None]); p32(f"cam.l{i}.out.b", f[a + "out.bias"] * f[a + "ls1.gamma"])
+        mlp32(f"cam.l{i}.", a + "mlp.", f[a + "ls2.gamma"])
+    mlp32("cam.out.", cl + "out.")
+
+    dl = pd + "depth_layer."
+    for nm in ("project_rays16", "project_rays8", "project_rays4"):
+        mlp16(f"{nm}.", f"{dl}{nm}.")                                  # K: 81 -> 128, 324 -> 384 (zero padded)
+    wc = f[dl + "features_channel_cat.weight"]
+    for j in range(4):
+        p16(f"fcat.{j}.w", wc[:, j * C:(j + 1) * C])
+    p32("fcat.0.b", f[dl + "features_channel_cat.bias"])
+    mlp16("tolat.", dl + "to_latents.")
+
+    def big_attn(dst, src):                    # single head of width C: q pre-scaled by C^-1/2; K and V projections separate (V^T is produced by a GEMM)
+        sc = C ** -0.5
+        wq, bq = _fold_ln(f[src + "q.weight"], f[src + "q.bias"], f[src + "norm_attnx.weight"], f[src + "norm_attnx.bias"])
+        p16(dst + "q.w", wq * sc); p32(dst + "q.b", bq * sc)
+        wkv, bkv = _fold_ln(f[src + "kv.weight"], f[src + "kv.bias"], f[src + "norm_attnctx.weight"], f[src + "norm_attnctx.bias"])
+        p16(dst + "k.w", wkv[:C]); p32(dst + "k.b", bkv[:C])
+        p16(dst + "v.w", wkv[C:]); p32(dst + "v.b", bkv[C:])
+        p16(dst + "out.w", f[src + "out.weight"] * f[src + "ls1.gamma"][:, None]); p32(dst + "out.b", f[src + "out.bias"] * f[src + "ls1.gamma"])
+        mlp16(dst, src + "mlp.", f[src + "ls2.gamma"])
+
+    big_attn("agg16.", dl + "aggregate_16.")
+    big_attn("pcam.", dl + "prompt_camera.")
+    depths = list(config["model"]["pixel_decoder"]["depths"])
+    for i in range(depths[0]):
+        src, dst = f"{dl}layers_16.{i}.", f"l16.{i}."
+        lin_ln16(dst + "q", src + "q", None, src + "norm_attnx")
+        lin_ln16(dst + "kv", src + "kv", None, src + "norm_attnctx")
+        p16(dst + "out.w", f[src + "out.weight"] * f[src + "ls1.gamma"][:, None]); p32(dst + "out.b", f[src + "out.bias"] * f[src + "ls1.gamma"])
+        mlp16(dst, src + "mlp.", f[src + "ls2.gamma"])
+    for nm, d, n in (("layers_8", C // 2, depths[1]), ("layers_4", C // 4, depths[2])):
+        for i in range(n):
+            src, dst = f"{dl}{nm}.{i}.", f"{nm}.{i}."
+            lin_ln16(dst + "q", src + "q", None, src + "norm_attnx")
+            wkv, bkv = _fold_ln(f[src + "kv.weight"], f[src + "kv.bias"], f[src + "norm_attnctx.weight"], f[src + "norm_attnctx.bias"])
+            p16(dst + "k.w", wkv[:d]); p32(dst + "k.b", bkv[:d])
+            p16(dst + "v.w", wkv[d:]); p32(dst + "v.b", bkv[d:])
+            p16(dst + "out.w", f[src + "out.weight"] * f[src + "ls1.gamma"][:, None]); p32(dst + "out.b", f[src + "out.bias"] * f[src + "ls1.gamma"])
+            mlp16(dst, src + "mlp.", f[src + "ls2.gamma"])
+    for nm, d in (("up8", C), ("up4", C // 2), ("up2", C // 4)):
+        for c in range(2):
+            src, dst = f"{dl}{nm}.convs.{c}.", f"{nm}.{c}."
+            p32(dst + "dw.w", f[src + "dwconv.weight"].reshape(d, 49).t()); p32(dst + "dw.b", f[src + "dwconv.bias"])
+            w1, b1 = _fold_ln(f[src + "pwconv1.weight"], f[src + "pwconv1.bias"], f[src + "norm.weight"], f[src + "norm.bias"])
+            p16(dst + "fc1.w", w1); p32(dst + "fc1.b", b1)
+            g = f[src + "gamma"]
+            p16(dst + "fc2.w", f[src + "pwconv2.weight"] * g[:, None]); p32(dst + "fc2.b", f[src + "pwconv2.bias"] * g)
+        p16(f"{nm}.up0.w", f[f"{dl}{nm}.up.0.weight"].reshape(d // 2, d)); p32(f"{nm}.up0.b", f[f"{dl}{nm}.up.0.bias"])
+        p16(f"{nm}.up2.w", _conv3_rows(f[f"{dl}{nm}.up.2.weight"])); p32(f"{nm}.up2.b", f[f"{dl}{nm}.up.2.bias"])
+    for nm, d in (("out8", C // 2), ("out4", C // 4), ("out2", C // 8)):
+        rows = torch.zeros(4, 9 * d)
+        rows[0] = _conv3_rows(f[f"{dl}{nm}.weight"])[0]
+        bias = torch.zeros(4); bias[0] = f[f"{dl}{nm}.bias"][0]
+        p16(f"{nm}.w", rows); p32(f"{nm}.b", bias)
+    return w
+
+
 class _EncPlan:
     """Device buffers + launch program of the ConvNeXt encoder for one (batch, network image shape)."""
 
-    def __init__(self, model: "UniDepthV1", B: int, Hn: int, Wn: int):
+    def __init__(self, model: "UniDepthV1", B: int, Hn: int, Wn: int, P: Optional[ops.Program] = None, img: Optional[torch.Tensor] = None):
         w, dev = model._w, model.device
         a = model._arch
         f16, f32 = torch.float16, torch.float32
@@ -80,13 +209,13 @@ class _EncPlan:
         def z(*shape, dtype=f16):
             return torch.zeros(*shape, dtype=dtype, device=dev)
 
-        P = ops.Program()
+        P = ops.Program() if P is None else P
         self.prog, self.B = P, B
         self.tap_points = []
 
         def tap(name, fn):
             self.tap_points.append((name, len(P), fn))
-        self.img = z(B, 3, Hn, Wn, dtype=f32)
+        self.img = z(B, 3, Hn, Wn, dtype=f32) if img is None else img
         H, W = Hn // 4, Wn // 4
         dims, depths = a["dims"], a["depths"]
         rows = B * H * W
@@ -214,6 +343,8 @@ class UniDepthV1:
         if self._w is None:
             with torch.cuda.device(self._device):
                 self._w = pack_convnext(self.config, self._sd, self._device)
+                if any(k.startswith("pixel_decoder.") for k in self._sd):
+                    self._w.update(pack_v1_decoder(self.config, self._sd, self._device))
 
     def _enc_plan(self, B, Hn, Wn) -> _EncPlan:
         key = ("enc", B, Hn, Wn)
@@ -285,8 +416,424 @@ class UniDepthV1:
             cls = [plan.cls[-i - 1].clone().unsqueeze(1) for i in range(4)]
         return feats, cls
 
+    def _full_plan(self, *sig) -> "_FullPlan":
+        key = ("full",) + tuple(sig)
+        if key not in self._plans:
+            while len(self._plans) >= 3:
+                self._plans.pop(next(iter(self._plans)))
+            with torch.cuda.device(self._device):
+                self._plans[key] = _FullPlan(self, *sig)
+        return self._plans[key]
+
     @torch.no_grad()
     def infer(self, rgbs: torch.Tensor, intrinsics=None, skip_camera: bool = False):
-        raise NotImplementedError(
-            "UniDepthV1.infer on the MI355X engine: the ConvNeXt-L encoder runs (pixel_encoder / stage_features), the V1 decoder "
-            "(unidepthv1/decoder.py: camera head, rsh_cart_8 ray embedding, Nystrom attention) is not built yet -- SURVEY.md 8f next-1")
+        """Same contract as the reference (unidepthv1.py:288-373): rgbs uint8 / float [3,H,W] or [B,3,H,W], optional pinhole intrinsics
+        [3,3] / [B,3,3] of the INPUT image, skip_camera (use the given camera instead of running the camera head)
+        -> {"intrinsics" [B,3,3], "points" [B,3,H,W], "depth" [B,1,H,W]} at the input resolution."""
+        self._ensure_packed()
+        if rgbs.ndim == 3:
+            rgbs = rgbs.unsqueeze(0)
+        if intrinsics is not None and intrinsics.ndim == 2:
+            intrinsics = intrinsics.unsqueeze(0)
+        B, _, H, W = rgbs.shape
+        is_u8 = rgbs.dtype == torch.uint8
+        if is_u8:
+            div255, normalize = True, True
+        else:                                   # the reference inspects the value range of float inputs (unidepthv1.py:305-313)
+            mn, mx = float(rgbs.min()), float(rgbs.max())
+            div255 = mx > 5
+            if div255:
+                mn, mx = mn / 255.0, mx / 255.0
+            normalize = mn >= 0.0 and mx <= 1.0
+        n_gt = 0 if intrinsics is None else int(intrinsics.shape[0])
+        assert n_gt in (0, 1, B), f"intrinsics batch {n_gt} does not match the image batch {B}"
+        skip = bool(skip_camera and intrinsics is not None)
+        with torch.cuda.device(self._device):
+            plan = self._full_plan(B, H, W, is_u8, div255, normalize, n_gt, skip)
+            plan.rgb.copy_(rgbs if is_u8 else rgbs.float(), non_blocking=True)
+            pl, pr, pt, pb = plan.pads
+            gtK = None
+            if intrinsics is not None:
+                gtK = intrinsics.detach().float().cpu().clone()                 # _preprocess (unidepthv1.py:57-63)
+                gtK[:, 0, 0] *= plan.ratio; gtK[:, 1, 1] *= plan.ratio
+                gtK[:, 0, 2] = gtK[:, 0, 2] * plan.ratio + pl
+                gtK[:, 1, 2] = gtK[:, 1, 2] * plan.ratio + pt
+                kinv = torch.zeros(n_gt, 3, 3)
+                kinv[:, 0, 0], kinv[:, 1, 1], kinv[:, 2, 2] = 1.0 / gtK[:, 0, 0], 1.0 / gtK[:, 1, 1], 1.0
+                kinv[:, 0, 2], kinv[:, 1, 2] = -gtK[:, 0, 2] / gtK[:, 0, 0], -gtK[:, 1, 2] / gtK[:, 1, 1]
+                plan.Kinv_gt.copy_(kinv.reshape(n_gt, 9))
+            plan.prog.run()
+            dev = self._device
+            points = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
+            depth = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
+            if gtK is None:
+                Kret = plan.Kpost.view(B, 3, 3).clone()
+                Kuse, nK = plan.Kpost, B
+            elif skip:                          # the "predicted" matrix IS the GT tensor, rescaled in place by _postprocess (unidepthv1.py:343-358)
+                Kp = gtK.clone()
+                Kp[:, 0, 0] /= plan.ratio; Kp[:, 1, 1] /= plan.ratio
+                Kp[:, 0, 2] = (Kp[:, 0, 2] - pl) / plan.ratio
+                Kp[:, 1, 2] = (Kp[:, 1, 2] - pt) / plan.ratio
+                Kuse = Kp.reshape(n_gt, 9).to(dev)
+                Kret, nK = Kuse.view(n_gt, 3, 3).expand(B, 3, 3).clone(), n_gt
+            else:                               # reference quirk: back-projection with the NETWORK-resolution GT matrix on the input pixel grid (:358)
+                Kret = plan.Kpost.view(B, 3, 3).clone()
+                Kuse, nK = gtK.reshape(n_gt, 9).to(dev), n_gt
+            from . import _lib as L
+            ops.v1_op(L.UD_V1_POINTS, a=plan.zout, b=Kuse, out=points, out2=depth, i=(B, H, W, 4, nK))
+        return {"intrinsics": Kret, "points": points, "depth": depth}
+
+    __call__ = infer
+
+
+# =====================================================================================================================
+# Full infer() plan: pre-processing + encoder + decoder + post-processing
+# =====================================================================================================================
+def v1_shapes(image_shape, network_shape):
+    """unidepthv1.py:38-47 _shapes + :29-35 _paddings: ((h, w) after the aspect-preserving resize, ratio, (pad_l, pad_r, pad_t, pad_b))."""
+    h, w = image_shape
+    if network_shape[1] / network_shape[0] > w / h:
+        ratio = network_shape[0] / h
+    else:
+        ratio = network_shape[1] / w
+    nh, nw = math.ceil(h * ratio - 0.5), math.ceil(w * ratio - 0.5)
+    Hn, Wn = network_shape
+    pt, pb = (Hn - nh) // 2, Hn - nh - (Hn - nh) // 2
+    pl, pr = (Wn - nw) // 2, Wn - nw - (Wn - nw) // 2
+    return (nh, nw), ratio, (pl, pr, pt, pb)
+
+
+def pos_embed_sine(h: int, w: int, num_pos_feats: int, temperature: float = 10000.0) -> torch.Tensor:
+    """PositionEmbeddingSine(num_pos_feats, normalize=True) of an unmasked h x w grid (layers/positional_encoding.py:14-57) -> [h*w, 2*npf].
+    A constant of the grid shape, computed once per plan on the host (like the V2 engine's resampled position embedding)."""
+    eps, scale = 1e-6, 2 * math.pi
+    yy = torch.arange(1, h + 1, dtype=torch.float32)[:, None].expand(h, w) / (h + eps) * scale
+    xx = torch.arange(1, w + 1, dtype=torch.float32)[None, :].expand(h, w) / (w + eps) * scale
+    dim_t = torch.arange(num_pos_feats, dtype=torch.float32)
+    dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / num_pos_feats)
+    px, py = xx[:, :, None] / dim_t, yy[:, :, None] / dim_t
+    px = torch.stack((px[:, :, 0::2].sin(), px[:, :, 1::2].cos()), dim=3).flatten(2)
+    py = torch.stack((py[:, :, 0::2].sin(), py[:, :, 1::2].cos()), dim=3).flatten(2)
+    return torch.cat((py, px), dim=2).reshape(h * w, -1)
+
+
+class _FullPlan:
+    """One launch program for infer(): unidepthv1.py:288-373 -> decoder.py:364-463 (Decoder.forward), :39-111 (CameraHead), :231-330
+    (DepthHead.forward).  Token streams are fp32 [B*n, C]; MFMA operands fp16; the 4-token camera transformer runs in fp32."""
+
+    def __init__(self, model: "UniDepthV1", B: int, H: int, W: int, is_u8: bool, div255: bool, normalize: bool, n_gt: int, skip_camera: bool):
+        from . import _lib as L
+        from .ops import UD_A_CONV3_ZERO, UD_ACT_NONE, UD_EPI_QKV
+        w, dev = model._w, model.device
+        f16, f32 = torch.float16, torch.float32
+        C = model.config["model"]["pixel_decoder"]["hidden_dim"]
+        heads = model.config["model"]["num_heads"]
+        dec_depths = list(model.config["model"]["pixel_decoder"]["depths"])
+        Hn, Wn = model.image_shape
+        self.B, self.H, self.W, self.Hn, self.Wn = B, H, W, Hn, Wn
+        (h_in, w_in), ratio, pads = v1_shapes((H, W), (Hn, Wn))
+        pl, pr, pt, pb = pads
+        self.ratio, self.pads, self.n_gt, self.skip = ratio, pads, n_gt, skip_camera
+
+        def z(*shape, dtype=f16):
+            return torch.zeros(*shape, dtype=dtype, device=dev)
+
+        P = ops.Program()
+        self.prog = P
+        self.tap_points = []
+
+        def tap(name, fn):
+            self.tap_points.append((name, len(P), fn))
+        zeros = z(256)
+        # ---------------- pre-processing + encoder
+        self.rgb = torch.zeros(B, 3, H, W, dtype=torch.uint8 if is_u8 else f32, device=dev)
+        img = z(B, 3, Hn, Wn, dtype=f32)
+        P.v1(L.UD_V1_PREPROCESS, a=self.rgb, out=img, i=(B, H, W, h_in, w_in, Hn, Wn, pl, pt, int(is_u8), int(div255), int(normalize)), tag="preprocess")
+        enc = _EncPlan(model, B, Hn, Wn, P=P, img=img)
+        self.enc = enc
+        self.dec_first = len(P)
+        # level shapes as the reference derives them (decoder.py:380-392): sorted (short, long) sides, common = second smallest level
+        lv = [tuple(sorted((hh, ww))) for hh, ww, _ in enc.shapes]
+        level_shapes = sorted(set(lv))[::-1]
+        assert len(level_shapes) == 4, "UniDepthV1 decoder: the four encoder stages must have distinct resolutions"
+        h, wd = level_shapes[-2]
+        hw = h * wd
+
+        def ln(src, dst, rows, D, eps=1e-5, **kw):
+            P.layernorm(x=src, y=dst, rows=rows, D=D, ldx=D, ldy=D, eps=eps, **dict(dict(rows_per_img=rows, in_rows_per_img=rows, out_rows_per_img=rows), **kw))
+
+        def gemm(A, Wn_, out, M, N, K, bias=True, **kw):
+            P.gemm(A=A, W=w[Wn_ + ".w"], out=out, M=M, N=N, K=K, lda=kw.pop("lda", K), ldw=w[Wn_ + ".w"].shape[1], ldc=kw.pop("ldc", N),
+                   **({"bias": w[Wn_ + ".b"]} if bias else {}), tag=kw.pop("tag", "v1." + Wn_), **kw)
+
+        def mlp(stream, pre, rows, D, hid_mult, accumulate=1, out=None, n_out=None):
+            """x (+)= fc2(GELU(fc1(LN(x))))  (layers/mlp.py:27-35; LayerScale folded into fc2)."""
+            nh = w[pre + "fc1.w"].shape[0]
+            xn = z(rows, D)
+            hid = z(rows, _rup(nh, 64))
+            ln(stream, xn, rows, D)
+            gemm(xn, pre + "fc1", hid, rows, nh, D, epi=UD_EPI_F16, act=UD_ACT_GELU, ldc=_rup(nh, 64))
+            n_out = D if n_out is None else n_out
+            gemm(hid, pre + "fc2", stream if out is None else out, rows, n_out, _rup(nh, 64), epi=UD_EPI_F32, accumulate=accumulate)
+
+        # ---------------- encoder features -> common resolution -> adapters (decoder.py:394-411, :21-36)
+        Mt = B * hw
+        feat = [z(Mt, C, dtype=f32) for _ in range(4)]           # adapted features, level-major like the reference's list
+        feat16 = [z(Mt, C) for _ in range(4)]
+        for j, (hh, ww, Cj) in enumerate(enc.shapes):
+            src = enc.stage_max[j]
+            if (hh, ww) != (h, wd):
+                rs = z(Mt, Cj, dtype=f32)
+                P.v1(L.UD_V1_RESIZE_AA, a=src, out=rs, i=(B, hh, ww, h, wd, Cj, Cj, Cj, 0, 0, hh, ww), tag="resize_aa")
+                src = rs
+            xn = z(Mt, Cj)
+            ln(src, xn, Mt, Cj)
+            gemm(xn, f"ad.{j}", feat[j], Mt, C, Cj, epi=UD_EPI_F32, act=UD_ACT_GELU, out2=feat16[j], ldc2=C)
+        tap("features", lambda: [t.view(B, hw, C).clone() for t in feat])
+        pos = pos_embed_sine(h, wd, C // 2)                                   # [hw, C]
+        pos_lvl = (pos[None] + w["host.level_embed"][:, None, :]).reshape(4 * hw, C).contiguous().to(dev)     # pos_embed + level_embed, [4 hw, C]
+        Nc = 4 * hw
+        # ---------------- camera head (decoder.py:39-111, :332-356) -- skipped with skip_camera (decoder.py:437-447)
+        self.K33 = z(B, 9, dtype=f32); self.Kinv = z(B, 9, dtype=f32); self.Kpost = z(B, 9, dtype=f32)
+        nb = n_gt if n_gt else B
+        self.Kinv_gt = z(max(nb, 1), 9, dtype=f32)
+        self.K_gt = z(max(nb, 1), 9, dtype=f32)
+        if not skip_camera:
+            ct = z(B * 4, C, dtype=f32)
+            for j in range(4):
+                cj = enc.cls[3 - j]                                             # deepest block first (decoder.py:375-377)
+                Cj = cj.shape[1]
+                cn = z(_rup(B, 8), Cj, dtype=f32)
+                P.layernorm(x=cj, y=cn, rows=B, D=Cj, ldx=Cj, ldy=Cj, eps=1e-5, rows_per_img=B, in_rows_per_img=B, out_rows_per_img=B, out_f32=1)
+                P.linear_f32(x=cn, W=w[f"tok.{j}.w"], bias=w[f"tok.{j}.b"], out=ct.data_ptr() + j * C * 4, M=B, N=C, K=Cj, ldx=Cj, ldw=Cj, ldc=4 * C,
+                             act=UD_ACT_GELU, tag="cam.tok")
+            Mc = B * 4
+
+            def ln32(src, dst, rows=Mc):
+                P.layernorm(x=src, y=dst, rows=rows, D=C, ldx=C, ldy=C, eps=1e-5, rows_per_img=rows, in_rows_per_img=rows, out_rows_per_img=rows, out_f32=1)
+
+            def lin32(xb, name, out, n, k, act=UD_ACT_NONE, accumulate=0, **kw):
+                P.linear_f32(x=xb, W=w[name + ".w"], bias=w[name + ".b"], out=out, M=Mc, N=n, K=k, ldx=k, ldw=k, ldc=kw.pop("ldc", n), act=act,
+                             accumulate=accumulate, tag="cam." + name, **kw)
+
+            def mlp32(pre, stream, out, accumulate, n_out=C):
+                nh = w[pre + "fc1.w"].shape[0]
+                cn_ = z(Mc, C, dtype=f32); ch_ = z(Mc, nh, dtype=f32)
+                ln32(stream, cn_)
+                lin32(cn_, pre + "fc1", ch_, nh, C, act=UD_ACT_GELU)
+                lin32(ch_, pre + "fc2", out, n_out, nh, accumulate=accumulate)
+            cn = z(Mc, C, dtype=f32); c1 = z(Mc, C // 2, dtype=f32); cls_t = z(Mc, C, dtype=f32)
+            ln32(ct, cn)
+            lin32(cn, "cam.cls1", c1, C // 2, C, act=UD_ACT_GELU)
+            lin32(c1, "cam.cls2", cls_t, C, C // 2)
+            # features_stack = cat(features, dim=1) + pos_embed  ->  in_features MLP (not residual)  ->  cat with the class tokens
+            fsn = z(B * Nc, C)
+            for j in range(4):
+                P.layernorm(x=feat[j], y=fsn, rows=Mt, D=C, ldx=C, ldy=C, eps=1e-5, rows_per_img=hw, in_rows_per_img=hw, out_rows_per_img=Nc,
+                            out_row_off=j * hw, add=pos_lvl)
+            hidc = z(B * Nc, 2 * C)
+            ctx = z(B * (Nc + 4), C, dtype=f32)
+            gemm(fsn, "cam.inf.fc1", hidc, B * Nc, 2 * C, C, epi=UD_EPI_F16, act=UD_ACT_GELU)
+            gemm(hidc, "cam.inf.fc2", ctx, B * Nc, C, 2 * C, epi=UD_EPI_F32, rows_in=Nc, rows_out=Nc + 4, row_off=0)
+            P.v1(L.UD_V1_COPY_ROWS, a=cls_t, out=ctx, i=(B, 4, Nc + 4, Nc, C, C, 0), tag="cat_cls")
+            # aggregate: one head of width C, 4 queries vs 4 hw + 4 keys (decoder.py:94)
+            ctxn = z(B * (Nc + 4), C)
+            ln(ctx, ctxn, B * (Nc + 4), C)
+            kvc = z(B * (Nc + 4), 2 * C)
+            gemm(ctxn, "cam.agg.kv", kvc, B * (Nc + 4), 2 * C, C, epi=UD_EPI_F16)
+            cq = z(Mc, C, dtype=f32); cao = z(Mc, C, dtype=f32)
+            ln32(cls_t, cn)
+            lin32(cn, "cam.agg.q", cq, C, C, add=w["cam.pos"], ldadd=C, add_mod=4)
+            P.v1(L.UD_V1_ATTN_FEWQ, a=cq, b=kvc, out=cao, i=(B, 4, Nc + 4, C), f=(C ** -0.5,), tag="cam.aggregate")
+            lin32(cao, "cam.agg.out", cls_t, C, C, accumulate=1)
+            mlp32("cam.agg.", cls_t, cls_t, 1)
+            ckv = z(Mc, 2 * C, dtype=f32)
+            for i in range(2):
+                ln32(cls_t, cn)                                                 # norm_attnx / norm_attnctx share the statistics
+                lin32(cn, f"cam.l{i}.q", cq, C, C, add=w["cam.pos"], ldadd=C, add_mod=4)
+                lin32(cn, f"cam.l{i}.kv", ckv, 2 * C, C)
+                P.attention_small_f32(cq, ckv, cao, B, 4, heads, C, (C // heads) ** -0.5)
+                lin32(cao, f"cam.l{i}.out", cls_t, C, C, accumulate=1)
+                mlp32(f"cam.l{i}.", cls_t, cls_t, 1)
+            raw = z(Mc, 1, dtype=f32)
+            mlp32("cam.out.", cls_t, raw, 0, n_out=1)
+            P.v1(L.UD_V1_CAMERA, a=raw, out=self.K33, out2=self.Kinv, c=self.Kpost, i=(B, Hn, Wn, pl, pt), f=(ratio,), tag="camera")
+            tap("intrinsics_net", lambda: self.K33.view(B, 3, 3).clone())
+        # ---------------- rays at network resolution (decoder.py:354-355 / unidepthv1.py:334-341 for GT intrinsics)
+        self.rays = z(nb, 3, Hn, Wn, dtype=f32)
+        P.rays(self.Kinv_gt if n_gt else self.Kinv, self.rays, nb, Hn, Wn, 0)
+        # ---------------- spherical-harmonics ray embeddings at 1/16, 1/8, 1/4 (decoder.py:205-225)
+        lvls = [(h, wd, C, "project_rays16"), (2 * h, 2 * wd, C // 2, "project_rays8"), (4 * h, 4 * wd, C // 4, "project_rays4")]
+        emb = []
+        for hh, ww, Cl, nm in lvls:
+            n = hh * ww
+            sh = z(nb * n, 128)
+            P.v1(L.UD_V1_SH_EMBED, a=self.rays, out=sh, i=(nb, Hn, Wn, hh, ww, 128, n), f=(1e-5,), tag="sh_embed")
+            hid = z(nb * n, 384)
+            e = z(nb * n, Cl, dtype=f32)
+            gemm(sh, nm + ".fc1", hid, nb * n, 324, 128, epi=UD_EPI_F16, act=UD_ACT_GELU, ldc=384)
+            gemm(hid, nm + ".fc2", e, nb * n, Cl, 384, epi=UD_EPI_F32)
+            if nb != B:                                                         # one GT camera for the whole batch: broadcast once, the rest of the program is per image
+                eb = z(B * n, Cl, dtype=f32)
+                for b in range(B):
+                    P.v1(L.UD_V1_COPY_ROWS, a=e, out=eb, i=(1, n, n, b * n, Cl, Cl, 0), tag="bcast")
+                e = eb
+            emb.append(e)
+        e16, e8, e4 = emb
+        tap("rays_embedding_16", lambda: e16.view(B, hw, C).clone())
+        # ---------------- latents: channel-concat projection + to_latents MLP (decoder.py:228-235)
+        lat = z(Mt, C, dtype=f32)
+        for j in range(4):
+            gemm(feat16[j], f"fcat.{j}", lat, Mt, C, C, bias=(j == 0), epi=UD_EPI_F32, accumulate=int(j > 0))
+        lat2 = z(Mt, C, dtype=f32)
+        mlp(lat, "tolat.", Mt, C, 2, accumulate=0, out=lat2)
+        lat = lat2
+
+        # ---------------- single-head attention of width C via GEMMs: S = Q K^T (fp32), row softmax, O = P V (layers/attention.py:109-142)
+        def big_attn(pre, x, ctxn, Nk, add_k=None):
+            """x += ls1 * out(softmax(q k^T) v);  x += ls2 * mlp(x).   ctxn: LayerNorm statistics of the context, fp16 [B*Nk, C]."""
+            Nkp = _rup(Nk, 64)
+            xn = z(Mt, C); q = z(Mt, C); k = z(B * Nk, C); vt = z(B, C, Nkp)
+            ln(x, xn, Mt, C)
+            gemm(xn, pre + "q", q, Mt, C, C, epi=UD_EPI_F16)
+            kw = dict(add=add_k, ldadd=C, rows_in=Nk, rows_out=Nk) if add_k is not None else {}
+            gemm(ctxn, pre + "k", k, B * Nk, C, C, epi=UD_EPI_F16, **kw)
+            # V^T[b] = Wv ctxn[b]^T (operands swapped: no transpose pass); its bias is added after P V (softmax rows sum to one)
+            P.gemm(A=w[pre + "v.w"], W=ctxn, out=vt, M=C, N=Nk, K=C, lda=C, ldw=C, ldc=Nkp, epi=UD_EPI_F16, groups=B, gA=0, gW=Nk * C, gOut=C * Nkp,
+                   tag="v1." + pre + "vT")
+            S = z(B * hw, Nk, dtype=f32)
+            P.gemm(A=q, W=k, out=S, M=hw, N=Nk, K=C, lda=C, ldw=C, ldc=Nk, epi=UD_EPI_F32, groups=B, gA=hw * C, gW=Nk * C, gOut=hw * Nk, tag="v1." + pre + "qk")
+            Pm = z(B * hw, Nkp)
+            P.v1(L.UD_V1_SOFTMAX, a=S, out=Pm, i=(B * hw, Nk, Nk, Nkp, 0, 0), f=(1.0,), tag="softmax")
+            o = z(Mt, C)
+            P.gemm(A=Pm, W=vt, bias=w[pre + "v.b"], out=o, M=hw, N=C, K=Nkp, lda=Nkp, ldw=Nkp, ldc=C, epi=UD_EPI_F16, groups=B, gA=hw * Nkp, gW=C * Nkp,
+                   gBias=0, gOut=hw * C, tag="v1." + pre + "pv")
+            gemm(o, pre + "out", x, Mt, C, C, epi=UD_EPI_F32, accumulate=1)
+            mlp(x, pre, Mt, C, 4)
+
+        tokn = z(B * Nc, C)                                                     # LayerNorm statistics of cat(features, dim=1)
+        for j in range(4):
+            P.layernorm(x=feat[j], y=tokn, rows=Mt, D=C, ldx=C, ldy=C, eps=1e-5, rows_per_img=hw, in_rows_per_img=hw, out_rows_per_img=Nc, out_row_off=j * hw)
+        big_attn("agg16.", lat, tokn, Nc, add_k=pos_lvl)
+        e16n = z(Mt, C)
+        ln(e16, e16n, Mt, C)
+        big_attn("pcam.", lat, e16n, hw)
+        # ---------------- layers_16: self-attention, 8 heads of 64, ray embedding added to q (decoder.py:246-247)
+        hwk = _rup(hw, 64)
+        for i in range(dec_depths[0]):
+            pre = f"l16.{i}."
+            xn = z(Mt, C); q = z(Mt, C); k = z(Mt, C); vt = z(B, heads, 64, hwk); ao = z(Mt, C)
+            ln(lat, xn, Mt, C)
+            gemm(xn, pre + "q", q, Mt, C, C, epi=UD_EPI_F16, add=e16, ldadd=C)
+            P.gemm(A=xn, W=w[pre + "kv.w"], bias=w[pre + "kv.b"], out=k, out2=vt, M=Mt, N=2 * C, K=C, lda=C, ldw=C, ldc=C, epi=UD_EPI_QKV, vsplit=C,
+                   tok_per_img=hw, kv_ld=hwk, heads_v=heads, tag="v1." + pre + "kv")
+            P.attention(Q=q, K=k, Vt=vt, O=ao, B=B, H=heads, Nq=hw, Nk=hw, ldq=C, ldk=C, ldo=C, kv_ld=hwk, q_rows_per_img=hw, k_rows_per_img=hw,
+                        scale=(C // heads) ** -0.5, tag="v1.l16.attn")
+            gemm(ao, pre + "out", lat, Mt, C, C, epi=UD_EPI_F32, accumulate=1)
+            mlp(lat, pre, Mt, C, 4)
+        tap("latents_16", lambda: lat.view(B, hw, C).clone())
+        self.depth_features_src = (lat, h, wd, C)
+
+        # ---------------- ConvUpsample (layers/upsample.py:13-45) and the 3x3 -> 1 output convs (decoder.py:267-271)
+        def conv_upsample(nm, x_tok, e_tok, hh, ww, Cl):
+            n = hh * ww
+            xs = z(B * n, Cl, dtype=f32)
+            P.v1(L.UD_V1_ADD, a=x_tok, b=e_tok, out=xs, i=((B * n * Cl) & 0x7fffffff, (B * n * Cl) >> 31), tag="add")
+            y = z(B * n, Cl, dtype=f32); xh = z(B * n, Cl); hid = z(B * n, 4 * Cl)
+            for c in range(2):
+                pre = f"{nm}.{c}."
+                P.dwconv7(x=xs, w=w[pre + "dw.w"], bias=w[pre + "dw.b"], y=y, B=B, H=hh, W=ww, C=Cl, ldx=Cl, ldy=Cl, tag="v1.dwconv")
+                ln(y, xh, B * n, Cl)
+                gemm(xh, pre + "fc1", hid, B * n, 4 * Cl, Cl, epi=UD_EPI_F16, act=UD_ACT_GELU)
+                gemm(hid, pre + "fc2", xs, B * n, Cl, 4 * Cl, epi=UD_EPI_F32, accumulate=1)
+            x16 = z(B * n, Cl)
+            P.v1(L.UD_V1_COPY_ROWS, a=xs, out=x16, i=(1, B * n, B * n, 0, Cl, Cl, 1), tag="to_f16")
+            u0 = z(B * n, Cl // 2)
+            gemm(x16, f"{nm}.up0", u0, B * n, Cl // 2, Cl, epi=UD_EPI_F16)
+            u1 = z(B * 4 * n, Cl // 2)
+            P.resize_ac(in_=u0, out=u1, G=1, B=B, Hin=hh, Win=ww, Hout=2 * hh, Wout=2 * ww, C=Cl // 2)                  # UpsamplingBilinear2d = align_corners
+            nxt = z(B * 4 * n, Cl // 2, dtype=f32); nxt16 = z(B * 4 * n, Cl // 2)
+            kp = w[f"{nm}.up2.w"].shape[1]
+            P.gemm(A=u1, W=w[f"{nm}.up2.w"], bias=w[f"{nm}.up2.b"], out=nxt, out2=nxt16, zeros=zeros, M=B * 4 * n, N=Cl // 2, K=kp, ldw=kp, ldc=Cl // 2,
+                   ldc2=Cl // 2, amode=UD_A_CONV3_ZERO, epi=UD_EPI_F32, Himg=2 * hh, Wimg=2 * ww, Cin=Cl // 2, cstride=Cl // 2, coff=0, rows_img=4 * n,
+                   img_stride=4 * n * (Cl // 2), tag=f"v1.{nm}.conv3")
+            return nxt, nxt16
+
+        def out_conv(nm, x16, hh, ww, Cl):
+            o = z(B * hh * ww, 4, dtype=f32)
+            kp = w[nm + ".w"].shape[1]
+            P.gemm(A=x16, W=w[nm + ".w"], bias=w[nm + ".b"], out=o, zeros=zeros, M=B * hh * ww, N=4, K=kp, ldw=kp, ldc=4, amode=UD_A_CONV3_ZERO, epi=UD_EPI_F32,
+                   act=L.UD_ACT_CLAMPEXP, Himg=hh, Wimg=ww, Cin=Cl, cstride=Cl, coff=0, rows_img=hh * ww, img_stride=hh * ww * Cl, tag="v1." + nm)
+            return o
+
+        # ---------------- Nystrom attention block (layers/nystrom_attention.py:22-84; xformers NystromAttention, 128 landmarks -- PARITY UNPINNED)
+        def nystrom_block(pre, x, e_tok, n, Cl, nh):
+            M = B * n
+            npad = _rup(n, 64)
+            Lm = 128
+            xn = z(M, Cl); q = z(M, Cl); k = z(M, Cl); vt = z(B, Cl, npad); ao = z(M, Cl)
+            ln(x, xn, M, Cl)
+            gemm(xn, pre + "q", q, M, Cl, Cl, epi=UD_EPI_F16, add=e_tok, ldadd=Cl)
+            gemm(xn, pre + "k", k, M, Cl, Cl, epi=UD_EPI_F16)
+            P.gemm(A=w[pre + "v.w"], W=xn, out=vt, M=Cl, N=n, K=Cl, lda=Cl, ldw=Cl, ldc=npad, epi=UD_EPI_F16, groups=B, gA=0, gW=n * Cl, gOut=Cl * npad, tag="v1.nys.vT")
+            ql = z(B * Lm, Cl); kl = z(B * Lm, Cl)
+            P.v1(L.UD_V1_SEGMENT_MEAN, a=q, out=ql, i=(B, n, Cl, Lm, Cl, Cl), tag="landmarks")
+            P.v1(L.UD_V1_SEGMENT_MEAN, a=k, out=kl, i=(B, n, Cl, Lm, Cl, Cl), tag="landmarks")
+            sc = 64 ** -0.5
+            S1 = z(M, Lm, dtype=f32); P1 = z(M, Lm); S2 = z(B * Lm, Lm, dtype=f32); K2 = z(B * Lm, Lm, dtype=f32)
+            S3 = z(B * Lm, n, dtype=f32); P3 = z(B * Lm, npad); k3 = z(B * Lm, 64, dtype=f32)
+            Z = z(B * Lm, Lm, dtype=f32); Zn = z(B * Lm, Lm, dtype=f32); KZ = z(B * Lm, Lm, dtype=f32); T1 = z(B * Lm, Lm, dtype=f32); T2 = z(B * Lm, Lm, dtype=f32)
+            T = z(B * Lm, 64, dtype=f32); Tt = z(B * 64, Lm)
+            for hd in range(nh):
+                o2 = hd * 64 * 2                                                 # byte offset of the head's 64 columns in an fp16 row
+                P.gemm(A=q.data_ptr() + o2, W=kl.data_ptr() + o2, out=S1, M=n, N=Lm, K=64, lda=Cl, ldw=Cl, ldc=Lm, epi=UD_EPI_F32, groups=B, gA=n * Cl,
+                       gW=Lm * Cl, gOut=n * Lm, tag="v1.nys.k1")
+                P.v1(L.UD_V1_SOFTMAX, a=S1, out=P1, i=(M, Lm, Lm, Lm, 0, 0), f=(sc,), tag="softmax")
+                P.gemm(A=ql.data_ptr() + o2, W=kl.data_ptr() + o2, out=S2, M=Lm, N=Lm, K=64, lda=Cl, ldw=Cl, ldc=Lm, epi=UD_EPI_F32, groups=B, gA=Lm * Cl,
+                       gW=Lm * Cl, gOut=Lm * Lm, tag="v1.nys.k2")
+                P.v1(L.UD_V1_SOFTMAX, a=S2, out=K2, i=(B * Lm, Lm, Lm, Lm, 1, 0), f=(sc,), tag="softmax")
+                P.gemm(A=ql.data_ptr() + o2, W=k.data_ptr() + o2, out=S3, M=Lm, N=n, K=64, lda=Cl, ldw=Cl, ldc=n, epi=UD_EPI_F32, groups=B, gA=Lm * Cl,
+                       gW=n * Cl, gOut=Lm * n, tag="v1.nys.k3")
+                P.v1(L.UD_V1_SOFTMAX, a=S3, out=P3, i=(B * Lm, n, n, npad, 0, 0), f=(sc,), tag="softmax")
+                P.gemm(A=P3, W=vt.data_ptr() + hd * 64 * npad * 2, bias=w[pre + "v.b"].data_ptr() + hd * 64 * 4, out=k3, M=Lm, N=64, K=npad, lda=npad, ldw=npad,
+                       ldc=64, epi=UD_EPI_F32, groups=B, gA=Lm * npad, gW=Cl * npad, gBias=0, gOut=Lm * 64, tag="v1.nys.k3v")
+                # pseudo-inverse of kernel_2: Z0 = K^T / ||K||_1, six Newton-Schulz steps Z <- 1/4 Z (13 I - KZ (15 I - KZ (7 I - KZ)))
+                P.v1(L.UD_V1_PINV_INIT, a=K2, out=Z, i=(B, Lm), tag="pinv")
+                za, zb = Z, Zn
+                for _ in range(6):
+                    P.v1(L.UD_V1_BMM, a=K2, b=za, out=KZ, i=(B, Lm, Lm, Lm), f=(1.0, 0.0), tag="pinv")        # KZ
+                    P.v1(L.UD_V1_BMM, a=K2, b=za, out=T1, i=(B, Lm, Lm, Lm), f=(-1.0, 7.0), tag="pinv")       # 7 I - KZ
+                    P.v1(L.UD_V1_BMM, a=KZ, b=T1, out=T2, i=(B, Lm, Lm, Lm), f=(-1.0, 15.0), tag="pinv")      # 15 I - KZ (7 I - KZ)
+                    P.v1(L.UD_V1_BMM, a=KZ, b=T2, out=T1, i=(B, Lm, Lm, Lm), f=(-1.0, 13.0), tag="pinv")      # 13 I - KZ (...)
+                    P.v1(L.UD_V1_BMM, a=za, b=T1, out=zb, i=(B, Lm, Lm, Lm), f=(0.25, 0.0), tag="pinv")       # Z <- 1/4 Z (...)
+                    za, zb = zb, za
+                P.v1(L.UD_V1_BMM, a=za, b=k3, out=T, i=(B, Lm, 64, Lm), f=(1.0, 0.0), tag="nys.pinv_k3")
+                P.v1(L.UD_V1_TRANSPOSE16, a=T, out=Tt, i=(B, Lm, 64, Lm), tag="nys.T")
+                P.gemm(A=P1, W=Tt, out=ao.data_ptr() + o2, M=n, N=64, K=Lm, lda=Lm, ldw=Lm, ldc=Cl, epi=UD_EPI_F16, groups=B, gA=n * Lm, gW=64 * Lm, gOut=n * Cl,
+                       tag="v1.nys.out")
+            gemm(ao, pre + "out", x, M, Cl, Cl, epi=UD_EPI_F32, accumulate=1)
+            mlp(x, pre, M, Cl, 4)
+            self._keep = getattr(self, "_keep", []) + [q, k, kl, ql, vt, ao, xn]        # raw-pointer operands of the per-head launches
+
+        lat8, lat8_16 = conv_upsample("up8", lat, e16, h, wd, C)
+        o8 = out_conv("out8", lat8_16, 2 * h, 2 * wd, C // 2)
+        for i in range(dec_depths[1]):
+            nystrom_block(f"layers_8.{i}.", lat8, e8, 4 * hw, C // 2, heads // 2)
+        lat4, lat4_16 = conv_upsample("up4", lat8, e8, 2 * h, 2 * wd, C // 2)
+        o4 = out_conv("out4", lat4_16, 4 * h, 4 * wd, C // 4)
+        for i in range(dec_depths[2]):
+            nystrom_block(f"layers_4.{i}.", lat4, e4, 16 * hw, C // 4, heads // 4)
+        lat2, lat2_16 = conv_upsample("up2", lat4, e4, 4 * h, 4 * wd, C // 4)
+        o2 = out_conv("out2", lat2_16, 8 * h, 8 * wd, C // 8)
+        tap("out8", lambda: o8.view(B, 2 * h, 2 * wd, 4)[..., 0].clone())
+        tap("out2", lambda: o2.view(B, 8 * h, 8 * wd, 4)[..., 0].clone())
+        # ---------------- multi-scale mean at network resolution, pad crop + resize to the input size (unidepthv1.py:66-86)
+        rs = []
+        for o, m in ((o8, 2), (o4, 4), (o2, 8)):
+            r = z(B * Hn * Wn, 4, dtype=f32)
+            P.v1(L.UD_V1_RESIZE_AA, a=o, out=r, i=(B, m * h, m * wd, Hn, Wn, 4, 4, 4, 0, 0, m * h, m * wd), tag="resize_aa")
+            rs.append(r)
+        pred = z(B * Hn * Wn, 4, dtype=f32)
+        P.v1(L.UD_V1_MEAN3, a=rs[0], b=rs[1], c=rs[2], out=pred, i=((B * Hn * Wn) & 0x7fffffff, 4, (B * Hn * Wn) >> 31), tag="mean3")
+        self.zout = z(B * H * W, 4, dtype=f32)
+        P.v1(L.UD_V1_RESIZE_AA, a=pred, out=self.zout, i=(B, Hn, Wn, H, W, 4, 4, 4, pt, pl, Hn - pt - pb, Wn - pl - pr), tag="resize_aa")
