@@ -347,11 +347,16 @@ class OracleV1(OracleConvNeXt):
             r = F.normalize(flat_interpolate(rays_hr, original, (h * mult, w_ * mult)), dim=-1)
             emb.append(self._mlp(real_sh_deg8(r), f"{dl}{nm}."))
         e16, e8, e4 = emb
+        T = self.taps_v1
+        T["rays_embedding_16"] = e16
         tokens = torch.cat(features, dim=1)
         f16 = self._lin(torch.cat(features, dim=-1), dl + "features_channel_cat")
         lat16 = self._mlp(f16, dl + "to_latents.")
+        T["to_latents"] = lat16
         lat16 = self._attn_block(lat16, dl + "aggregate_16.", 1, context=tokens, pos_embed_context=pos + level_embed)
+        T["aggregate_16"] = lat16
         lat16 = self._attn_block(lat16, dl + "prompt_camera.", 1, context=e16)
+        T["prompt_camera"] = lat16
         for i in range(self.dec_depths[0]):
             lat16 = self._attn_block(lat16, f"{dl}layers_16.{i}.", heads, pos_embed=e16)
         self.taps_v1["latents_16"] = lat16
@@ -359,16 +364,22 @@ class OracleV1(OracleConvNeXt):
         def nchw(t, hh, ww):
             return t.permute(0, 2, 1).reshape(B, -1, hh, ww).contiguous()
         lat8 = self._conv_upsample(nchw(lat16 + e16, h, w_), dl + "up8.")
+        T["up8"] = lat8
         out8 = F.conv2d(nchw(lat8, 2 * h, 2 * w_), self.w[dl + "out8.weight"], self.w[dl + "out8.bias"], padding=1)
         for i in range(self.dec_depths[1]):
             lat8 = self._attn_block(lat8, f"{dl}layers_8.{i}.", heads // 2, pos_embed=e8, nystrom=True)
+        T["layers_8"] = lat8
         lat4 = self._conv_upsample(nchw(lat8 + e8, 2 * h, 2 * w_), dl + "up4.")
+        T["up4"] = lat4
         out4 = F.conv2d(nchw(lat4, 4 * h, 4 * w_), self.w[dl + "out4.weight"], self.w[dl + "out4.bias"], padding=1)
         for i in range(self.dec_depths[2]):
             lat4 = self._attn_block(lat4, f"{dl}layers_4.{i}.", heads // 4, pos_embed=e4, nystrom=True)
+        T["layers_4"] = lat4
         lat2 = self._conv_upsample(nchw(lat4 + e4, 4 * h, 4 * w_), dl + "up2.")
+        T["up2"] = lat2
         out2 = F.conv2d(nchw(lat2, 8 * h, 8 * w_), self.w[dl + "out2.weight"], self.w[dl + "out2.bias"], padding=1)
         ms = [o.clamp(-10.0, 10.0).exp() for o in (out8, out4, out2)]
+        T["out8"], T["out4"], T["out2"] = [m[:, 0] for m in ms]
         return ms, nchw(lat16, h, w_)
 
     # ---- infer (unidepthv1.py:288-373)

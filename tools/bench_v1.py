@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""UniDepthV1 (ConvNeXt-L) on one MI355X at BASELINE.json configs[3]: 640x480 inputs, batch 16.  Prints images/s, ms per infer() and the
+per-kernel-class breakdown (HIP events around every launch of the program).  GPU box only."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from oracle import synth_v1
+from unidepth_amd import UniDepthV1
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+cfg = synth_v1.load_config_v1(); sd = synth_v1.make_synthetic_checkpoint_v1(cfg, 211)
+m = UniDepthV1(cfg).load_state_dict(sd).to("cuda").eval()
+rgb = torch.randint(0, 256, (B, 3, 480, 640), dtype=torch.uint8, generator=torch.Generator().manual_seed(1)).cuda()
+for _ in range(3): m.infer(rgb)
+torch.cuda.synchronize()
+t0 = time.perf_counter(); K = 10
+for _ in range(K): m.infer(rgb)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / K
+plan = next(reversed(m._plans.values())); P = plan.prog; n = len(P)
+tot = {}
+for rep in range(2):
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    evs[0].record()
+    for i in range(n):
+        P.run(i, i + 1); evs[i + 1].record()
+    torch.cuda.synchronize()
+    if rep:
+        for i in range(n):
+            cls, tag, fl, nb = P.meta[i]
+            key = cls if cls.startswith("gemm") or cls.startswith("conv") else tag if cls.startswith("v1.") else cls
+            d = tot.setdefault(key, [0.0, 0.0, 0]); d[0] += evs[i].elapsed_time(evs[i + 1]); d[1] += fl; d[2] += 1
+enc_ms = sum(evs[i].elapsed_time(evs[i + 1]) for i in range(plan.dec_first))
+print(json.dumps({"workload": f"UniDepthV1 ConvNeXt-L infer(), 640x480, bs={B}", "images_per_s": round(B / dt, 2), "ms_per_infer": round(dt * 1e3, 3),
+                  "launches": n, "encoder_ms": round(enc_ms, 3), "decoder_ms": round(sum(v[0] for v in tot.values()) - enc_ms, 3)}))
+for k, v in sorted(tot.items(), key=lambda kv: -kv[1][0])[:24]:
+    print(f"  {k:58s} {v[0]:8.3f} ms  x{v[2]:4d}  {v[1] / (v[0] * 1e-3) / 1e12 if v[1] else 0:7.1f} TF")

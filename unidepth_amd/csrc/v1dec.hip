@@ -213,24 +213,51 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(const half_t* in, hal
 }
 
 // batched fp32 matmul of small square-ish matrices, C = diag * I + alpha * A B  (A [G, M, K], B [G, K, N], row-major, all <= 128):
-// the Newton-Schulz pseudo-inverse iterations (xformers iterative_pinv) and pinv @ kernel_3.  Block = (16 x 16 output tile, group).
+// the Newton-Schulz pseudo-inverse iterations (xformers iterative_pinv) and pinv @ kernel_3.
 __global__ __launch_bounds__(256) void bmm_small_kernel(const float* A, const float* Bm, float* Cm, int M, int N, int K, float alpha, float diag) {
-  __shared__ float as[16][17], bs[16][17];
-  const int g = blockIdx.z;
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int row = blockIdx.y * 16 + ty, col = blockIdx.x * 16 + tx;
+  // 64 x 64 output tile per block, 4 x 4 per thread, K in steps of 16 through LDS
+  __shared__ float as[16][68], bs[16][68];
+  const int g = blockIdx.z, tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
   const float* a = A + (size_t)g * M * K;
   const float* b = Bm + (size_t)g * K * N;
-  float acc = 0.f;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
   for (int k0 = 0; k0 < K; k0 += 16) {
-    as[ty][tx] = (row < M && k0 + tx < K) ? a[(size_t)row * K + k0 + tx] : 0.f;
-    bs[ty][tx] = (k0 + ty < K && col < N) ? b[(size_t)(k0 + ty) * N + col] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = tid + e * 256;
+      const int am = idx >> 4, ak = idx & 15;                 // A tile: 64 rows x 16 k (k fastest: coalesced 64-byte runs)
+      as[ak][am] = (m0 + am < M && k0 + ak < K) ? a[(size_t)(m0 + am) * K + k0 + ak] : 0.f;
+      const int bk = idx >> 6, bn = idx & 63;                 // B tile: 16 k x 64 columns
+      bs[bk][bn] = (k0 + bk < K && n0 + bn < N) ? b[(size_t)(k0 + bk) * N + n0 + bn] : 0.f;
+    }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc = fmaf(as[ty][k], bs[k][tx], acc);
+    for (int k = 0; k < 16; ++k) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) av[i] = as[k][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = bs[k][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
     __syncthreads();
   }
-  if (row < M && col < N) Cm[((size_t)g * M + row) * N + col] = alpha * acc + (row == col ? diag : 0.f);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = m0 + ty * 4 + i, col = n0 + tx * 4 + j;
+      if (row < M && col < N) Cm[((size_t)g * M + row) * N + col] = alpha * acc[i][j] + (row == col ? diag : 0.f);
+    }
 }
 
 // Z0 = K^T / max_j sum_i K[i, j]  (xformers iterative_pinv, exact 1 / ||K||_1 initialisation), K fp32 [G, n, n], n <= 256.  Block = group.
@@ -410,7 +437,7 @@ extern "C" int ud_v1_op(const UdV1Op* desc, void* stream) {
     }
     case UD_V1_BMM: {            // a, b fp32, out fp32: out[g] = f[1] * I + f[0] * a[g] b[g]; i = G, M, N, K
       if (!d.a || !d.b || !d.out || i[0] <= 0 || i[1] <= 0 || i[2] <= 0 || i[3] <= 0) break;
-      hipLaunchKernelGGL(bmm_small_kernel, dim3((i[2] + 15) / 16, (i[1] + 15) / 16, i[0]), dim3(256), 0, s, (const float*)d.a, (const float*)d.b, (float*)d.out, i[1], i[2], i[3], d.f[0], d.f[1]);
+      hipLaunchKernelGGL(bmm_small_kernel, dim3((i[2] + 63) / 64, (i[1] + 63) / 64, i[0]), dim3(256), 0, s, (const float*)d.a, (const float*)d.b, (float*)d.out, i[1], i[2], i[3], d.f[0], d.f[1]);
       UD_CHECK_LAUNCH("ud_v1_op(bmm) launch");
       return UD_OK;
     }

@@ -485,6 +485,20 @@ class UniDepthV1:
 
     __call__ = infer
 
+    @torch.no_grad()
+    def infer_with_taps(self, rgbs: torch.Tensor, intrinsics=None, skip_camera: bool = False):
+        """infer() + the decoder's intermediate tensors (segmented replay of the launch program; parity tooling)."""
+        out = self.infer(rgbs, intrinsics, skip_camera)             # builds / refreshes the plan and its inputs
+        plan = next(reversed(self._plans.values()))
+        taps, pos = {}, 0
+        with torch.cuda.device(self._device):
+            for name, at, fn in sorted(plan.tap_points, key=lambda t: t[1]):
+                if at > pos:
+                    plan.prog.run(pos, at)
+                    pos = at
+                taps[name] = fn()
+            plan.prog.run(pos, len(plan.prog))
+        return out, taps
 
 # =====================================================================================================================
 # Full infer() plan: pre-processing + encoder + decoder + post-processing
@@ -688,6 +702,7 @@ class _FullPlan:
         lat2 = z(Mt, C, dtype=f32)
         mlp(lat, "tolat.", Mt, C, 2, accumulate=0, out=lat2)
         lat = lat2
+        tap("to_latents", lambda: lat.view(B, hw, C).clone())
 
         # ---------------- single-head attention of width C via GEMMs: S = Q K^T (fp32), row softmax, O = P V (layers/attention.py:109-142)
         def big_attn(pre, x, ctxn, Nk, add_k=None):
@@ -715,9 +730,11 @@ class _FullPlan:
         for j in range(4):
             P.layernorm(x=feat[j], y=tokn, rows=Mt, D=C, ldx=C, ldy=C, eps=1e-5, rows_per_img=hw, in_rows_per_img=hw, out_rows_per_img=Nc, out_row_off=j * hw)
         big_attn("agg16.", lat, tokn, Nc, add_k=pos_lvl)
+        tap("aggregate_16", lambda: lat.view(B, hw, C).clone())
         e16n = z(Mt, C)
         ln(e16, e16n, Mt, C)
         big_attn("pcam.", lat, e16n, hw)
+        tap("prompt_camera", lambda: lat.view(B, hw, C).clone())
         # ---------------- layers_16: self-attention, 8 heads of 64, ray embedding added to q (decoder.py:246-247)
         hwk = _rup(hw, 64)
         for i in range(dec_depths[0]):
@@ -780,52 +797,61 @@ class _FullPlan:
             P.v1(L.UD_V1_SEGMENT_MEAN, a=q, out=ql, i=(B, n, Cl, Lm, Cl, Cl), tag="landmarks")
             P.v1(L.UD_V1_SEGMENT_MEAN, a=k, out=kl, i=(B, n, Cl, Lm, Cl, Cl), tag="landmarks")
             sc = 64 ** -0.5
-            S1 = z(M, Lm, dtype=f32); P1 = z(M, Lm); S2 = z(B * Lm, Lm, dtype=f32); K2 = z(B * Lm, Lm, dtype=f32)
-            S3 = z(B * Lm, n, dtype=f32); P3 = z(B * Lm, npad); k3 = z(B * Lm, 64, dtype=f32)
-            Z = z(B * Lm, Lm, dtype=f32); Zn = z(B * Lm, Lm, dtype=f32); KZ = z(B * Lm, Lm, dtype=f32); T1 = z(B * Lm, Lm, dtype=f32); T2 = z(B * Lm, Lm, dtype=f32)
-            T = z(B * Lm, 64, dtype=f32); Tt = z(B * 64, Lm)
+            G = nh * B                                                         # (head, image) groups of the small fp32 matrices
+            S1 = z(M, Lm, dtype=f32); P1 = z(nh, M, Lm); S2 = z(B * Lm, Lm, dtype=f32); K2 = z(G * Lm, Lm, dtype=f32)
+            S3 = z(B * Lm, n, dtype=f32); P3 = z(B * Lm, npad); k3 = z(G * Lm, 64, dtype=f32)
+            Z = z(G * Lm, Lm, dtype=f32); Zn = z(G * Lm, Lm, dtype=f32); KZ = z(G * Lm, Lm, dtype=f32); T1 = z(G * Lm, Lm, dtype=f32); T2 = z(G * Lm, Lm, dtype=f32)
+            T = z(G * Lm, 64, dtype=f32); Tt = z(G * 64, Lm)
             for hd in range(nh):
                 o2 = hd * 64 * 2                                                 # byte offset of the head's 64 columns in an fp16 row
                 P.gemm(A=q.data_ptr() + o2, W=kl.data_ptr() + o2, out=S1, M=n, N=Lm, K=64, lda=Cl, ldw=Cl, ldc=Lm, epi=UD_EPI_F32, groups=B, gA=n * Cl,
                        gW=Lm * Cl, gOut=n * Lm, tag="v1.nys.k1")
-                P.v1(L.UD_V1_SOFTMAX, a=S1, out=P1, i=(M, Lm, Lm, Lm, 0, 0), f=(sc,), tag="softmax")
+                P.v1(L.UD_V1_SOFTMAX, a=S1, out=P1[hd], i=(M, Lm, Lm, Lm, 0, 0), f=(sc,), tag="softmax")
                 P.gemm(A=ql.data_ptr() + o2, W=kl.data_ptr() + o2, out=S2, M=Lm, N=Lm, K=64, lda=Cl, ldw=Cl, ldc=Lm, epi=UD_EPI_F32, groups=B, gA=Lm * Cl,
                        gW=Lm * Cl, gOut=Lm * Lm, tag="v1.nys.k2")
-                P.v1(L.UD_V1_SOFTMAX, a=S2, out=K2, i=(B * Lm, Lm, Lm, Lm, 1, 0), f=(sc,), tag="softmax")
+                P.v1(L.UD_V1_SOFTMAX, a=S2, out=K2[hd * B * Lm:(hd + 1) * B * Lm], i=(B * Lm, Lm, Lm, Lm, 1, 0), f=(sc,), tag="softmax")
                 P.gemm(A=ql.data_ptr() + o2, W=k.data_ptr() + o2, out=S3, M=Lm, N=n, K=64, lda=Cl, ldw=Cl, ldc=n, epi=UD_EPI_F32, groups=B, gA=Lm * Cl,
                        gW=n * Cl, gOut=Lm * n, tag="v1.nys.k3")
                 P.v1(L.UD_V1_SOFTMAX, a=S3, out=P3, i=(B * Lm, n, n, npad, 0, 0), f=(sc,), tag="softmax")
-                P.gemm(A=P3, W=vt.data_ptr() + hd * 64 * npad * 2, bias=w[pre + "v.b"].data_ptr() + hd * 64 * 4, out=k3, M=Lm, N=64, K=npad, lda=npad, ldw=npad,
-                       ldc=64, epi=UD_EPI_F32, groups=B, gA=Lm * npad, gW=Cl * npad, gBias=0, gOut=Lm * 64, tag="v1.nys.k3v")
-                # pseudo-inverse of kernel_2: Z0 = K^T / ||K||_1, six Newton-Schulz steps Z <- 1/4 Z (13 I - KZ (15 I - KZ (7 I - KZ)))
-                P.v1(L.UD_V1_PINV_INIT, a=K2, out=Z, i=(B, Lm), tag="pinv")
-                za, zb = Z, Zn
-                for _ in range(6):
-                    P.v1(L.UD_V1_BMM, a=K2, b=za, out=KZ, i=(B, Lm, Lm, Lm), f=(1.0, 0.0), tag="pinv")        # KZ
-                    P.v1(L.UD_V1_BMM, a=K2, b=za, out=T1, i=(B, Lm, Lm, Lm), f=(-1.0, 7.0), tag="pinv")       # 7 I - KZ
-                    P.v1(L.UD_V1_BMM, a=KZ, b=T1, out=T2, i=(B, Lm, Lm, Lm), f=(-1.0, 15.0), tag="pinv")      # 15 I - KZ (7 I - KZ)
-                    P.v1(L.UD_V1_BMM, a=KZ, b=T2, out=T1, i=(B, Lm, Lm, Lm), f=(-1.0, 13.0), tag="pinv")      # 13 I - KZ (...)
-                    P.v1(L.UD_V1_BMM, a=za, b=T1, out=zb, i=(B, Lm, Lm, Lm), f=(0.25, 0.0), tag="pinv")       # Z <- 1/4 Z (...)
-                    za, zb = zb, za
-                P.v1(L.UD_V1_BMM, a=za, b=k3, out=T, i=(B, Lm, 64, Lm), f=(1.0, 0.0), tag="nys.pinv_k3")
-                P.v1(L.UD_V1_TRANSPOSE16, a=T, out=Tt, i=(B, Lm, 64, Lm), tag="nys.T")
-                P.gemm(A=P1, W=Tt, out=ao.data_ptr() + o2, M=n, N=64, K=Lm, lda=Lm, ldw=Lm, ldc=Cl, epi=UD_EPI_F16, groups=B, gA=n * Lm, gW=64 * Lm, gOut=n * Cl,
-                       tag="v1.nys.out")
+                P.gemm(A=P3, W=vt.data_ptr() + hd * 64 * npad * 2, bias=w[pre + "v.b"].data_ptr() + hd * 64 * 4, out=k3[hd * B * Lm:(hd + 1) * B * Lm], M=Lm, N=64,
+                       K=npad, lda=npad, ldw=npad, ldc=64, epi=UD_EPI_F32, groups=B, gA=Lm * npad, gW=Cl * npad, gBias=0, gOut=Lm * 64, tag="v1.nys.k3v")
+            # pseudo-inverse of kernel_2 for all (head, image) pairs at once: Z0 = K^T / ||K||_1, six Newton-Schulz steps
+            # Z <- 1/4 Z (13 I - KZ (15 I - KZ (7 I - KZ)))
+            P.v1(L.UD_V1_PINV_INIT, a=K2, out=Z, i=(G, Lm), tag="pinv")
+            za, zb = Z, Zn
+            for _ in range(6):
+                P.v1(L.UD_V1_BMM, a=K2, b=za, out=KZ, i=(G, Lm, Lm, Lm), f=(1.0, 0.0), tag="pinv")        # KZ
+                P.v1(L.UD_V1_BMM, a=K2, b=za, out=T1, i=(G, Lm, Lm, Lm), f=(-1.0, 7.0), tag="pinv")       # 7 I - KZ
+                P.v1(L.UD_V1_BMM, a=KZ, b=T1, out=T2, i=(G, Lm, Lm, Lm), f=(-1.0, 15.0), tag="pinv")      # 15 I - KZ (7 I - KZ)
+                P.v1(L.UD_V1_BMM, a=KZ, b=T2, out=T1, i=(G, Lm, Lm, Lm), f=(-1.0, 13.0), tag="pinv")      # 13 I - KZ (...)
+                P.v1(L.UD_V1_BMM, a=za, b=T1, out=zb, i=(G, Lm, Lm, Lm), f=(0.25, 0.0), tag="pinv")       # Z <- 1/4 Z (...)
+                za, zb = zb, za
+            P.v1(L.UD_V1_BMM, a=za, b=k3, out=T, i=(G, Lm, 64, Lm), f=(1.0, 0.0), tag="nys.pinv_k3")
+            P.v1(L.UD_V1_TRANSPOSE16, a=T, out=Tt, i=(G, Lm, 64, Lm), tag="nys.T")
+            for hd in range(nh):
+                P.gemm(A=P1[hd], W=Tt[hd * B * 64:(hd + 1) * B * 64], out=ao.data_ptr() + hd * 64 * 2, M=n, N=64, K=Lm, lda=Lm, ldw=Lm, ldc=Cl, epi=UD_EPI_F16,
+                       groups=B, gA=n * Lm, gW=64 * Lm, gOut=n * Cl, tag="v1.nys.out")
             gemm(ao, pre + "out", x, M, Cl, Cl, epi=UD_EPI_F32, accumulate=1)
             mlp(x, pre, M, Cl, 4)
             self._keep = getattr(self, "_keep", []) + [q, k, kl, ql, vt, ao, xn]        # raw-pointer operands of the per-head launches
 
         lat8, lat8_16 = conv_upsample("up8", lat, e16, h, wd, C)
+        tap("up8", lambda: lat8.view(B, 4 * hw, C // 2).clone())
         o8 = out_conv("out8", lat8_16, 2 * h, 2 * wd, C // 2)
         for i in range(dec_depths[1]):
             nystrom_block(f"layers_8.{i}.", lat8, e8, 4 * hw, C // 2, heads // 2)
+        tap("layers_8", lambda: lat8.view(B, 4 * hw, C // 2).clone())
         lat4, lat4_16 = conv_upsample("up4", lat8, e8, 2 * h, 2 * wd, C // 2)
+        tap("up4", lambda: lat4.view(B, 16 * hw, C // 4).clone())
         o4 = out_conv("out4", lat4_16, 4 * h, 4 * wd, C // 4)
         for i in range(dec_depths[2]):
             nystrom_block(f"layers_4.{i}.", lat4, e4, 16 * hw, C // 4, heads // 4)
+        tap("layers_4", lambda: lat4.view(B, 16 * hw, C // 4).clone())
         lat2, lat2_16 = conv_upsample("up2", lat4, e4, 4 * h, 4 * wd, C // 4)
+        tap("up2", lambda: lat2.view(B, 64 * hw, C // 8).clone())
         o2 = out_conv("out2", lat2_16, 8 * h, 8 * wd, C // 8)
         tap("out8", lambda: o8.view(B, 2 * h, 2 * wd, 4)[..., 0].clone())
+        tap("out4", lambda: o4.view(B, 4 * h, 4 * wd, 4)[..., 0].clone())
         tap("out2", lambda: o2.view(B, 8 * h, 8 * wd, 4)[..., 0].clone())
         # ---------------- multi-scale mean at network resolution, pad crop + resize to the input size (unidepthv1.py:66-86)
         rs = []
