@@ -144,6 +144,8 @@ typedef struct UdAttention {
   float scale;
   int kv_broadcast;
   int kv_group;           /* with kv_broadcast: image i uses the K/V of image i / kv_group (0 -> all share image 0) */
+  int q_prescaled;        /* != 0: Q already holds q * scale * log2(e) (folded into the q projection by the caller): `scale` is ignored and the
+                           * kernel skips the per-score multiply (softmax(q k^T scale) is unchanged) */
 } UdAttention;
 int ud_attention_f16(const UdAttention* desc, void* stream);
 

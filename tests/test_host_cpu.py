@@ -69,6 +69,8 @@ def test_weight_folding_algebra_matches_oracle_blocks():
     ref = F.linear(F.layer_norm(x, (D,), sd["pixel_encoder.blocks.3.norm1.weight"], sd["pixel_encoder.blocks.3.norm1.bias"], 1e-6),
                    sd["pixel_encoder.blocks.3.attn.qkv.weight"], sd["pixel_encoder.blocks.3.attn.qkv.bias"])
     got = F.linear(F.layer_norm(x, (D,), eps=1e-6), w["enc.3.qkv.w"].float()[:, :D], w["enc.3.qkv.b"])
+    qc = (D // a["heads"]) ** -0.5 * weights.LOG2E         # the q rows carry the softmax scale and log2(e) (UdAttention.q_prescaled)
+    got[:, :D] /= qc
     assert (got - ref).norm() / ref.norm() < 2e-3          # fp16 weight rounding only
     # decoder cross-attention block 1 end to end on a tiny problem, fp32 activations
     orc = restate.OracleV2(cfg, sd)
@@ -80,7 +82,7 @@ def test_weight_folding_algebra_matches_oracle_blocks():
     kv = F.linear(F.layer_norm(ctx, (C,), eps=1e-5), g("kv.w").float()[:, :C], g("kv.b"))
     k = kv[..., : H * 64].view(2, 5, H, 64).transpose(1, 2)
     v = kv[..., H * 64:].view(2, 5, H, 64).transpose(1, 2)
-    o = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v
+    o = torch.softmax(q @ k.transpose(-1, -2) / weights.LOG2E, -1) @ v       # q already holds hd^-1/2 * log2(e)
     y = xq + F.linear(o.transpose(1, 2).reshape(2, 7, H * 64), g("out.w").float())
     hmid = F.gelu(F.linear(F.layer_norm(y, (C,), eps=1e-5), g("fc1.w").float(), g("fc1.b")))
     y = y + F.linear(hmid, g("fc2.w").float(), g("fc2.b"))

@@ -669,3 +669,38 @@ def test_program_replay_matches_eager(ops):
     assert torch.equal(o1, o2)
     with pytest.raises(RuntimeError):
         ops.gemm(A=A, W=W, out=o1, M=M, N=N, K=100, lda=K, ldw=K, ldc=N, epi=ops.UD_EPI_F16)   # K % 64 != 0 -> error code
+
+
+@pytest.mark.parametrize("N,spike", [(1370, False), (300, True), (64, False)])
+def test_attention_prescaled_q_matches_classic_path(ops, N, spike):
+    """UdAttention.q_prescaled: Q holding q * scale * log2(e) (what the engine's folded q projection produces) must give the same
+    attention as the classic (Q, scale) call -- including rows whose maximum jumps late in the key sequence (rescale path)."""
+    B, H = 2, 3
+    D = H * 64
+    Np, kvld = (N + 15) // 16 * 16, (N + 63) // 64 * 64
+    g = torch.Generator().manual_seed(0)
+    q = torch.randn(B * Np, D, generator=g)
+    k = torch.randn(B * Np, D, generator=g)
+    if spike:
+        k[N - 5] = q[7] * 3.0                                # row 7's maximum jumps by far more than the deferral threshold in the last tile
+        k[Np + 100] = -q[Np + 3] * 2.0
+    qk = torch.cat([q, k], dim=1).half().cuda()
+    vt = torch.zeros(B, H, 64, kvld)
+    v = torch.randn(B, H, N, 64, generator=g)
+    vt[..., vt_cols(N).cpu()] = v.transpose(2, 3)
+    vt = vt.half().cuda()
+    c = 0.125 * 1.4426950408889634
+    qk_pre = qk.clone()
+    qk_pre[:, :D] = (qk[:, :D].float() * c).half()
+    outs = []
+    for pre, src in ((0, qk), (1, qk_pre)):
+        o = torch.zeros(B * Np, D, dtype=torch.half, device="cuda")
+        ops.attention(Q=src, K=src.data_ptr() + D * 2, Vt=vt, O=o, B=B, H=H, Nq=N, Nk=N, ldq=2 * D, ldk=2 * D, ldo=D, kv_ld=kvld,
+                      q_rows_per_img=Np, k_rows_per_img=Np, scale=0.125, q_prescaled=pre)
+        outs.append(o.float().view(B, Np, H, 64)[:, :N])
+    qq = qk[:, :D].float().view(B, Np, H, 64)[:, :N].transpose(1, 2)
+    kk = qk[:, D:].float().view(B, Np, H, 64)[:, :N].transpose(1, 2)
+    ref = (torch.softmax(qq @ kk.transpose(-1, -2) * 0.125, -1) @ v.cuda().half().float()).transpose(1, 2)
+    torch.cuda.synchronize()
+    assert rel(outs[0], ref) < 2e-3 and rel(outs[1], ref) < 2e-3, (rel(outs[0], ref), rel(outs[1], ref))
+    assert torch.isfinite(outs[1]).all()

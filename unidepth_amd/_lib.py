@@ -62,7 +62,7 @@ UD_ACT_CLAMPEXP = 3
 class UdAttention(C.Structure):
     _fields_ = [("Q", vp), ("K", vp), ("Vt", vp), ("O", vp), ("B", i32), ("H", i32), ("Nq", i32), ("Nk", i32),
                 ("ldq", i32), ("ldk", i32), ("ldo", i32), ("kv_ld", i32), ("q_rows_per_img", i32),
-                ("k_rows_per_img", i32), ("scale", f32), ("kv_broadcast", i32), ("kv_group", i32)]
+                ("k_rows_per_img", i32), ("scale", f32), ("kv_broadcast", i32), ("kv_group", i32), ("q_prescaled", i32)]
 
 
 class UdPreprocess(C.Structure):

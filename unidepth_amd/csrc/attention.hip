@@ -27,7 +27,14 @@ constexpr int STAGE = KS_BYTES + VS_BYTES;
 
 // ABL: ablation mask for tools/ablate_attn.py (instrumented builds only; the product instantiates ABL = 0):
 //   1 no exp/softmax VALU, 2 no P V MFMAs, 4 no Q K^T MFMAs, 8 no K/V tile traffic (global loads + LDS stores), 16 no barrier
-template <int ABL>
+// MODE 0: Q as given, P = exp2(S c - m c) with c = scale log2(e) (one fma per score).
+// MODE 1 / 2: Q arrives PRE-SCALED by c (UdAttention.q_prescaled: the engine folds c into the q projection's weights at load time), and
+//   the running maximum is subtracted by the MFMA itself -- the score accumulators start at -m instead of 0 -- so P = exp2(S'') with
+//   no VALU in between: 31 fewer VALU instructions per 64-key tile and lane (the kernel is VALU-issue bound: PMC VALU active 53 %, MFMA
+//   busy 34 %).  A growing maximum (deferred, threshold 2^8 as before) is handled on the rare path by shifting S''.
+//   MODE 2 additionally forms the row sums with v_dot2_f32_f16 on the packed P pairs (16 instead of 32 adds; the sum is then over the
+//   ROUNDED probabilities, i.e. exactly what P V multiplies).
+template <int ABL, int MODE>
 __global__ __launch_bounds__(256) void attention_kernel(const UdAttention p, const float defer_thr) {
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   const int tid = threadIdx.x;
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const UdAttention p, con
   for (int db = 0; db < 2; ++db)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[db][r] = 0.0f;
-  float m_i = -1.0e30f;
+  float m_i = MODE ? 0.0f : -1.0e30f;
   float l_i = 0.0f;
   const float c = p.scale * 1.4426950408889634f;
 
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const UdAttention p, con
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) s[kb][r] = MODE ? -m_i : 0.0f;
       const char* kp = sb + (kb * 32 + ql) * 128;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -146,38 +153,74 @@ __global__ __launch_bounds__(256) void attention_kernel(const UdAttention p, con
 #pragma unroll
       for (int r = 0; r < 16; r += 2) mt = fmaxf(fmaxf(mt, s[kb][r]), s[kb][r + 1]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    if (__any((mt - m_i) * c > defer_thr)) {
-      const float m_new = fmaxf(m_i, mt);
-      const float alpha = __builtin_amdgcn_exp2f((m_i - m_new) * c);
-      m_i = m_new;
-      l_i *= alpha;
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-    }
-    const float mc = m_i * c;
     float ls = 0.0f;
     half8 pf[2][2];
+    if constexpr (MODE == 0) {
+      if (__any((mt - m_i) * c > defer_thr)) {
+        const float m_new = fmaxf(m_i, mt);
+        const float alpha = __builtin_amdgcn_exp2f((m_i - m_new) * c);
+        m_i = m_new;
+        l_i *= alpha;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+        for (int db = 0; db < 2; ++db)
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+          for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+      }
+      const float mc = m_i * c;
 #pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-          f32x2 pv;
-          if constexpr (ABL & 1) {
-            pv[0] = s[kb][t * 8 + e];
-            pv[1] = s[kb][t * 8 + e + 1];
-          } else {
-            pv[0] = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], c, -mc));
-            pv[1] = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e + 1], c, -mc));
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            f32x2 pv;
+            if constexpr (ABL & 1) {
+              pv[0] = s[kb][t * 8 + e];
+              pv[1] = s[kb][t * 8 + e + 1];
+            } else {
+              pv[0] = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e], c, -mc));
+              pv[1] = __builtin_amdgcn_exp2f(fmaf(s[kb][t * 8 + e + 1], c, -mc));
+            }
+            ls += pv[0] + pv[1];
+            const half2v ph = __builtin_convertvector(pv, half2v);      // v_cvt_pk_f16_f32 (round to nearest even)
+            pf[kb][t][e] = ph[0];
+            pf[kb][t][e + 1] = ph[1];
           }
-          ls += pv[0] + pv[1];
-          const half2v ph = __builtin_convertvector(pv, half2v);      // v_cvt_pk_f16_f32 (round to nearest even)
-          pf[kb][t][e] = ph[0];
-          pf[kb][t][e + 1] = ph[1];
+    } else {
+      // scores are already S - m (in log2 units); mt = how far this tile's row maximum exceeds the running one
+      if (kt == 0 || __any(mt > defer_thr)) {
+        const float d = kt == 0 ? mt : fmaxf(mt, 0.0f);
+        m_i += d;
+        if (kt != 0) {                                   // first tile: O and l are still zero (and exp2(-d) may overflow)
+          const float alpha = __builtin_amdgcn_exp2f(-d);
+          l_i *= alpha;
+#pragma unroll
+          for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
         }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[kb][r] -= d;
+      }
+      const half2v ones = {(half_t)1.0f, (half_t)1.0f};
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            f32x2 pv;
+            pv[0] = __builtin_amdgcn_exp2f(s[kb][t * 8 + e]);
+            pv[1] = __builtin_amdgcn_exp2f(s[kb][t * 8 + e + 1]);
+            const half2v ph = __builtin_convertvector(pv, half2v);
+            if constexpr (MODE == 2) ls = __builtin_amdgcn_fdot2(ph, ones, ls, false);
+            else ls += pv[0] + pv[1];
+            pf[kb][t][e] = ph[0];
+            pf[kb][t][e + 1] = ph[1];
+          }
+    }
     l_i += ls;
 
     // ---- O^T += V^T P^T
@@ -238,12 +281,16 @@ extern "C" int ud_attention_f16(const UdAttention* desc, void* stream) {
   const int extra_lds = ((ud_debug_flags_host() >> 16) & 255) * 1024;   // tools only: occupancy experiments
 #ifdef UD_ABLATE
   switch ((ud_debug_flags_host() >> 8) & 31) {
-#define UD_ABL_CASE(X) case X: hipLaunchKernelGGL(attention_kernel<X>, grid, dim3(256), extra_lds, (hipStream_t)stream, d, thr); break;
+#define UD_ABL_CASE(X) case X: hipLaunchKernelGGL((attention_kernel<X, 0>), grid, dim3(256), extra_lds, (hipStream_t)stream, d, thr); break;
     UD_ABL_CASE(1) UD_ABL_CASE(2) UD_ABL_CASE(3) UD_ABL_CASE(4) UD_ABL_CASE(7) UD_ABL_CASE(8) UD_ABL_CASE(9) UD_ABL_CASE(24) UD_ABL_CASE(25) UD_ABL_CASE(31)
-    default: hipLaunchKernelGGL(attention_kernel<0>, grid, dim3(256), extra_lds, (hipStream_t)stream, d, thr);
+    default: hipLaunchKernelGGL((attention_kernel<0, 0>), grid, dim3(256), extra_lds, (hipStream_t)stream, d, thr);
   }
 #else
-  hipLaunchKernelGGL(attention_kernel<0>, grid, dim3(256), extra_lds, (hipStream_t)stream, d, thr);
+#ifndef UD_ATTN_PRE_MODE
+#define UD_ATTN_PRE_MODE 1
+#endif
+  if (d.q_prescaled) hipLaunchKernelGGL((attention_kernel<0, UD_ATTN_PRE_MODE>), grid, dim3(256), extra_lds, (hipStream_t)stream, d, thr);
+  else hipLaunchKernelGGL((attention_kernel<0, 0>), grid, dim3(256), extra_lds, (hipStream_t)stream, d, thr);
 #endif
   UD_CHECK_LAUNCH("ud_attention_f16 launch");
   return UD_OK;

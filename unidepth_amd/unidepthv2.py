@@ -146,10 +146,12 @@ class _Plan:
                 def _qkv0():                                                    # [B, N, 3D] = Q | K | V (attention.py:53-55 layout)
                     cols = ((torch.arange(N) & ~15) | ((torch.arange(N) & 4) << 1) | ((torch.arange(N) & 8) >> 1) | (torch.arange(N) & 3)).to(dev)
                     v = vt[:, :, :, cols].permute(0, 3, 1, 2).reshape(B, N, D)
-                    return torch.cat([qk.view(B, Np, 2 * D)[:, :N], v], dim=2).float()
+                    qkv = torch.cat([qk.view(B, Np, 2 * D)[:, :N], v], dim=2).float()
+                    qkv[..., :D] /= (D // heads) ** -0.5 * 1.4426950408889634      # Q is stored pre-scaled for the attention kernel
+                    return qkv
                 tap("blocks.0.attn.qkv", _qkv0)
             P.attention(Q=qk, K=qk.data_ptr() + D * 2, Vt=vt, O=ao, B=B, H=heads, Nq=N, Nk=N, ldq=2 * D, ldk=2 * D, ldo=D,
-                        kv_ld=Nkp, q_rows_per_img=Np, k_rows_per_img=Np, scale=(D // heads) ** -0.5, tag="enc.attn")
+                        kv_ld=Nkp, q_rows_per_img=Np, k_rows_per_img=Np, scale=(D // heads) ** -0.5, q_prescaled=1, tag="enc.attn")
             P.gemm(A=ao, W=w[f"enc.{i}.proj.w"], bias=w[f"enc.{i}.proj.b"], out=x, M=M, N=D, K=D, lda=D, ldw=D, ldc=D,
                    epi=UD_EPI_F32, accumulate=1, tag="enc.proj", flops=2.0 * B * N * D * D)
             P.layernorm(x=x, y=xn, rows=M, D=D, ldx=D, ldy=D, eps=1e-6, rows_per_img=M, in_rows_per_img=M, out_rows_per_img=M)
@@ -261,7 +263,7 @@ class _Plan:
                gOut2=nb * Hd * 64 * hwkp, tag="dh.kv(x4)", **G4)
         bc = int(nb == 1 and B > 1)
         P.attention(Q=qd, K=kd, Vt=vtd, O=aod, B=4 * B, H=Hd, Nq=hw, Nk=hw, ldq=HC, ldk=HC, ldo=HC, kv_ld=hwkp, q_rows_per_img=hwp,
-                    k_rows_per_img=hwp, scale=scale_d, kv_broadcast=bc, kv_group=B, tag="dh.attn(x4)")
+                    k_rows_per_img=hwp, scale=scale_d, kv_broadcast=bc, kv_group=B, q_prescaled=1, tag="dh.attn(x4)")
         P.gemm(A=aod, W=w["dhg.out.w"], out=feat_all, M=Md, N=C, K=HC, lda=HC, ldw=HC, ldc=C, epi=UD_EPI_F32, accumulate=1,
                gA=Md * HC, gW=C * HC, gOut=Md * C, tag="dh.out(x4)", **G4)
         ln(feat_all, fn, 4 * Md)

@@ -13,6 +13,8 @@ from __future__ import annotations
 
 import torch
 
+LOG2E = 1.4426950408889634
+
 ARCH = {  # backbones/dinov2.py:388-427, encoder.py:139-193
     "dinov2_vits14": (384, 12, 6, [3, 6, 9, 12]),
     "dinov2_vitb14": (768, 12, 12, [3, 6, 9, 12]),
@@ -96,6 +98,10 @@ def pack(config: dict, sd: dict, device) -> dict:
     for i in range(a["depth"]):
         b = f"{pe}blocks.{i}."
         w, bb = _fold_ln(f[b + "attn.qkv.weight"], f[b + "attn.qkv.bias"], f[b + "norm1.weight"], f[b + "norm1.bias"])
+        # softmax scale and the log2(e) of the kernel's exp2 live in the q projection (exact algebra; UdAttention.q_prescaled)
+        qc = (D // a["heads"]) ** -0.5 * LOG2E
+        w, bb = w.clone(), bb.clone()
+        w[:D] *= qc; bb[:D] *= qc
         put16(f"enc.{i}.qkv.w", w); put32(f"enc.{i}.qkv.b", bb)
         g1 = f[b + "ls1.gamma"]
         put16(f"enc.{i}.proj.w", f[b + "attn.proj.weight"] * g1[:, None]); put32(f"enc.{i}.proj.b", f[b + "attn.proj.bias"] * g1)
@@ -128,7 +134,8 @@ def pack(config: dict, sd: dict, device) -> dict:
 
     def attn_block(src, dst, layer_scale):
         wq, bq = _fold_ln(f[src + "q.weight"], None, f[src + "norm_attnx.weight"], f[src + "norm_attnx.bias"])
-        put16(dst + "q.w", _pad_head_rows(wq, H, hd)); put32(dst + "q.b", _pad_head_vec(bq, H, hd))
+        qc = hd ** -0.5 * LOG2E                                              # q pre-scaled for the attention kernel (UdAttention.q_prescaled)
+        put16(dst + "q.w", _pad_head_rows(wq * qc, H, hd)); put32(dst + "q.b", _pad_head_vec(bq * qc, H, hd))
         wkv, bkv = _fold_ln(f[src + "kv.weight"], None, f[src + "norm_attnctx.weight"], f[src + "norm_attnctx.bias"])
         wk, wv, bk, bv = wkv[:C], wkv[C:], bkv[:C], bkv[C:]                     # rows [K | V], heads-major (attention.py:119-121)
         put16(dst + "kv.w", torch.cat([_pad_head_rows(wk, H, hd), _pad_head_rows(wv, H, hd)], 0))
