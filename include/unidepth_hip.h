@@ -43,6 +43,9 @@ extern "C" {
 #define UD_A_DENSE 0          /* A is [M, lda] row-major                                              */
 #define UD_A_CONV3_ZERO 1     /* A rows are gathered 3x3 taps of an NHWC image, zero padding           */
 #define UD_A_CONV3_REFLECT 2  /* same, reflect padding (reference decoder.py:199-226)                   */
+#define UD_A_CONV3_REFLECT_UP 3  /* reflect-padded 3x3 taps of the bilinear align_corners=True up-sampling of A [B, Hsrc, Wsrc, Cin] to
+                                  * (Himg, Wimg) (decoder.py:299-301,309-311 fused into the following conv; UD_EPI_HEAD only); img_stride and gA
+                                  * describe the LOW-resolution A */
 
 /* C[M,N] = A[M,K] * W[N,K]^T on v_mfma_f32_16x16x32_f16 tiles, fp32 accumulate.
  * Replaces: nn.Linear / F.linear everywhere on the path (metadinov2/attention.py:53,60; mlp.py:36-40;
@@ -87,6 +90,7 @@ typedef struct UdGemm {
    * shared between streams.  NULL = never split. */
   void* splitk_ws;
   void* splitk_cnt;
+  int Hsrc, Wsrc;              /* UD_A_CONV3_REFLECT_UP: size of the low-resolution source image */
 } UdGemm;
 
 int ud_gemm_f16(const UdGemm* desc, void* stream);

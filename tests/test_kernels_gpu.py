@@ -704,3 +704,39 @@ def test_attention_prescaled_q_matches_classic_path(ops, N, spike):
     torch.cuda.synchronize()
     assert rel(outs[0], ref) < 2e-3 and rel(outs[1], ref) < 2e-3, (rel(outs[0], ref), rel(outs[1], ref))
     assert torch.isfinite(outs[1]).all()
+
+
+def test_gemm_head_conv_with_fused_upsampling(ops):
+    """UD_A_CONV3_REFLECT_UP: 3x3 reflect conv + LeakyReLU + 1x1 + clip/exp over the align_corners=True up-sampling of a low-resolution
+    NHWC map that is never materialised == the same head on the map written by ud_resize_ac_nhwc_f16 (bit-compatible interpolation) and
+    == the fp32 PyTorch statement."""
+    B, Hs, Ws, Hn, Wn, C = 2, 37, 45, 70, 91, 64
+    g = torch.Generator().manual_seed(3)
+    lr = torch.randn(2, B, Hs, Ws, C, generator=g).half().cuda()
+    wt = (torch.randn(2, 32, C, 3, 3, generator=g) * (9 * C) ** -0.5).cuda()
+    b1 = torch.randn(2, 32, generator=g).cuda() * 0.1
+    w2 = torch.randn(2, 32, generator=g).cuda() * 0.2
+    b2 = [0.1, -0.2]
+    wrows = wt.permute(0, 1, 3, 4, 2).reshape(2, 32, 9 * C)
+    kp = (9 * C + 63) // 64 * 64
+    wp = torch.zeros(2, 32, kp, dtype=torch.half, device="cuda")
+    wp[:, :, : 9 * C] = wrows.half()
+    zeros = torch.zeros(256, dtype=torch.half, device="cuda")
+    common = dict(W=wp, bias=b1, w2=w2, zeros=zeros, M=B * Hn * Wn, N=32, K=kp, ldw=kp, epi=ops.UD_EPI_HEAD, Himg=Hn, Wimg=Wn, Cin=C, cstride=C,
+                  coff=0, rows_img=Hn * Wn, b2=b2[0], post_add=2.0, b2_g1=b2[1], post_add_g1=0.0, groups=2, gW=32 * kp, gBias=32, gOut=B * Hn * Wn, gW2=32)
+    out_f = torch.zeros(2, B, Hn, Wn, device="cuda")
+    ops.gemm(A=lr, out=out_f, amode=3, Hsrc=Hs, Wsrc=Ws, img_stride=Hs * Ws * C, gA=B * Hs * Ws * C, **common)
+    hr = torch.zeros(2, B, Hn, Wn, C, dtype=torch.half, device="cuda")
+    import ctypes
+    d = ops.mk(ops.UdResizeAC, in_=lr, out=hr, G=2, B=B, Hin=Hs, Win=Ws, Hout=Hn, Wout=Wn, C=C)
+    ops.check(ops.lib.ud_resize_ac_nhwc_f16(ctypes.byref(d), ops.cur_stream()))
+    out_m = torch.zeros(2, B, Hn, Wn, device="cuda")
+    ops.gemm(A=hr, out=out_m, amode=ops.UD_A_CONV3_REFLECT, img_stride=Hn * Wn * C, gA=B * Hn * Wn * C, **common)
+    torch.cuda.synchronize()
+    assert rel(out_f, out_m) < 5e-4, rel(out_f, out_m)               # same interpolation expression (contraction may differ by an ulp of fp16)
+    for gi in range(2):
+        up = F.interpolate(lr[gi].float().permute(0, 3, 1, 2), size=(Hn, Wn), mode="bilinear", align_corners=True).half().float()
+        y = F.conv2d(F.pad(up, (1, 1, 1, 1), mode="reflect"), wp[gi, :, : 9 * C].float().view(32, 3, 3, C).permute(0, 3, 1, 2), b1[gi])
+        y = (F.leaky_relu(y, 0.01) * w2[gi].view(1, 32, 1, 1)).sum(1) + b2[gi]
+        ref = torch.exp(y.clamp(-8, 8) + (2.0 if gi == 0 else 0.0))
+        assert rel(out_f[gi], ref) < 2e-3, gi

@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("UNIDEPTH_HIP_LIB", os.path.join(_HERE, "libunidepth_h
 
 UD_EPI_F16, UD_EPI_F32, UD_EPI_QKV, UD_EPI_D2S, UD_EPI_HEAD = 0, 1, 2, 3, 4
 UD_ACT_NONE, UD_ACT_GELU, UD_ACT_LRELU = 0, 1, 2
-UD_A_DENSE, UD_A_CONV3_ZERO, UD_A_CONV3_REFLECT = 0, 1, 2
+UD_A_DENSE, UD_A_CONV3_ZERO, UD_A_CONV3_REFLECT, UD_A_CONV3_REFLECT_UP = 0, 1, 2, 3
 
 vp, fp, i32, i64, f32 = C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_float
 
@@ -31,7 +31,7 @@ class UdGemm(C.Structure):
         ("groups", i32),
         ("gA", i64), ("gW", i64), ("gBias", i64), ("gOut", i64), ("gOut2", i64), ("gW2", i64),
         ("b2_g1", f32), ("post_add_g1", f32), ("tile_hint", i32),
-        ("splitk_ws", vp), ("splitk_cnt", vp),
+        ("splitk_ws", vp), ("splitk_cnt", vp), ("Hsrc", i32), ("Wsrc", i32),
     ]
 
 

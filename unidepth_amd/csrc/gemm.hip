@@ -1123,7 +1123,11 @@ int launch_big(const UdGemm& d, hipStream_t s, int which) {
 // ================================================================================================================
 constexpr int HALO_BYTES = 41 * 1024;          // 328 pixel slots x 128 B (324 used)
 
-template <int NT, int EPI, bool REFLECT>
+// UPS: the convolution's input is the bilinear align_corners=True up-sampling of A [B, Hsrc, Wsrc, Cin] to (Himg, Wimg) (reference
+// decoder.py:299-301,309-311 F.interpolate between to_*_lr and to_*_hr) and is NEVER materialised: every halo pixel is interpolated once
+// from its 4 source pixels while the tile is staged (round 1 wrote the 518 x 518 x 64-channel map of both branches to HBM, 549 MB, and
+// re-read it with halos, 697 MB: resize_ac_kernel 0.20 ms + this kernel 0.27 ms per step).
+template <int NT, int EPI, bool REFLECT, bool UPS = false>
 __global__ __launch_bounds__(256) void conv_tile_kernel(const UdGemm p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* halo = smem;
@@ -1139,6 +1143,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const UdGemm p) {
   const half_t* in = (const half_t*)p.A + (long long)g * p.gA + (long long)b * p.img_stride + p.coff;
   const half_t* W = (const half_t*)p.W + (long long)g * p.gW;
   const float* bias = p.bias + (long long)g * p.gBias;
+  const float ups_sy = UPS && p.Himg > 1 ? (float)(p.Hsrc - 1) / (float)(p.Himg - 1) : 0.f;
+  const float ups_sx = UPS && p.Wimg > 1 ? (float)(p.Wsrc - 1) / (float)(p.Wimg - 1) : 0.f;
 
   f32x4 acc[4][NT];
 #pragma unroll
@@ -1146,26 +1152,85 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const UdGemm p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  auto halo_coord = [&](int i, int& hp, int& cpos, int& iy, int& ix, bool& ok) {
+    const int idx = i * 64 + lane;
+    hp = idx >> 3;
+    cpos = idx & 7;
+    const int hy = hp / 18, hx = hp - hy * 18;
+    iy = y0 - 1 + hy;
+    ix = x0 - 1 + hx;
+    ok = hp < 324;
+    if constexpr (REFLECT) {
+      iy = iy < 0 ? -iy : (iy >= p.Himg ? 2 * p.Himg - 2 - iy : iy);
+      ix = ix < 0 ? -ix : (ix >= p.Wimg ? 2 * p.Wimg - 2 - ix : ix);
+      ok = ok && iy >= 0 && ix >= 0;         // tile overhang beyond the reflected border: unused outputs
+    } else {
+      ok = ok && (unsigned)iy < (unsigned)p.Himg && (unsigned)ix < (unsigned)p.Wimg;
+    }
+  };
   auto issue_halo = [&](int cc) {
-#pragma unroll
-    for (int j = 0; j < 11; ++j) {
-      const int i = wv + 4 * j;                  // wave-instruction index (uniform)
-      if (i < 41) {
+    if constexpr (UPS) {
+      // (1) the source pixels this halo needs form a small patch (<= 13 x 13 for the decoder's 4/7 scale): DMA it to LDS once;
+      // (2) every (halo pixel, 8-channel chunk) is interpolated from 4 LDS reads with packed fp16 math (v_pk_fma_f16: the operands and the
+      //     result are fp16 anyway) and stored where the plain loader's DMA would have put it.
+      // Reading the 4 source pixels straight from global memory per item exposed an L2 round trip per item (1.05 ms per step).
+      const int ylo = y0 == 0 ? 0 : y0 - 1, yhi = y0 + 16 < p.Himg ? y0 + 16 : p.Himg - 1;
+      const int xlo = x0 == 0 ? 0 : x0 - 1, xhi = x0 + 16 < p.Wimg ? x0 + 16 : p.Wimg - 1;
+      const int syA = (int)(ups_sy * (float)ylo), sxA = (int)(ups_sx * (float)xlo);
+      int syB = (int)(ups_sy * (float)yhi) + 1, sxB = (int)(ups_sx * (float)xhi) + 1;
+      syB = syB < p.Hsrc ? syB : p.Hsrc - 1;
+      sxB = sxB < p.Wsrc ? sxB : p.Wsrc - 1;
+      const int PR = syB - syA + 1, PC = sxB - sxA + 1;          // <= UPS_PATCH each (checked on the host)
+      char* patch = wbuf + 2 * WB;
+      const int npiece = (PR * PC * 8 + 63) >> 6;
+      for (int i = wv; i < npiece; i += 4) {
         const int idx = i * 64 + lane;
-        const int hp = idx >> 3, cpos = idx & 7;
-        const int hy = hp / 18, hx = hp - hy * 18;
-        int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-        bool ok = hp < 324;
-        if constexpr (REFLECT) {
-          iy = iy < 0 ? -iy : (iy >= p.Himg ? 2 * p.Himg - 2 - iy : iy);
-          ix = ix < 0 ? -ix : (ix >= p.Wimg ? 2 * p.Wimg - 2 - ix : ix);
-          ok = ok && iy >= 0 && ix >= 0;         // tile overhang beyond the reflected border: unused outputs
-        } else {
-          ok = ok && (unsigned)iy < (unsigned)p.Himg && (unsigned)ix < (unsigned)p.Wimg;
+        int pp = idx >> 3;
+        pp = pp < PR * PC ? pp : PR * PC - 1;
+        const int pr = pp / PC, pc = pp - pr * PC;
+        ud_glds16(in + ((long long)(syA + pr) * p.Wsrc + sxA + pc) * p.cstride + cc * 64 + ((idx & 7) << 3), patch + i * 1024);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 11; ++j) {
+        const int i = wv + 4 * j;
+        if (i < 41) {
+          int hp, cpos, iy, ix;
+          bool ok;
+          halo_coord(i, hp, cpos, iy, ix, ok);
+          half8 o8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o8[e] = (half_t)0.f;
+          if (ok) {
+            const float fy = ups_sy * (float)iy, fx = ups_sx * (float)ix;
+            const int sy0 = (int)fy, sx0 = (int)fx;
+            const int sy1 = sy0 + (sy0 < p.Hsrc - 1), sx1 = sx0 + (sx0 < p.Wsrc - 1);
+            const half_t ly = (half_t)(fy - (float)sy0), lx = (half_t)(fx - (float)sx0);
+            const int cs = (cpos ^ ((hp >> 1) & 7)) << 4;
+            const half8 h00 = *(const half8*)(patch + ((sy0 - syA) * PC + (sx0 - sxA)) * 128 + cs);
+            const half8 h01 = *(const half8*)(patch + ((sy0 - syA) * PC + (sx1 - sxA)) * 128 + cs);
+            const half8 h10 = *(const half8*)(patch + ((sy1 - syA) * PC + (sx0 - sxA)) * 128 + cs);
+            const half8 h11 = *(const half8*)(patch + ((sy1 - syA) * PC + (sx1 - sxA)) * 128 + cs);
+            const half8 top = h00 + lx * (h01 - h00);
+            const half8 bot = h10 + lx * (h11 - h10);
+            o8 = top + ly * (bot - top);
+          }
+          *(half8*)(halo + i * 1024 + lane * 16) = o8;
         }
-        const half_t* src = ok ? in + ((long long)iy * p.Wimg + ix) * p.cstride + cc * 64 + ((cpos ^ ((hp >> 1) & 7)) << 3)
-                               : (const half_t*)p.zeros;
-        ud_glds16(src, halo + i * 1024);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 11; ++j) {
+        const int i = wv + 4 * j;                  // wave-instruction index (uniform)
+        if (i < 41) {
+          int hp, cpos, iy, ix;
+          bool ok;
+          halo_coord(i, hp, cpos, iy, ix, ok);
+          const half_t* src = ok ? in + ((long long)iy * p.Wimg + ix) * p.cstride + cc * 64 + ((cpos ^ ((hp >> 1) & 7)) << 3)
+                                 : (const half_t*)p.zeros;
+          ud_glds16(src, halo + i * 1024);
+        }
       }
     }
   };
@@ -1259,12 +1324,17 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const UdGemm p) {
   }
 }
 
-template <int NT, int EPI, bool REFLECT>
+constexpr int UPS_PATCH = 13;                  // source patch side of the fused up-sampling loader (halo of 18 at a scale <= 0.6, + 2)
+template <int NT, int EPI, bool REFLECT, bool UPS = false>
 int launch_conv_tile(const UdGemm& d, hipStream_t s) {
-  const int lds = HALO_BYTES + 2 * NT * 16 * 128;
+  const int lds = HALO_BYTES + 2 * NT * 16 * 128 + (UPS ? (UPS_PATCH * UPS_PATCH * 128 + 1023) / 1024 * 1024 : 0);
+  if (UPS) {
+    static bool attr_set[UD_MAX_DEVICES];
+    if (!ud_attr_once(attr_set)) (void)hipFuncSetAttribute((const void*)conv_tile_kernel<NT, EPI, REFLECT, UPS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  }
   const int B = d.M / d.rows_img;
   dim3 grid(((d.Wimg + 15) >> 4) * ((d.Himg + 15) >> 4), B, d.groups > 0 ? d.groups : 1);
-  hipLaunchKernelGGL((conv_tile_kernel<NT, EPI, REFLECT>), grid, dim3(256), lds, s, d);
+  hipLaunchKernelGGL((conv_tile_kernel<NT, EPI, REFLECT, UPS>), grid, dim3(256), lds, s, d);
   UD_CHECK_LAUNCH("ud_gemm_f16 (halo-tile conv) launch");
   return UD_OK;
 }
@@ -1353,6 +1423,10 @@ extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
     ud_set_error("ud_gemm_f16: bad argument (need K % 64 == 0, N % 4 == 0)");
     return UD_ERR_BAD_ARG;
   }
+  if (d.amode == UD_A_CONV3_REFLECT_UP && d.epi != UD_EPI_HEAD) {
+    ud_set_error("ud_gemm_f16: CONV3_REFLECT_UP is implemented for the HEAD epilogue only");
+    return UD_ERR_UNSUPPORTED;
+  }
   if (d.amode != UD_A_DENSE && (!d.zeros || (d.Cin & 7) || d.K < 9 * d.Cin || d.rows_img < d.Himg * d.Wimg)) {
     ud_set_error("ud_gemm_f16: bad conv geometry");
     return UD_ERR_BAD_ARG;
@@ -1374,9 +1448,18 @@ extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
     return dispatch_bn<UD_EPI_D2S, UD_A_DENSE>(d, s);
   }
   if (d.epi == UD_EPI_HEAD) {
-    if (d.amode != UD_A_CONV3_REFLECT || d.N != 32 || !d.w2 || !d.bias) {
+    if ((d.amode != UD_A_CONV3_REFLECT && d.amode != UD_A_CONV3_REFLECT_UP) || d.N != 32 || !d.w2 || !d.bias) {
       ud_set_error("ud_gemm_f16: HEAD epilogue needs reflect conv, N == 32");
       return UD_ERR_BAD_ARG;
+    }
+    if (d.amode == UD_A_CONV3_REFLECT_UP) {
+      // the loader stages a source patch of at most UPS_PATCH^2 pixels per 16 x 16 tile: 17 * scale + 3 <= UPS_PATCH
+      const bool fits = 17.0 * (d.Hsrc - 1) / (d.Himg > 1 ? d.Himg - 1 : 1) + 3.0 <= UPS_PATCH && 17.0 * (d.Wsrc - 1) / (d.Wimg > 1 ? d.Wimg - 1 : 1) + 3.0 <= UPS_PATCH;
+      if (!conv_tile_ok(d) || d.Hsrc < 1 || d.Wsrc < 1 || (d.cstride & 7) || !fits) {
+        ud_set_error("ud_gemm_f16: CONV3_REFLECT_UP needs Cin % 64 == 0, dense images, Hsrc / Wsrc >= 1 and an up-sampling factor >= ~1.7");
+        return UD_ERR_BAD_ARG;
+      }
+      return launch_conv_tile<2, UD_EPI_HEAD, true, true>(d, s);
     }
     if (conv_tile_ok(d)) return launch_conv_tile<2, UD_EPI_HEAD, true>(d, s);
     return launch<Cfg<32, 32, 32>, UD_EPI_HEAD, UD_A_CONV3_REFLECT>(d, s);

@@ -7,7 +7,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (UD_A_CONV3_REFLECT, UD_A_CONV3_ZERO, UD_A_DENSE, UD_ACT_GELU, UD_ACT_LRELU, UD_ACT_NONE,  # noqa: F401
+from ._lib import (UD_A_CONV3_REFLECT, UD_A_CONV3_REFLECT_UP, UD_A_CONV3_ZERO, UD_A_DENSE, UD_ACT_GELU, UD_ACT_LRELU, UD_ACT_NONE,  # noqa: F401
                    UD_EPI_D2S, UD_EPI_F16, UD_EPI_F32, UD_EPI_HEAD, UD_EPI_QKV, UdAttention, UdFinalize, UdGemm,
                    UdDwConv7, UdLayerNorm, UdLinearF32, UdPreprocess, UdRayEmbed, UdResizeAC, UdUpsample2x, check, lib)
 
@@ -112,7 +112,7 @@ class Program:
         elif pick <= 4:
             cls = "gemm256_kernel<%d, %d, %d>" % (pick, epi, amode)
         else:
-            cls = "conv_tile_kernel<%d, %d, %s>" % (n // 16, epi, "true" if amode == 2 else "false")
+            cls = "conv_tile_kernel<%d, %d, %s, %s>" % (n // 16, epi, "true" if amode >= 2 else "false", "true" if amode == 3 else "false")
         self.keep.extend(v for v in kw.values() if isinstance(v, torch.Tensor))
         # algorithmic HBM bytes (every operand element once): A (conv modes: the image, not the 9x gathered rows), W, outputs,
         # + the old fp32 values of an accumulating epilogue

@@ -23,7 +23,7 @@ from typing import Optional
 import torch
 
 from . import ops
-from .ops import (UD_A_CONV3_REFLECT, UD_A_CONV3_ZERO, UD_ACT_GELU, UD_ACT_LRELU, UD_ACT_NONE, UD_EPI_D2S, UD_EPI_F16,
+from .ops import (UD_A_CONV3_REFLECT, UD_A_CONV3_REFLECT_UP, UD_A_CONV3_ZERO, UD_ACT_GELU, UD_ACT_LRELU, UD_ACT_NONE, UD_EPI_D2S, UD_EPI_F16,
                   UD_EPI_F32, UD_EPI_HEAD, UD_EPI_QKV)
 from .cameras import GT_OPENCV, GT_PINHOLE, as_camera
 
@@ -323,15 +323,20 @@ class _Plan:
         P.gemm(A=xh, W=w["dh.lr.w"], bias=w["dh.lr.b"], out=lr, zeros=zeros, M=Mh, N=o2, K=kp, ldw=kp, ldc=o2, amode=UD_A_CONV3_REFLECT,
                epi=UD_EPI_F16, Himg=gh, Wimg=gw, Cin=nd, cstride=ldx, coff=0, rows_img=gh * gw, img_stride=gh * gw * ldx,
                groups=2, gA=0, gW=o2 * kp, gBias=o2, gOut=Mh * o2, tag="dh.lr(mlp folded)", flops=2.0 * 2 * Mh * o2 * 9 * nd)
-        hr = z(2, B * Hn * Wn, o2)
-        P.resize_ac(in_=lr, out=hr, G=2, B=B, Hin=gh, Win=gw, Hout=Hn, Wout=Wn, C=o2)
         self.net = z(2, B, Hn, Wn, dtype=f32)              # [0] radius, [1] confidence at network resolution
         kp = w["dh.hr.w"].shape[2]
         b2 = w["dh.hr.b2"]
-        P.gemm(A=hr, W=w["dh.hr.w"], bias=w["dh.hr.b1"], w2=w["dh.hr.w2"], out=self.net, zeros=zeros, M=B * Hn * Wn, N=32, K=kp, ldw=kp,
-               amode=UD_A_CONV3_REFLECT, epi=UD_EPI_HEAD, Himg=Hn, Wimg=Wn, Cin=o2, cstride=o2, coff=0, rows_img=Hn * Wn,
-               img_stride=Hn * Wn * o2, b2=b2[0], post_add=2.0, b2_g1=b2[1], post_add_g1=0.0, groups=2, gA=B * Hn * Wn * o2,
-               gW=32 * kp, gBias=32, gOut=B * Hn * Wn, gW2=32)
+        head = dict(W=w["dh.hr.w"], bias=w["dh.hr.b1"], w2=w["dh.hr.w2"], out=self.net, zeros=zeros, M=B * Hn * Wn, N=32, K=kp, ldw=kp, epi=UD_EPI_HEAD,
+                    Himg=Hn, Wimg=Wn, Cin=o2, cstride=o2, coff=0, rows_img=Hn * Wn, b2=b2[0], post_add=2.0, b2_g1=b2[1], post_add_g1=0.0, groups=2,
+                    gW=32 * kp, gBias=32, gOut=B * Hn * Wn, gW2=32, flops=2.0 * 2 * B * Hn * Wn * 32 * 9 * o2)
+        if o2 % 64 == 0:
+            # ViT-L: the align_corners=True up-sampling to network resolution (decoder.py:299-301,309-311) happens inside the head conv's halo
+            # loader -- the 518 x 518 x 64-channel maps of both branches (549 MB at bs = 8) are never written
+            P.gemm(A=lr, amode=UD_A_CONV3_REFLECT_UP, Hsrc=gh, Wsrc=gw, img_stride=gh * gw * o2, gA=Mh * o2, tag="dh.hr(up fused)", **head)
+        else:                                              # narrower heads (ViT-S / ViT-B: 32 / 48 channels): materialised up-sampling + implicit GEMM
+            hr = z(2, B * Hn * Wn, o2)
+            P.resize_ac(in_=lr, out=hr, G=2, B=B, Hin=gh, Win=gw, Hout=Hn, Wout=Wn, C=o2)
+            P.gemm(A=hr, amode=UD_A_CONV3_REFLECT, img_stride=Hn * Wn * o2, gA=B * Hn * Wn * o2, **head)
         tap("logdepth", lambda: (torch.log(self.net[0]) - 2.0).view(B, 1, Hn, Wn))     # pre-exp head output (valid while |log| < 8: no clip)
         tap("logconf", lambda: torch.log(self.net[1]).view(B, 1, Hn, Wn))
         self.nb = nb
