@@ -295,6 +295,35 @@ typedef struct UdV1Op {
 } UdV1Op;
 int ud_v1_op(const UdV1Op* desc, void* stream);
 
+/* ---- the reference's two native extensions (evaluation / loss side), forward only ----
+ * K nearest neighbours of every p1 point among the p2 points of the same cloud: replaces KNN.knn_points_idx
+ * (unidepth/ops/knn/src/knn_ext.cpp:8 -> knn.h:44-80 KNearestNeighborIdx -> knn.cu:314-419 KNearestNeighborIdxCuda; caller
+ * functions/knn.py:72 _knn_points.forward <- utils/chamfer_distance.py:143-144 <- utils/evaluation_depth.py:12-34).
+ *   p1 [N,P1,D], p2 [N,P2,D] fp32 contiguous; lengths1/lengths2 int64 [N] or NULL (= P1 / P2 everywhere).
+ *   dists fp32 [N,P1,K] squared L2 (norm 2) or L1 (norm 1) distances, idx int64 [N,P1,K]; every element is written (padding = 0).
+ *   The K neighbours are the K smallest (dist, index) pairs in ascending order, i.e. already what functions/knn.py:75-91 obtains by
+ *   sorting; ties resolve to the lower index (knn_cpu.cpp:40-58).  1 <= D <= 32 (D <= 8 on the register path), 1 <= K <= 32.
+ *   work: optional u64 [N*P1] scratch; when given and K == 1, small P1 problems are split over P2 (ud_knn_split slices). */
+typedef struct UdKnn {
+  const float* p1; const float* p2;
+  const long long* lengths1; const long long* lengths2;
+  float* dists; long long* idx;
+  unsigned long long* work;
+  int N, P1, P2, D, K, norm;
+} UdKnn;
+int ud_knn_points(const UdKnn* desc, void* stream);
+int ud_knn_split(const UdKnn* desc);
+/* Patch gather: replaces RandomPatchExtraction.extract_patches_forward (unidepth/ops/extract_patches/src/extract_patches.cpp:3-6 ->
+ * src/cuda/extract_patches_kernel.cu:9-35,65-95) together with the zero padding its module does first (modules/patch_extractor.py:26-42).
+ *   in fp32 [B,C,H,W]; centers int32 [B,N,2] = (y, x) in the coordinates of the image padded by (pad_h, pad_w) on every side (pass
+ *   pad = 0 for raw coordinates); out fp32, B*N*C*h*w elements in [b][n][c][i][j] order -- the order the reference kernel writes
+ *   (extract_patches_kernel.cu:91), which it then views as {B,C,N,h,w} (:22).  Pixels outside the image read as 0. */
+typedef struct UdExtractPatches {
+  const float* in; float* out; const int* centers;
+  int B, C, H, W, N, h, w, pad_h, pad_w;
+} UdExtractPatches;
+int ud_extract_patches(const UdExtractPatches* desc, void* stream);
+
 /* ---- launch programs: a recorded list of the ops above replayed with one call (host-side runtime) ---- */
 typedef struct UdProgram UdProgram;
 UdProgram* ud_program_create(void);
@@ -325,7 +354,7 @@ int ud_program_add_v1_op(UdProgram*, const UdV1Op*);
 /* run ops [first, last) on `stream`; returns 0 or the first failing op's error code */
 int ud_program_run(const UdProgram*, int first, int last, void* stream);
 
-/* library info; ud_struct_size(i): sizeof the i-th descriptor struct in declaration order (UdGemm = 0 ... UdLinearF32 = 8, UdDwConv7 = 9, UdV1Op = 10) */
+/* library info; ud_struct_size(i): sizeof the i-th descriptor struct in declaration order (UdGemm = 0 ... UdLinearF32 = 8, UdDwConv7 = 9, UdV1Op = 10, UdKnn = 11, UdExtractPatches = 12) */
 int ud_version(void);
 int ud_struct_size(int which);
 const char* ud_last_error(void);

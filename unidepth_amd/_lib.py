@@ -54,6 +54,16 @@ class UdV1Op(C.Structure):
     _fields_ = [("kind", i32), ("a", vp), ("b", vp), ("c", vp), ("out", vp), ("out2", vp), ("i", i32 * 12), ("f", f32 * 4)]
 
 
+class UdKnn(C.Structure):
+    _fields_ = [("p1", vp), ("p2", vp), ("lengths1", vp), ("lengths2", vp), ("dists", vp), ("idx", vp), ("work", vp),
+                ("N", i32), ("P1", i32), ("P2", i32), ("D", i32), ("K", i32), ("norm", i32)]
+
+
+class UdExtractPatches(C.Structure):
+    _fields_ = [("in_", vp), ("out", vp), ("centers", vp), ("B", i32), ("C", i32), ("H", i32), ("W", i32), ("N", i32),
+                ("h", i32), ("w", i32), ("pad_h", i32), ("pad_w", i32)]
+
+
 (UD_V1_RESIZE_AA, UD_V1_SH_EMBED, UD_V1_SOFTMAX, UD_V1_ATTN_FEWQ, UD_V1_SEGMENT_MEAN, UD_V1_BMM, UD_V1_PINV_INIT, UD_V1_ADD, UD_V1_COPY_ROWS,
  UD_V1_TRANSPOSE16, UD_V1_CAMERA, UD_V1_POINTS, UD_V1_MEAN3, UD_V1_PREPROCESS) = range(1, 15)
 UD_ACT_CLAMPEXP = 3
@@ -145,6 +155,9 @@ def _load():
         "ud_program_add_spatial_mean": [vp, vp, vp, i32, i32, i32, i32],
         "ud_v1_op": [P(UdV1Op), vp],
         "ud_program_add_v1_op": [vp, P(UdV1Op)],
+        "ud_knn_points": [P(UdKnn), vp],
+        "ud_knn_split": [P(UdKnn)],
+        "ud_extract_patches": [P(UdExtractPatches), vp],
         "ud_program_run": [vp, i32, i32, vp],
         "ud_version": [],
         "ud_struct_size": [i32],
@@ -157,7 +170,7 @@ def _load():
     lib.ud_program_create.restype = vp
     lib.ud_last_error.argtypes = []
     lib.ud_last_error.restype = C.c_char_p
-    for i, st in enumerate([UdGemm, UdLayerNorm, UdAttention, UdPreprocess, UdRayEmbed, UdUpsample2x, UdResizeAC, UdFinalize, UdLinearF32, UdDwConv7, UdV1Op]):
+    for i, st in enumerate([UdGemm, UdLayerNorm, UdAttention, UdPreprocess, UdRayEmbed, UdUpsample2x, UdResizeAC, UdFinalize, UdLinearF32, UdDwConv7, UdV1Op, UdKnn, UdExtractPatches]):
         if lib.ud_struct_size(i) != C.sizeof(st):
             raise ImportError(f"ctypes mirror of {st.__name__} is out of sync with include/unidepth_hip.h "
                               f"({C.sizeof(st)} vs {lib.ud_struct_size(i)} bytes)")

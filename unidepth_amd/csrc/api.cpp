@@ -26,6 +26,8 @@ extern "C" int ud_struct_size(int which) {
     case 8: return (int)sizeof(UdLinearF32);
     case 9: return (int)sizeof(UdDwConv7);
     case 10: return (int)sizeof(UdV1Op);
+    case 11: return (int)sizeof(UdKnn);
+    case 12: return (int)sizeof(UdExtractPatches);
     default: return -1;
   }
 }

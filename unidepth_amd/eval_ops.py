@@ -1,0 +1,151 @@
+"""Host-side mirror of the reference's two native extensions (evaluation / loss side), over the C-ABI of include/unidepth_hip.h:
+
+    knn_points, knn_gather          unidepth/ops/knn/functions/knn.py:113-196, 199-249  (forward; the KNN extension)
+    ChamferDistance, chamfer_dist   unidepth/utils/chamfer_distance.py:60-159, unidepth/utils/evaluation_depth.py:12-18
+    RandomPatchExtractor            unidepth/ops/extract_patches/modules/patch_extractor.py:10-42 (forward)
+
+Same names, argument meaning and error behaviour; inference / evaluation only (no autograd: the reference's backward kernels are
+training code).  Tensors must live on the GPU: there is no CPU path."""
+from __future__ import annotations
+
+from collections import namedtuple
+from typing import Optional, Tuple, Union
+
+import torch
+
+from . import _lib
+from .ops import check, cur_stream, mk
+
+_KNN = namedtuple("KNN", "dists idx knn")
+
+
+def _lengths(lengths: Optional[torch.Tensor], N: int, device) -> Optional[torch.Tensor]:
+    if lengths is None:
+        return None
+    if lengths.ndim != 1 or lengths.shape[0] != N:
+        raise ValueError("Expected lengths to be of shape (N,)")
+    return lengths.to(device=device, dtype=torch.int64).contiguous()
+
+
+def knn_points(p1: torch.Tensor, p2: torch.Tensor, lengths1: Union[torch.Tensor, None] = None, lengths2: Union[torch.Tensor, None] = None,
+               norm: int = 2, K: int = 1, version: int = -1, return_nn: bool = False, return_sorted: bool = True) -> _KNN:
+    """K nearest neighbours in p2 of every point of p1 (functions/knn.py:113-196).  `version` selected a CUDA kernel variant in the
+    reference and is accepted and ignored; the result is always sorted ascending (what return_sorted=True gives the reference; an
+    unsorted result is any order, so this satisfies return_sorted=False too).  dists are squared L2 (norm 2) or L1 (norm 1)."""
+    if p1.shape[0] != p2.shape[0]:
+        raise ValueError("pts1 and pts2 must have the same batch dimension.")
+    if p1.shape[2] != p2.shape[2]:
+        raise ValueError("pts1 and pts2 must have the same point dimension.")
+    if norm not in (1, 2):
+        raise ValueError("Support for 1 or 2 norm.")
+    if not p1.is_cuda or not p2.is_cuda:
+        raise RuntimeError("knn_points: GPU tensors expected (the HIP kernel is the only implementation)")
+    p1 = p1.float().contiguous()
+    p2 = p2.float().contiguous()
+    N, P1, D = p1.shape
+    P2 = p2.shape[1]
+    l1 = _lengths(lengths1, N, p1.device)
+    l2 = _lengths(lengths2, N, p1.device)
+    dists = torch.empty(N, P1, K, device=p1.device, dtype=torch.float32)
+    idx = torch.empty(N, P1, K, device=p1.device, dtype=torch.int64)
+    if N * P1 * K:
+        d = mk(_lib.UdKnn, p1=p1, p2=p2, lengths1=l1, lengths2=l2, dists=dists, idx=idx, work=None, N=N, P1=P1, P2=P2, D=D, K=K, norm=norm)
+        if K == 1 and -(-P1 // 256) * N < 1024 and P2 > 4096:
+            work = torch.empty(N * P1, device=p1.device, dtype=torch.int64)     # scratch for the P2-split merge
+            d.work = work.data_ptr()
+        check(_lib.lib.ud_knn_points(d, cur_stream()), "ud_knn_points")
+    nn = knn_gather(p2, idx, lengths2) if return_nn else None
+    return _KNN(dists=dists, idx=idx, knn=nn)
+
+
+def knn_gather(x: torch.Tensor, idx: torch.Tensor, lengths: Union[torch.Tensor, None] = None) -> torch.Tensor:
+    """x_out[n, l, k] = x[n, idx[n, l, k]], zero where k >= lengths[n] (functions/knn.py:199-249).  Plain indexing: no kernel of ours."""
+    N, M, U = x.shape
+    _N, L, K = idx.shape
+    if N != _N:
+        raise ValueError("x and idx must have same batch dimension.")
+    if lengths is None:
+        lengths = torch.full((N,), M, dtype=torch.int64, device=x.device)
+    x_out = x[:, :, None].expand(-1, -1, K, -1).gather(1, idx[:, :, :, None].expand(-1, -1, -1, U))
+    if lengths.min() < K:
+        mask = lengths[:, None] <= torch.arange(K, device=x.device)[None]
+        x_out[mask[:, None].expand(-1, L, -1)[:, :, :, None].expand(-1, -1, -1, U)] = 0.0
+    return x_out
+
+
+def _handle_pointcloud_input(points, lengths, normals):
+    if points.ndim != 3:
+        raise ValueError("Expected points to be of shape (N, P, D)")
+    if lengths is not None and (lengths.ndim != 1 or lengths.shape[0] != points.shape[0]):
+        raise ValueError("Expected lengths to be of shape (N,)")
+    if lengths is None:
+        lengths = torch.full((points.shape[0],), points.shape[1], dtype=torch.int64, device=points.device)
+    if normals is not None and normals.ndim != 3:
+        raise ValueError("Expected normals to be of shape (N, P, 3")
+    return points, lengths, normals
+
+
+class ChamferDistance(torch.nn.Module):
+    """Per-point squared distances to the nearest neighbour in the other cloud, both directions (utils/chamfer_distance.py:60-159):
+    returns (cham_x [N,P1], cham_y [N,P2], idx_x [N,P1], idx_y [N,P2]).  The reduction arguments are validated and, as in the
+    reference, otherwise unused; normals are accepted and ignored (the reference never reads them either)."""
+
+    def forward(self, x, y, x_lengths=None, y_lengths=None, x_normals=None, y_normals=None, weights=None,
+                batch_reduction: Union[str, None] = "mean", point_reduction: str = "mean"):
+        if batch_reduction is not None and batch_reduction not in ["mean", "sum"]:
+            raise ValueError('batch_reduction must be one of ["mean", "sum"] or None')
+        if point_reduction not in ["mean", "sum"]:
+            raise ValueError('point_reduction must be one of ["mean", "sum"]')
+        x, x_lengths, x_normals = _handle_pointcloud_input(x, x_lengths, x_normals)
+        y, y_lengths, y_normals = _handle_pointcloud_input(y, y_lengths, y_normals)
+        N, P1, D = x.shape
+        P2 = y.shape[1]
+        if y.shape[0] != N or y.shape[2] != D:
+            raise ValueError("y does not have the correct shape.")
+        if weights is not None:
+            if weights.size(0) != N:
+                raise ValueError("weights must be of shape (N,).")
+            if not (weights >= 0).all():
+                raise ValueError("weights cannot be negative.")
+            if weights.sum() == 0.0:
+                weights = weights.view(N, 1)
+                z = (x.sum((1, 2)) * weights)
+                return (z.sum() * 0.0, z.sum() * 0.0) if batch_reduction in ["mean", "sum"] else (z * 0.0, z * 0.0)
+        x_nn = knn_points(x, y, lengths1=x_lengths, lengths2=y_lengths, K=1)       # rows beyond a length are already zero
+        y_nn = knn_points(y, x, lengths1=y_lengths, lengths2=x_lengths, K=1)
+        cham_x = x_nn.dists[..., 0]
+        cham_y = y_nn.dists[..., 0]
+        if weights is not None:
+            cham_x = cham_x * weights.view(N, 1)
+            cham_y = cham_y * weights.view(N, 1)
+        return cham_x, cham_y, x_nn.idx[..., -1], y_nn.idx[..., -1]
+
+
+def chamfer_dist(tensor1: torch.Tensor, tensor2: torch.Tensor) -> torch.Tensor:
+    """(sqrt(d(x->y)) + sqrt(d(y->x))) / 2 per point, clouds of equal size (utils/evaluation_depth.py:12-18)."""
+    d1, d2, _, _ = ChamferDistance()(tensor1, tensor2)
+    return (torch.sqrt(d1) + torch.sqrt(d2)) / 2
+
+
+class RandomPatchExtractor(torch.nn.Module):
+    """patch_size = (width, height) patches around `centers` [B,N,2] = (y, x), zero beyond the image border
+    (modules/patch_extractor.py:16-42).  The result has the reference's shape {B, C, N, h, w} over memory written in [b][n][c][i][j]
+    order (extract_patches_kernel.cu:22 vs :91) -- identical for the C = 1 tensors every reference call site passes."""
+
+    def forward(self, tensor: torch.Tensor, centers: torch.Tensor, patch_size: Tuple[int, int]) -> torch.Tensor:
+        if not tensor.is_cuda:
+            raise RuntimeError("RandomPatchExtractor: GPU tensors expected (the HIP kernel is the only implementation)")
+        dtype = tensor.dtype
+        patch_width, patch_height = patch_size
+        pad_w, pad_h = patch_width // 2, patch_height // 2
+        B, Cc, H, W = tensor.shape
+        N = centers.shape[1]
+        # the reference shifts the centres into padded coordinates in the image dtype, then truncates (.int()) -- kept, so that
+        # fractional / negative centres round the same way
+        cpad = (centers.to(tensor.device) + torch.tensor([pad_h, pad_w], dtype=dtype, device=tensor.device).reshape(1, 1, 2)).int().contiguous()
+        x = tensor.float().contiguous()
+        out = torch.empty(B, Cc, N, patch_height, patch_width, device=tensor.device, dtype=torch.float32)
+        d = mk(_lib.UdExtractPatches, in_=x, out=out, centers=cpad, B=B, C=Cc, H=H, W=W, N=N, h=patch_height, w=patch_width,
+               pad_h=pad_h, pad_w=pad_w)
+        check(_lib.lib.ud_extract_patches(d, cur_stream()), "ud_extract_patches")
+        return out.to(dtype)
