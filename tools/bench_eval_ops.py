@@ -49,7 +49,7 @@ def main():
     from oracle import build_ref_knn                                                 # CPU baseline leg only
     ref = build_ref_knn.load_ref()
     if ref is not None:
-        nq = 1024
+        nq = 16384
         l1, l2 = torch.tensor([nq]), torch.tensor([P])
         torch.set_num_threads(1)
         t0 = time.perf_counter()

@@ -50,7 +50,7 @@ def knn_points(p1: torch.Tensor, p2: torch.Tensor, lengths1: Union[torch.Tensor,
     idx = torch.empty(N, P1, K, device=p1.device, dtype=torch.int64)
     if N * P1 * K:
         d = mk(_lib.UdKnn, p1=p1, p2=p2, lengths1=l1, lengths2=l2, dists=dists, idx=idx, work=None, N=N, P1=P1, P2=P2, D=D, K=K, norm=norm)
-        if K == 1 and -(-P1 // 256) * N < 1024 and P2 > 4096:
+        if K == 1 and -(-P1 // 512) * N < 1024 and P2 > 4096:
             work = torch.empty(N * P1, device=p1.device, dtype=torch.int64)     # scratch for the P2-split merge
             d.work = work.data_ptr()
         check(_lib.lib.ud_knn_points(d, cur_stream()), "ud_knn_points")
