@@ -82,7 +82,9 @@ typedef struct UdGemm {
   float b2_g1, post_add_g1;    /* group 1 constants for UD_EPI_HEAD */
   int tile_hint;               /* 0 = auto, 1 = force 128x128 tiles, 2 = force 256x256, 3 = force 192x256 (dense A only),
                                   5 / 6 = 128x128 tiles: plain 2-stage kernel / 4-stage pipelined ring (6 is what auto picks when the
-                                  tile count is at most the CU count and K >= 512), 7 = 6 + the two-way K split below */
+                                  tile count is at most the CU count and K >= 512), 7 = 6 + the two-way K split below,
+                                  8 = row-balanced schedule of the 256-column kernel (dense A; auto picks it when the tile list
+                                  would leave the last round partly empty) */
   /* optional scratch for the two-way K split of small problems (at most 128 tiles of 128x128, K >= 1024, dense A, F16 / F32
    * epilogues): two workgroups on different CUs each take half of K, the later one adds the other's fp32 partial tile (a + b is
    * order-independent, so results do not depend on timing) and runs the epilogue.  splitk_ws: 2 * tiles * 64 KB; splitk_cnt: one

@@ -56,7 +56,8 @@ def test_gemm_f16_dense(ops, M, N, K, act):
 
 
 @pytest.mark.parametrize("M,N,K,hint", [(1100, 512, 128, 2), (2048, 256, 64, 2), (3000, 1152, 384, 2), (2600, 1024, 4096, 2), (1100, 512, 128, 1),
-                                           (1100, 512, 128, 3), (3000, 1152, 384, 3), (2600, 1024, 2048, 3)])
+                                           (1100, 512, 128, 3), (3000, 1152, 384, 3), (2600, 1024, 2048, 3),
+                                           (11000, 1024, 256, 8), (8190, 4096, 128, 8), (20000, 512, 192, 8), (5555, 768, 1024, 8)])
 def test_gemm_big_tiles_f16_f32(ops, M, N, K, hint):
     """256x256 / 4-stage kernel (tile_hint=2) against the same fp32 statement; edge tiles in M and N, deep K ring."""
     A = rnd(M, K, seed=1).half()
@@ -76,7 +77,7 @@ def test_gemm_big_tiles_f16_f32(ops, M, N, K, hint):
     assert rel(x16.float(), x0 + ref) < 1e-3
 
 
-@pytest.mark.parametrize("hint", [2, 3])
+@pytest.mark.parametrize("hint", [2, 3, 8])
 def test_gemm_big_tiles_persistent(ops, hint):
     """More tiles than CUs: every workgroup walks several tiles (K-tile stream continuous across tiles, epilogue of tile t
     beside the operand DMA of tile t+1), straight-line full-tile epilogues and the edge-tile path in one launch; fp16+GELU,
@@ -115,6 +116,42 @@ def test_gemm_big_tiles_persistent(ops, hint):
     assert rel(vt[..., vt_cols(Npad)].float(), want) < 1e-3
     assert (vt[..., vt_cols(Npad)].float() - want).abs().max() < 2e-2
     assert vt_unused_zero(vt, Npad)
+
+
+def test_gemm_row_balanced_schedule_is_bit_identical(ops):
+    """tile_hint 8 (row-balanced spans cut into 128 / 192 / 256-row tiles, one column group of workgroups per 256 outputs) only
+    re-orders WHICH workgroup computes a row: every output element must carry the same bits as the classic tile list gives it --
+    fp16 + GELU, fp32 accumulate, Q|K + V^T -- including an M that is not a multiple of 64 and spans of unequal length."""
+    B, Npad, D, H = 8, 1376, 512, 8
+    K = 512
+    for M in (B * Npad, B * Npad - 40):
+        A = rnd(M, K, seed=1).half()
+        outs = {}
+        for hint in (2, 8):
+            N = 2048
+            W = rnd(N, K, scale=K ** -0.5, seed=2).half()
+            bias = rnd(N, seed=3)
+            o16 = torch.zeros(M, N, dtype=torch.half, device="cuda")
+            ops.gemm(A=A, W=W, bias=bias, out=o16, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, epi=ops.UD_EPI_F16, act=ops.UD_ACT_GELU, tile_hint=hint)
+            x = rnd(M, N, seed=5)
+            ops.gemm(A=A, W=W, bias=bias, out=x, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, epi=ops.UD_EPI_F32, accumulate=1, tile_hint=hint)
+            res = [o16, x]
+            if M == B * Npad:
+                N, kv_ld = 3 * D, 1408
+                W = rnd(N, K, scale=K ** -0.5, seed=4).half()
+                bias = rnd(N, seed=6)
+                qk = torch.zeros(M, 2 * D, dtype=torch.half, device="cuda")
+                vt = torch.zeros(B, H, 64, kv_ld, dtype=torch.half, device="cuda")
+                ops.gemm(A=A, W=W, bias=bias, out=qk, out2=vt, M=M, N=N, K=K, lda=K, ldw=K, ldc=2 * D, epi=ops.UD_EPI_QKV,
+                         vsplit=2 * D, tok_per_img=Npad, kv_ld=kv_ld, heads_v=H, tile_hint=hint)
+                res += [qk, vt]
+                if hint == 8:
+                    ref = A.float() @ W.float().t() + bias
+                    assert rel(qk.float(), ref[:, :2 * D]) < 1e-3
+            torch.cuda.synchronize()
+            outs[hint] = res
+        for a, b in zip(outs[2], outs[8]):
+            assert torch.equal(a, b)
 
 
 def test_gemm_big_tiles_qkv_d2s(ops):

@@ -25,5 +25,10 @@ for k in f:
     wr = sum(w.get(k, [0])) / max(1, len(w.get(k, [0])))
     out["kernels"][k] = {"launches": len(f[k]), "hbm_read_bytes": round(fr * 2048), "hbm_write_bytes": round(wr * 1024),
                          "hbm_total_bytes": round(fr * 2048 + wr * 1024)}
-json.dump(out, open("profiles/r01_hbm_traffic.json", "w"), indent=1)
+json.dump(out, open(f"profiles/{tag}_hbm_traffic.json", "w"), indent=1)
+import os
+if os.path.exists(f"{src}/v1trace/v_kernel_stats.csv"):
+    shutil.copy(f"{src}/v1trace/v_kernel_stats.csv", f"profiles/{tag}_v1_cnvnxtl_640x480_bs16_kernel_stats.csv")
+if os.path.exists(f"gpurun_out/prof_{tag}.v1.log"):
+    shutil.copy(f"gpurun_out/prof_{tag}.v1.log", f"profiles/{tag}_v1_cnvnxtl_640x480_bs16_breakdown.txt")
 print("updated profiles/ from", src)

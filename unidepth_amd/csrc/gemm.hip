@@ -57,8 +57,8 @@ struct ConvLane {
 // residual-as-accumulator-init: for `out += A W^T` epilogues the old fp32 values are loaded into the accumulators BEFORE the
 // K loop (overlapping the first operand DMA) instead of being re-read in the epilogue, where every tile of a one-round GEMM
 // would hit HBM at the same moment; the epilogue then only writes.
-template <int TM, int TN>
-__device__ __forceinline__ void gemm_preload_acc(const UdGemm& p, f32x4 (&acc)[TM][TN], int mbase, int nbase, int lane, const char* out) {
+template <int TM, int TN, int TMA>      // TM row tiles used of an accumulator array of TMA (deduced)
+__device__ __forceinline__ void gemm_preload_acc(const UdGemm& p, f32x4 (&acc)[TMA][TN], int mbase, int nbase, int lane, const char* out) {
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = mbase + i * 16 + (lane & 15);
@@ -84,8 +84,8 @@ __device__ __forceinline__ float ud_act_t(float x) {
 
 // ACT = activation of the fp16 output (EPI_F16/QKV) or of the fp16 copy (EPI_F32/D2S), resolved ONCE per kernel by
 // gemm_epilogue below: a per-element switch on the runtime value compiled to ~700 scalar branches in the unrolled epilogue.
-template <int TM, int TN, int EPI, bool SWAP, bool PRELOADED, int ACT>
-__device__ __forceinline__ void gemm_epilogue_impl(const UdGemm& p, f32x4 (&acc)[TM][TN], int mbase, int nbase, int lane, const float* bias,
+template <int TM, int TN, int EPI, bool SWAP, bool PRELOADED, int ACT, int TMA>
+__device__ __forceinline__ void gemm_epilogue_impl(const UdGemm& p, f32x4 (&acc)[TMA][TN], int mbase, int nbase, int lane, const float* bias,
                                                    char* out, char* out2, const float* w2, float b2, float post_add, char* stage) {
   if constexpr (!SWAP) {
     // V^T tiles of UD_EPI_QKV: lane owns tokens mb..mb+3 (one image: tok_per_img % 4 == 0) for column n.
@@ -273,8 +273,8 @@ __device__ __forceinline__ void gemm_epilogue_impl(const UdGemm& p, f32x4 (&acc)
   }
 }
 
-template <int TM, int TN, int EPI, bool SWAP, bool PRELOADED = false>
-__device__ __forceinline__ void gemm_epilogue(const UdGemm& p, f32x4 (&acc)[TM][TN], int mbase, int nbase, int lane, const float* bias,
+template <int TM, int TN, int EPI, bool SWAP, bool PRELOADED = false, int TMA = TM>
+__device__ __forceinline__ void gemm_epilogue(const UdGemm& p, f32x4 (&acc)[TMA][TN], int mbase, int nbase, int lane, const float* bias,
                                               char* out, char* out2, const float* w2, float b2, float post_add, char* stage) {
   const int a = (EPI == UD_EPI_F16 || EPI == UD_EPI_QKV) ? p.act : p.act2;
   if constexpr (EPI == UD_EPI_HEAD || EPI == UD_EPI_QKV) {
@@ -649,7 +649,11 @@ __device__ __forceinline__ void ud_interleave_reads() {
   __builtin_amdgcn_sched_group_barrier(0x8, M - q * R, 0);
 }
 
-template <int MH, int EPI, int AMODE>
+// BAL (row-balanced schedule, dense A, MH = 4): instead of whole 256-row tiles dealt round-robin (fc1: 688 tiles on 256 CUs = 2.69
+// rounds, the third one 69 % full), every column of 256 outputs gets floor(256 / tiles_n) workgroups and each of them a contiguous
+// span of ceil(M / 64) / that many 64-row units (+-1), cut into tiles of 64 * {2, 3, 4} rows of near-equal height (fc1: 704 rows =
+// 256 + 256 + 192 per CU): all CUs finish together.  A tile of 64 * MHC rows runs the MHC-instantiation of the tile body.
+template <int MH, int EPI, int AMODE, bool BAL = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using C = BigCfg<MH>;
@@ -692,9 +696,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   unsigned cyx[C::A_LOADS];       // conv: (y << 16) | x of the row's pixel (y = 0x4000 for rows past the image: always padding)
   unsigned pb[4];
   const float inv_cc = (AMODE != UD_A_DENSE) ? 1.0f / (float)(p.Cin >> 3) : 0.0f;
-  auto setup = [&](int m0, int n0) {
+  auto setup = [&](int m0, int n0, int mh) {
 #pragma unroll
     for (int i = 0; i < C::A_LOADS; ++i) {
+      if (i >= mh) continue;
       int m = m0 + lrow + 64 * i;
       m = m < p.M ? m : p.M - 1;
       if constexpr (AMODE == UD_A_DENSE) {
@@ -714,11 +719,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
       pb[i] = ((unsigned)n * (unsigned)p.ldw + csrc * 8) * 2u;
     }
   };
-  auto issue = [&](int kt, int stg) {
+  auto issue = [&](int kt, int stg, int mh) {
     char* sb = smem + stg * C::STAGE + wv * 1024;
     if constexpr (AMODE == UD_A_DENSE) {
 #pragma unroll
-      for (int i = 0; i < C::A_LOADS; ++i) ud_bufl16(rA, pa[i], kt * 128, sb + i * 8192);
+      for (int i = 0; i < C::A_LOADS; ++i)
+        if (i < mh) ud_bufl16(rA, pa[i], kt * 128, sb + i * 8192);
     } else {
       // implicit-GEMM gather: this lane's 16-byte chunk = 8 channels of tap (kc / (Cin/8)); one tap decode per K-tile;
       // padding taps use an offset beyond the descriptor's range and read as zeros
@@ -730,6 +736,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
       const int dy = t3 - 1, dx = tap - t3 * 3 - 1;
 #pragma unroll
       for (int i = 0; i < C::A_LOADS; ++i) {
+        if (i >= mh) continue;
         const int yy = (int)(cyx[i] >> 16) + dy, xx = (int)(cyx[i] & 0xffff) + dx;
         const bool ok = tap < 9 && (unsigned)yy < (unsigned)p.Himg && (unsigned)xx < (unsigned)p.Wimg;
         const unsigned off = ok ? pa[i] + (unsigned)((yy * p.Wimg + xx) * p.cstride + p.coff + cch) * 2u : 0xfffffff0u;
@@ -744,7 +751,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   const int fswz = (lane & 15) >> 1;
   const int c0 = ((lane >> 4) ^ fswz) << 4;          // k-step 0
   const int c1 = ((4 + (lane >> 4)) ^ fswz) << 4;    // k-step 1
-  const int a_off = (wm * (BM / 2) + (lane & 15)) * 128;
   const int b_off = C::A_BYTES + (wn * 64 + (lane & 15)) * 128;
 
   f32x4 acc[TM][4];
@@ -753,25 +759,72 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
 
   constexpr bool ACC_EPI = (EPI == UD_EPI_F32);        // `out (+)= ...`: old values are preloaded into the accumulators
 
-  int m0, n0;
-  int t = blockIdx.x;
-  decode(t, m0, n0);
-  setup(m0, n0);
-  issue(0, 0);
+  int m0, n0, mhc = MH;
+  int t = blockIdx.x;          // classic: index into the tile list; balanced: index of the tile inside this workgroup's row span
+  int bal_k = 0, bal_tb = 0, bal_te = 0, bal_u0 = 0, bal_n0 = 0;
+  if constexpr (BAL) {
+    const int G = gridDim.x;                       // = cpc * tiles_n (launch256bal)
+    const int cpc = G / tiles_n;                   // workgroups per column of 256 outputs
+    const int U = (p.M + 63) >> 6;                 // 64-row units per column
+    // blocks b, b + 8, ... share an XCD (and its L2): give each XCD a compact block of the (row span x column) grid, 4 x 2 XCDs when
+    // the grid divides (fc1: 4 row spans x 8 columns per XCD: 5.6 MB of A rows + 4 MB of W panels per L2 -- with one column pair
+    // per XCD instead every L2 streamed all of A, 2.3x the fabric traffic, and the balanced schedule gained only 3 %)
+    int col, r;
+    if ((G & 7) == 0 && (cpc & 3) == 0 && (tiles_n & 1) == 0) {
+      const int x = blockIdx.x & 7, j = blockIdx.x >> 3;          // XCD, slot inside the XCD (G / 8 slots)
+      const int cx = tiles_n >> 1, rx = cpc >> 2;                  // columns / row spans per XCD
+      col = (x & 1) * cx + j % cx;
+      r = (x >> 1) * rx + j / cx;
+    } else {
+      const int lc = blockIdx.x;
+      col = lc / cpc;
+      r = lc - col * cpc;
+    }
+    const int base = U / cpc, extra = U - base * cpc;
+    const int un = base + (r < extra ? 1 : 0);
+    if (un == 0) return;
+    bal_u0 = r * base + (r < extra ? r : extra);
+    bal_k = (un + 3) >> 2;
+    bal_tb = un / bal_k;
+    bal_te = un - bal_tb * bal_k;
+    bal_n0 = col << 8;
+    t = 0;
+  }
+  auto tile_at = [&](int i, int& tm0, int& tn0, int& tmh) {
+    if constexpr (BAL) {
+      tmh = bal_tb + (i < bal_te ? 1 : 0);
+      tm0 = (bal_u0 + i * bal_tb + (i < bal_te ? i : bal_te)) << 6;
+      tn0 = bal_n0;
+    } else {
+      decode(i, tm0, tn0);
+      tmh = MH;
+    }
+  };
+  const int tcount = BAL ? bal_k : nblk;
+  const int tstep = BAL ? 1 : (int)gridDim.x;
+  tile_at(t, m0, n0, mhc);
+  setup(m0, n0, mhc);
+  issue(0, 0, mhc);
 
   int trace_tile = 0;
   bool first = true;
-  for (; t < nblk; t += gridDim.x, ++trace_tile) {
+  for (; t < tcount; t += tstep, ++trace_tile) {
     UD_STAMP(0);
-    const int tn = t + gridDim.x;
-    const bool has_next = tn < nblk;
-    int m0n = 0, n0n = 0;
-    if (has_next) decode(tn, m0n, n0n);
-    const int mbase = m0 + wm * (BM / 2), nbase = n0 + wn * 64;
+    const int tn = t + tstep;
+    const bool has_next = tn < tcount;
+    int m0n = 0, n0n = 0, mhn = MH;
+    if (has_next) tile_at(tn, m0n, n0n, mhn);
     const bool swap = !(EPI == UD_EPI_QKV && n0 >= p.vsplit);
+    // ---- the tile body, instantiated per tile height (MHC row tiles of 16 per wave and m-half)
+    auto tile_body = [&](auto MHT) {
+    constexpr int MHC = decltype(MHT)::value;
+    constexpr int TMC = 2 * MHC;
+    constexpr int BMC = 64 * MHC;
+    const int a_off = (wm * (BMC / 2) + (lane & 15)) * 128;
+    const int mbase = m0 + wm * (BMC / 2), nbase = n0 + wn * 64;
 
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TMC; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -784,7 +837,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
       if (p.accumulate) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        gemm_preload_acc<TM, 4>(p, acc, mbase, nbase, ln, (const char*)p.out);
+        gemm_preload_acc<TMC, 4>(p, acc, mbase, nbase, ln, (const char*)p.out);
       }
     }
     if (first) {
@@ -796,7 +849,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
     {  // first fragments of this tile (its K-tile 0 landed before the barrier that ended the previous tile's K loop)
       const char* sb0 = smem + stg * C::STAGE;
 #pragma unroll
-      for (int i = 0; i < MH; ++i) a0[i] = *(const half8*)(sb0 + a_off + i * 2048 + c0);
+      for (int i = 0; i < MHC; ++i) a0[i] = *(const half8*)(sb0 + a_off + i * 2048 + c0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) b0[j] = *(const half8*)(sb0 + b_off + j * 2048 + c0);
     }
@@ -809,37 +862,37 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
       const char* sb = smem + stg * C::STAGE;
       const char* sbn = smem + (stg ^ 1) * C::STAGE;
 #define UD_MFMA_HALF(ROW0, AF, BF)                                                                               \
-  _Pragma("unroll") for (int i = 0; i < MH; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) {               \
+  _Pragma("unroll") for (int i = 0; i < MHC; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) {               \
     if constexpr (SWAP) acc[ROW0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[j], AF[i], acc[ROW0 + i][j], 0, 0, 0); \
     else acc[ROW0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AF[i], BF[j], acc[ROW0 + i][j], 0, 0, 0);   \
   }
       // ---- phase (k0, m-half 0): DMA of the whole next K-tile goes out first
       if constexpr (LAST) {
         if (has_next) {
-          setup(m0n, n0n);
-          issue(0, stg ^ 1);
+          setup(m0n, n0n, mhn);
+          issue(0, stg ^ 1, mhn);
         }
       } else {
-        issue(kt + 1, stg ^ 1);
+        issue(kt + 1, stg ^ 1, MHC);
       }
 #pragma unroll
-      for (int i = 0; i < MH; ++i) a1[i] = *(const half8*)(sb + a_off + (MH + i) * 2048 + c0);
+      for (int i = 0; i < MHC; ++i) a1[i] = *(const half8*)(sb + a_off + (MHC + i) * 2048 + c0);
       UD_MFMA_HALF(0, a0, b0)
-      ud_interleave_reads<MH, 4 * MH>();
+      ud_interleave_reads<MHC, 4 * MHC>();
       __builtin_amdgcn_sched_barrier(0);
       // ---- phase (k0, m-half 1)
 #pragma unroll
-      for (int i = 0; i < MH; ++i) a0[i] = *(const half8*)(sb + a_off + i * 2048 + c1);
+      for (int i = 0; i < MHC; ++i) a0[i] = *(const half8*)(sb + a_off + i * 2048 + c1);
 #pragma unroll
       for (int j = 0; j < 4; ++j) b1[j] = *(const half8*)(sb + b_off + j * 2048 + c1);
-      UD_MFMA_HALF(MH, a1, b0)
-      ud_interleave_reads<MH + 4, 4 * MH>();
+      UD_MFMA_HALF(MHC, a1, b0)
+      ud_interleave_reads<MHC + 4, 4 * MHC>();
       __builtin_amdgcn_sched_barrier(0);
       // ---- phase (k1, m-half 0)
 #pragma unroll
-      for (int i = 0; i < MH; ++i) a1[i] = *(const half8*)(sb + a_off + (MH + i) * 2048 + c1);
+      for (int i = 0; i < MHC; ++i) a1[i] = *(const half8*)(sb + a_off + (MHC + i) * 2048 + c1);
       UD_MFMA_HALF(0, a0, b1)
-      ud_interleave_reads<MH, 4 * MH>();
+      ud_interleave_reads<MHC, 4 * MHC>();
       __builtin_amdgcn_sched_barrier(0);
       // ---- phase (k1, m-half 1): next K-tile must have landed for every wave before anyone reads it
       asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
@@ -847,12 +900,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
       asm volatile("" ::: "memory");
       if constexpr (!LAST) {                   // (the next TILE's first fragments are read after the epilogue: 32 registers less there)
 #pragma unroll
-        for (int i = 0; i < MH; ++i) a0[i] = *(const half8*)(sbn + a_off + i * 2048 + c0);
+        for (int i = 0; i < MHC; ++i) a0[i] = *(const half8*)(sbn + a_off + i * 2048 + c0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) b0[j] = *(const half8*)(sbn + b_off + j * 2048 + c0);
       }
-      UD_MFMA_HALF(MH, a1, b1)
-      if constexpr (!LAST) ud_interleave_reads<MH + 4, 4 * MH>();
+      UD_MFMA_HALF(MHC, a1, b1)
+      if constexpr (!LAST) ud_interleave_reads<MHC + 4, 4 * MHC>();
       __builtin_amdgcn_sched_barrier(0);
 #undef UD_MFMA_HALF
       stg ^= 1;
@@ -877,7 +930,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
     // nbase + 16 (j + (q & 1)) + 8 (q >> 1): 16-byte stores, 64-byte row segments.  V^T tiles (!SWAP) own 4 consecutive rows
     // (tokens) per lane; the same exchange between row tiles i / i+1 gives 8 consecutive tokens starting at
     // (v_permlane32_swap between row tiles i / i+1 packs them in the V^T block order, see below).
-    const bool full = (m0 + BM <= p.M) && (n0 + 256 <= p.N) && p.rows_in == 0 && p.add == nullptr && p.bias != nullptr;
+    const bool full = (m0 + BMC <= p.M) && (n0 + 256 <= p.N) && p.rows_in == 0 && p.add == nullptr && p.bias != nullptr;
     bool fast = false;
     int eln = lane;
     asm volatile("" : "+v"(eln));              // epilogue addresses are derived here, per tile: nothing of them lives across the K loop
@@ -894,7 +947,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
           auto body = [&](auto ACT) {
             constexpr int AC = decltype(ACT)::value;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
+            for (int i = 0; i < TMC; ++i) {
               unsigned w[4][2];
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
@@ -928,7 +981,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
               const int nv = n - p.vsplit;
               half_t* vrow = vt + (size_t)((nv >> 6) * 64 + (nv & 63)) * p.kv_ld;
 #pragma unroll
-              for (int ip = 0; ip < MH; ++ip) {
+              for (int ip = 0; ip < MHC; ++ip) {
                 unsigned w0[2], w1[2];
                 w0[0] = ud_pack2(acc[2 * ip][j][0] + bvn, acc[2 * ip][j][1] + bvn);
                 w0[1] = ud_pack2(acc[2 * ip][j][2] + bvn, acc[2 * ip][j][3] + bvn);
@@ -960,7 +1013,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
         const bool wr32 = p.accumulate != 2;   // accumulate == 2: the fp32 stream dies here, only the fp16 copy is consumed
         const bool lre = p.act2 == UD_ACT_LRELU;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TMC; ++i) {
           unsigned w[4][2];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -993,7 +1046,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
       // ConvTranspose(k = s) depth-to-space accumulate, straight-line: the wave's 64 columns lie inside ONE (a, c) sub-pixel block
       // when Co % 64 == 0, so the destination pixel depends on the row only (one (img, y, x) decode per row tile, not per element);
       // fp32 read-modify-write in 16-byte pieces, fp16 copy paired to 16-byte stores.
-      fast = (m0 + BM <= p.M) && (n0 + 256 <= p.N) && (p.d2s_Co & 63) == 0 && (p.ldc & 3) == 0 && (p.out2 == nullptr || (p.ldc2 & 7) == 0);
+      fast = (m0 + BMC <= p.M) && (n0 + 256 <= p.N) && (p.d2s_Co & 63) == 0 && (p.ldc & 3) == 0 && (p.out2 == nullptr || (p.ldc2 & 7) == 0);
       if (fast) {
         const int k = p.d2s_k;
         const int ac = nbase / p.d2s_Co;
@@ -1005,7 +1058,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
         for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(p.bias + o0 + j * 16 + 4 * fq);
         const bool lre = p.act2 == UD_ACT_LRELU;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < TMC; ++i) {
           const int m = mbase + i * 16 + frow;
           const int img = m / p.d2s_rows_in_img;
           const int pp = m - img * p.d2s_rows_in_img;
@@ -1048,10 +1101,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
       // generic path: edge tiles, row remaps, `add` operands, depth-to-space (8-byte fp16 stores, per-element bounds checks)
       constexpr bool PRE = ACC_EPI;            // the residual is already inside the accumulators (in-loop or preloaded)
       if constexpr (EPI == UD_EPI_QKV) {
-        if (swap) gemm_epilogue<TM, 4, EPI, true, PRE>(p, acc, mbase, nbase, eln, p.bias, (char*)p.out, (char*)p.out2, nullptr, 0.f, 0.f, nullptr);
-        else gemm_epilogue<TM, 4, EPI, false, PRE>(p, acc, mbase, nbase, eln, p.bias, (char*)p.out, (char*)p.out2, nullptr, 0.f, 0.f, nullptr);
+        if (swap) gemm_epilogue<TMC, 4, EPI, true, PRE>(p, acc, mbase, nbase, eln, p.bias, (char*)p.out, (char*)p.out2, nullptr, 0.f, 0.f, nullptr);
+        else gemm_epilogue<TMC, 4, EPI, false, PRE>(p, acc, mbase, nbase, eln, p.bias, (char*)p.out, (char*)p.out2, nullptr, 0.f, 0.f, nullptr);
       } else {
-        gemm_epilogue<TM, 4, EPI, true, PRE>(p, acc, mbase, nbase, eln, p.bias, (char*)p.out, (char*)p.out2, nullptr, 0.f, 0.f, nullptr);
+        gemm_epilogue<TMC, 4, EPI, true, PRE>(p, acc, mbase, nbase, eln, p.bias, (char*)p.out, (char*)p.out2, nullptr, 0.f, 0.f, nullptr);
       }
     }
     UD_STAMP(3);
@@ -1059,9 +1112,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     UD_STAMP(4);
 #endif
+    };
+    if constexpr (BAL) {
+      if (mhc == 4) tile_body(IntTag<4>{});
+      else if (mhc == 3) tile_body(IntTag<3>{});
+      else tile_body(IntTag<2>{});
+    } else {
+      tile_body(IntTag<MH>{});
+    }
     UD_STAMP(5);
     m0 = m0n;
     n0 = n0n;
+    mhc = mhn;
   }
 }
 
@@ -1082,6 +1144,43 @@ int launch256(const UdGemm& d, hipStream_t s) {
   return UD_OK;
 }
 
+// Row-balanced schedule (gemm256_kernel<4, EPI, DENSE, true>): worth it when the classic tile list leaves the last round partly empty.
+// Needs at least two 64-row units per workgroup (tile heights 128 / 192 / 256 only).
+inline int bal_cpc(const UdGemm& d) {
+  const int tiles_n = (d.N + 255) >> 8;
+  if (tiles_n > 128 || (d.N & 255)) return 0;
+  const int cpc = 256 / tiles_n;
+  const int U = (d.M + 63) >> 6;
+  return (U / cpc >= 2) ? cpc : 0;
+}
+// predicted time (us) of the balanced schedule, same units as pick_tiles: rows of the longest span at the 256-row tile's per-row
+// rate, plus the fixed cost and ~2.5 us of un-hidden prologue / epilogue per extra tile
+inline double bal_time(const UdGemm& d) {
+  const int cpc = bal_cpc(d);
+  if (!cpc) return 1e30;
+  const int U = (d.M + 63) >> 6;
+  const int un = (U + cpc - 1) / cpc;
+  const int k = (un + 3) >> 2;
+  return 8.0 + (un * (30.0 / 4.0) + (k - 1) * 2.5) * ((double)d.K / 1024.0);
+}
+
+template <int EPI>
+int launch256bal(const UdGemm& d, hipStream_t s) {
+  const int tiles_n = (d.N + 255) >> 8;
+  const int cpc = bal_cpc(d);
+  const int lds = 2 * BigCfg<4>::STAGE;
+  static bool attr_set[UD_MAX_DEVICES];
+  if (!ud_attr_once(attr_set)) {
+    if (hipFuncSetAttribute((const void*)gemm256_kernel<4, EPI, UD_A_DENSE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      ud_set_error("ud_gemm_f16: cannot reserve the LDS ring of the large-tile kernel");
+      return UD_ERR_LAUNCH;
+    }
+  }
+  hipLaunchKernelGGL((gemm256_kernel<4, EPI, UD_A_DENSE, true>), dim3(cpc * tiles_n), dim3(512), lds, s, d);
+  UD_CHECK_LAUNCH("ud_gemm_f16 (large tile, row-balanced) launch");
+  return UD_OK;
+}
+
 // Tile-shape choice for dense GEMMs.  Cost model fitted on MI355X (tools/bench_gemm*.py): per-launch fixed cost + rounds x
 // K-loop time per round.  The large-tile kernel (one workgroup per CU) loses to wave quantisation when the tile count is
 // small or just above a multiple of 256 CUs; the 128x128 kernel runs two workgroups per CU, so its rounds quantise in halves.
@@ -1094,22 +1193,30 @@ inline int pick_tiles(const UdGemm& d) {
     if (a_bytes >= 2147483648.0 || 2.0 * d.N * d.ldw >= 2147483648.0) return 0;
   }
   if (d.epi == UD_EPI_QKV && (d.vsplit & 255)) return 0;
-  if (d.tile_hint == 1 || d.tile_hint >= 5) return 0;
+  if (d.tile_hint == 1 || (d.tile_hint >= 5 && d.tile_hint != 8)) return 0;
   if (d.tile_hint == 2) return 4;
   if (d.tile_hint == 3) return 3;
+  const bool bal_ok = d.amode == UD_A_DENSE && (d.epi == UD_EPI_F16 || d.epi == UD_EPI_F32 || d.epi == UD_EPI_QKV) && bal_cpc(d) > 0;
+  if (d.tile_hint == 8 && bal_ok) return 8;
   const double kk = (double)d.K / 1024.0;
   const double tn = (double)((d.N + 255) / 256);
   const double t256 = 8.0 + ceil(tn * ((d.M + 255) / 256) / 256.0) * 30.0 * kk;
   const double t192 = 8.0 + ceil(tn * ((d.M + 191) / 192) / 256.0) * 23.5 * kk;
+  const double tbal = bal_ok ? bal_time(d) : 1e30;
   const double small_tiles = (double)((d.N + 127) / 128) * ((d.M + 127) / 128);
   const double t_small = 6.0 + ceil(small_tiles / 256.0) * 0.5 * 21.5 * kk;
-  const double t_big = t256 <= t192 ? t256 : t192;
+  double t_big = t256 <= t192 ? t256 : t192;
+  int which = t256 <= t192 ? 4 : 3;
+  if (tbal < 0.985 * t_big) { t_big = tbal; which = 8; }      // measured: fc1 94.5 vs 98.5 us (model 95.5 / 98), qkv 82 vs 74.5 (80.5 / 78.5)
   if (t_big >= 0.93 * t_small) return 0;
-  return t256 <= t192 ? 4 : 3;
+  return which;
 }
 
 template <int EPI, int AMODE = UD_A_DENSE>
 int launch_big(const UdGemm& d, hipStream_t s, int which) {
+  if constexpr (AMODE == UD_A_DENSE && (EPI == UD_EPI_F16 || EPI == UD_EPI_F32 || EPI == UD_EPI_QKV)) {
+    if (which == 8) return launch256bal<EPI>(d, s);
+  }
   return which == 3 ? launch256<3, EPI, AMODE>(d, s) : launch256<4, EPI, AMODE>(d, s);
 }
 
