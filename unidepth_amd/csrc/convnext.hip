@@ -82,27 +82,38 @@ __global__ __launch_bounds__(256, 2) void dwconv7_lds_kernel(const UdDwConv7 p) 
     }
   }
   const int c = cb + lane;
-  float wk[49];
+  f32x2 wk[25];                  // taps in register pairs: the packed FMA broadcasts either half (op_sel), no splat copies
 #pragma unroll
-  for (int k = 0; k < 49; ++k) wk[k] = p.w[(size_t)k * p.C + c];
+  for (int k = 0; k < 25; ++k) wk[k] = (f32x2){p.w[(size_t)(2 * k) * p.C + c], k < 24 ? p.w[(size_t)(2 * k + 1) * p.C + c] : 0.f};
   const float bv = p.bias ? p.bias[c] : 0.f;
   __syncthreads();
+  // two neighbouring outputs per packed fp32 FMA (v_pk_fma_f32: 56 per filter row instead of 112 scalar FMAs): output pair
+  // (2q, 2q+1) at tap kx needs the input pair starting at column 2q + kx -- an even-aligned pair pe[] for even kx, an odd-aligned
+  // one po[] for odd kx; both come straight from LDS (ds_read2st64_b32: two pixels of this lane's channel per read).  Per output
+  // the taps are still accumulated ky-major, kx ascending, one fused multiply-add each: the same bits as the scalar loop.
 #pragma unroll 1
   for (int rr = 0; rr < 2; ++rr) {
     const int r = wv * 2 + rr;
-    float acc[DW_TX];
+    f32x2 acc[DW_TX / 2];
 #pragma unroll
-    for (int o = 0; o < DW_TX; ++o) acc[o] = bv;
+    for (int o = 0; o < DW_TX / 2; ++o) acc[o] = (f32x2){bv, bv};
 #pragma unroll
     for (int ky = 0; ky < 7; ++ky) {
       const float* hrow = halo + (r + ky) * DW_HX * 64 + lane;
+      f32x2 pe[DW_HX / 2], po[DW_HX / 2 - 1];
 #pragma unroll
-      for (int j = 0; j < DW_HX; ++j) {
-        const float v = hrow[j * 64];
+      for (int i = 0; i < DW_HX / 2; ++i) pe[i] = (f32x2){hrow[(2 * i) * 64], hrow[(2 * i + 1) * 64]};
 #pragma unroll
-        for (int o = 0; o < DW_TX; ++o) {
-          const int kx = j - o;
-          if (kx >= 0 && kx < 7) acc[o] = fmaf(v, wk[ky * 7 + kx], acc[o]);
+      for (int i = 0; i < DW_HX / 2 - 1; ++i) po[i] = (f32x2){hrow[(2 * i + 1) * 64], hrow[(2 * i + 2) * 64]};
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) {
+        const f32x2 wp = wk[(ky * 7 + kx) >> 1];
+#pragma unroll
+        for (int q = 0; q < DW_TX / 2; ++q) {
+          const f32x2 v = (kx & 1) ? po[q + (kx >> 1)] : pe[q + (kx >> 1)];
+          // acc += v * broadcast(wp.lo | wp.hi): the tap is picked with op_sel (the compiler materialises a {w, w} pair per tap)
+          if ((ky * 7 + kx) & 1) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc[q]) : "v"(v), "v"(wp));
+          else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc[q]) : "v"(v), "v"(wp));
         }
       }
     }
@@ -111,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void dwconv7_lds_kernel(const UdDwConv7 p) 
       float* out = p.y + (((size_t)b * p.H + y) * p.W + x0) * p.ldy + c;
 #pragma unroll
       for (int o = 0; o < DW_TX; ++o)
-        if (x0 + o < p.W) out[(size_t)o * p.ldy] = acc[o];
+        if (x0 + o < p.W) out[(size_t)o * p.ldy] = acc[o >> 1][o & 1];
     }
   }
 }

@@ -1186,7 +1186,7 @@ int launch256bal(const UdGemm& d, hipStream_t s) {
 // small or just above a multiple of 256 CUs; the 128x128 kernel runs two workgroups per CU, so its rounds quantise in halves.
 // Returns 0 (128x128), 3 (192x256) or 4 (256x256).
 inline int pick_tiles(const UdGemm& d) {
-  if (d.amode == UD_A_CONV3_REFLECT || d.groups > 1 || d.M < 1024 || d.N < 256 || (d.K & 63)) return 0;
+  if (d.amode == UD_A_CONV3_REFLECT || d.groups > 1 || d.M < 1024 || d.N < 192 || (d.K & 63)) return 0;
   if (d.amode == UD_A_CONV3_ZERO && d.epi != UD_EPI_F16 && d.epi != UD_EPI_F32) return 0;
   {  // the large-tile loader addresses its operands with 32-bit byte offsets inside 2 GB buffer descriptors
     const double a_bytes = d.amode == UD_A_DENSE ? 2.0 * d.M * d.lda : 2.0 * ((double)(d.M / d.rows_img) + 1.0) * (double)d.img_stride;
