@@ -1202,7 +1202,9 @@ inline int pick_tiles(const UdGemm& d) {
   const double tn = (double)((d.N + 255) / 256);
   const double t256 = 8.0 + ceil(tn * ((d.M + 255) / 256) / 256.0) * 30.0 * kk;
   const double t192 = 8.0 + ceil(tn * ((d.M + 191) / 192) / 256.0) * 23.5 * kk;
-  const double tbal = bal_ok ? bal_time(d) : 1e30;
+  // a span of one tile per workgroup cannot finish earlier than the tile list does (proj / fc2 at bs = 8: 192 rows either way, and the
+  // MH = 4 instantiation measured 4 % slower there): the balanced schedule competes only when spans hold two or more tiles
+  const double tbal = (bal_ok && ((d.M + 63) / 64 + bal_cpc(d) - 1) / bal_cpc(d) > 4) ? bal_time(d) : 1e30;
   const double small_tiles = (double)((d.N + 127) / 128) * ((d.M + 127) / 128);
   const double t_small = 6.0 + ceil(small_tiles / 256.0) * 0.5 * 21.5 * kk;
   double t_big = t256 <= t192 ? t256 : t192;
