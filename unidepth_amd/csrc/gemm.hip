@@ -82,6 +82,16 @@ __device__ __forceinline__ float ud_act_t(float x) {
   else return x;
 }
 
+template <int ACT>
+__device__ __forceinline__ f32x4 ud_act4_t(f32x4 v) {      // GELU on packed fp32 pairs (same bits as the scalar function)
+  if constexpr (ACT == UD_ACT_GELU) {
+    const f32x2 g0 = ud_gelu_erf2((f32x2){v[0], v[1]}), g1 = ud_gelu_erf2((f32x2){v[2], v[3]});
+    return (f32x4){g0[0], g0[1], g1[0], g1[1]};
+  } else {
+    return (f32x4){ud_act_t<ACT>(v[0]), ud_act_t<ACT>(v[1]), ud_act_t<ACT>(v[2]), ud_act_t<ACT>(v[3])};
+  }
+}
+
 // ACT = activation of the fp16 output (EPI_F16/QKV) or of the fp16 copy (EPI_F32/D2S), resolved ONCE per kernel by
 // gemm_epilogue below: a per-element switch on the runtime value compiled to ~700 scalar branches in the unrolled epilogue.
 template <int TM, int TN, int EPI, bool SWAP, bool PRELOADED, int ACT, int TMA>
@@ -137,7 +147,7 @@ __device__ __forceinline__ void gemm_epilogue_impl(const UdGemm& p, f32x4 (&acc)
               }
               half4 h;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) h[r] = (half_t)ud_act_t<ACT>(v[r]);
+              for (int r = 0; r < 4; ++r) h[r] = (half_t)ud_act4_t<ACT>(v)[r];
               *(half4*)(stage + (il * 16 + (lane & 15)) * 144 + (j * 16 + 4 * (lane >> 4)) * 2) = h;
             }
           }
@@ -221,7 +231,7 @@ __device__ __forceinline__ void gemm_epilogue_impl(const UdGemm& p, f32x4 (&acc)
           if (out2) {
             half4 h;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = (half_t)ud_act_t<ACT>(v[r]);
+            for (int r = 0; r < 4; ++r) h[r] = (half_t)ud_act4_t<ACT>(v)[r];
             *(half4*)((half_t*)out2 + pix * p.ldc2 + o) = h;
           }
         }
@@ -243,7 +253,7 @@ __device__ __forceinline__ void gemm_epilogue_impl(const UdGemm& p, f32x4 (&acc)
         if constexpr (EPI == UD_EPI_F16 || EPI == UD_EPI_QKV) {
           half4 h;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) h[r] = (half_t)ud_act_t<ACT>(v[r]);
+          for (int r = 0; r < 4; ++r) h[r] = (half_t)ud_act4_t<ACT>(v)[r];
           *(half4*)((half_t*)out + (size_t)orow * p.ldc + nb) = h;
         } else if constexpr (EPI == UD_EPI_F32) {
           float* dst = (float*)out + (size_t)orow * p.ldc + nb;
@@ -254,8 +264,7 @@ __device__ __forceinline__ void gemm_epilogue_impl(const UdGemm& p, f32x4 (&acc)
             }
           }
           if (p.act == UD_ACT_GELU) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = ud_gelu_erf(v[r]);
+            v = ud_act4_t<UD_ACT_GELU>(v);
           } else if (p.act == UD_ACT_CLAMPEXP) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = ud_clampexp(v[r]);
@@ -264,7 +273,7 @@ __device__ __forceinline__ void gemm_epilogue_impl(const UdGemm& p, f32x4 (&acc)
           if (out2) {
             half4 h;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = (half_t)ud_act_t<ACT>(v[r]);
+            for (int r = 0; r < 4; ++r) h[r] = (half_t)ud_act4_t<ACT>(v)[r];
             *(half4*)((half_t*)out2 + (size_t)orow * p.ldc2 + nb) = h;
           }
         }
@@ -952,8 +961,14 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 const f32x4 v = acc[i][j] + bv[j];
-                w[j][0] = ud_pack2(ud_act_t<AC>(v[0]), ud_act_t<AC>(v[1]));
-                w[j][1] = ud_pack2(ud_act_t<AC>(v[2]), ud_act_t<AC>(v[3]));
+                if constexpr (AC == UD_ACT_GELU) {
+                  const f32x2 g0 = ud_gelu_erf2((f32x2){v[0], v[1]}), g1 = ud_gelu_erf2((f32x2){v[2], v[3]});
+                  w[j][0] = ud_pack2(g0[0], g0[1]);
+                  w[j][1] = ud_pack2(g1[0], g1[1]);
+                } else {
+                  w[j][0] = ud_pack2(ud_act_t<AC>(v[0]), ud_act_t<AC>(v[1]));
+                  w[j][1] = ud_pack2(ud_act_t<AC>(v[2]), ud_act_t<AC>(v[3]));
+                }
               }
 #pragma unroll
               for (int jp = 0; jp < 2; ++jp) {
