@@ -275,6 +275,8 @@ int ud_spatial_mean_f32(const float* x, float* out, int B, int HW, int C, int ld
  *                i = rows & 0x7fffffff, N, ldi, ldo, out_f32, rows >> 31
  *  ATTN_FEWQ     T <= 8 queries against Nk keys, ONE head of width D (camera head `aggregate`, decoder.py:94, layers/attention.py:81-165):
  *                a = q fp32 [B*T, D], b = kv fp16 [B*Nk, 2D] = [K | V], out fp32 [B*T, D].  i = B, T, Nk, D; f[0] = scale
+ *                c (optional) = fp32 scratch of B * ceil(Nk / 64) * T * (D + 2) floats: the keys are then processed in chunks of 64 by
+ *                separate workgroups and merged in a second launch (deterministic order)
  *  SEGMENT_MEAN  Nystrom landmark pooling (xformers AvgPool): fp16 [G, N, ldi] -> n segment means, fp16 out and optional fp32 out2.  i = G, N, C, n, ldi, ldo
  *  BMM           out[g] = f[1] * I + f[0] * a[g] b[g], small fp32 matrices (Newton-Schulz pseudo-inverse of xformers iterative_pinv).  i = G, M, N, K
  *  PINV_INIT     Z0 = K^T / max column sum (iterative_pinv initialisation).  i = G, n

@@ -170,6 +170,20 @@ def test_v1_softmax_fewq_segment_bmm_pinv(ops):
     ref = torch.softmax(q.view(B, T, D) @ kk.transpose(1, 2) * D ** -0.5, dim=-1) @ vv
     torch.cuda.synchronize()
     assert rel(o.view(B, T, D), ref) < 1e-5
+    # the same through key chunks of 64 + merge (scratch given): 1000 keys = 15 full chunks + one of 40
+    o2 = torch.zeros(B * T, D, device="cuda")
+    ws = torch.zeros(B * 16 * T * (D + 2), device="cuda")
+    ops.v1_op(L.UD_V1_ATTN_FEWQ, a=q, b=kv, c=ws, out=o2, i=(B, T, Nk, D), f=(D ** -0.5,))
+    torch.cuda.synchronize()
+    assert rel(o2.view(B, T, D), ref) < 1e-5
+    # batched fp32 matmul on the fp32 matrix pipe: odd shapes, alpha / diagonal term
+    for (G, M, N, K) in ((3, 128, 64, 128), (2, 100, 72, 50), (1, 33, 129, 17)):
+        a_ = torch.randn(G, M, K, generator=g).cuda(); b_ = torch.randn(G, K, N, generator=g).cuda()
+        c_ = torch.zeros(G, M, N, device="cuda")
+        ops.v1_op(L.UD_V1_BMM, a=a_, b=b_, out=c_, i=(G, M, N, K), f=(-0.5, 3.0))
+        torch.cuda.synchronize()
+        want = -0.5 * (a_.double() @ b_.double()) + 3.0 * torch.eye(M, N, device="cuda", dtype=torch.float64)
+        assert rel(c_.double(), want) < 1e-6
     # landmark pooling
     x = torch.randn(3, 1064, 256, generator=g).half().cuda()
     m16 = torch.zeros(3, 128, 256, dtype=torch.half, device="cuda"); m32 = torch.zeros(3, 128, 256, device="cuda")

@@ -68,24 +68,25 @@ __global__ __launch_bounds__(256, 2) void dwconv7_lds_kernel(const UdDwConv7 p) 
   const int t = blockIdx.x;
   const int x0 = (t % tx_n) * DW_TX, y0 = ((t / tx_n) % ty_n) * DW_TY, b = t / (tx_n * ty_n);
   const int cb = blockIdx.y * 64;
-  const float* img = p.x + (size_t)b * p.H * p.W * p.ldx + cb;
-  // ---- halo load: wave-instruction = 4 consecutive halo pixels x 64 channels
+  // ---- halo load by LDS-DMA: one wave instruction = 4 consecutive halo pixels x 64 channels = 1 KB, landing at wave-uniform base +
+  // lane * 16; pixels outside the image use an offset beyond the descriptor's range and arrive as zeros.  All ~20 loads of a wave are
+  // in flight together (the global_load -> VGPR -> ds_write version serialised them on the register round trip: 14 us per block).
   const int sub = lane >> 4, c4 = (lane & 15) * 4;
+  const ud_rsrc_t rs = ud_make_rsrc(p.x, (unsigned)((size_t)p.B * p.H * p.W * p.ldx * sizeof(float)));
   for (int i = wv; i < (DW_HY * DW_HX + 3) / 4; i += 4) {
     const int hp = i * 4 + sub;
-    if (hp < DW_HY * DW_HX) {
-      const int hy = hp / DW_HX, hx = hp - hy * DW_HX;
-      const int iy = y0 + hy - 3, ix = x0 + hx - 3;
-      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v = *(const f32x4*)(img + ((size_t)iy * p.W + ix) * p.ldx + c4);
-      *(f32x4*)(halo + hp * 64 + c4) = v;
-    }
+    const int hy = hp / DW_HX, hx = hp - hy * DW_HX;
+    const int iy = y0 + hy - 3, ix = x0 + hx - 3;
+    const bool ok = hp < DW_HY * DW_HX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    const unsigned off = ok ? (unsigned)(((((size_t)b * p.H + iy) * p.W + ix) * p.ldx + cb + c4) * sizeof(float)) : 0xfffffff0u;
+    ud_bufl16(rs, off, 0, halo + i * 256);
   }
   const int c = cb + lane;
   f32x2 wk[25];                  // taps in register pairs: the packed FMA broadcasts either half (op_sel), no splat copies
 #pragma unroll
   for (int k = 0; k < 25; ++k) wk[k] = (f32x2){p.w[(size_t)(2 * k) * p.C + c], k < 24 ? p.w[(size_t)(2 * k + 1) * p.C + c] : 0.f};
   const float bv = p.bias ? p.bias[c] : 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // two neighbouring outputs per packed fp32 FMA (v_pk_fma_f32: 56 per filter row instead of 112 scalar FMAs): output pair
   // (2q, 2q+1) at tap kx needs the input pair starting at column 2q + kx -- an even-aligned pair pe[] for even kx, an odd-aligned
@@ -232,7 +233,8 @@ extern "C" int ud_dwconv7_nhwc_f32(const UdDwConv7* desc, void* stream) {
     ud_set_error("ud_dwconv7_nhwc_f32: bad argument (C, ldx, ldy % 4 == 0)");
     return UD_ERR_BAD_ARG;
   }
-  if ((d.C & 63) == 0) {
+  // the LDS-tiled kernel addresses the image through one buffer descriptor (32-bit byte offsets)
+  if ((d.C & 63) == 0 && (double)d.B * d.H * d.W * d.ldx * 4.0 < 4294967000.0) {
     constexpr int lds = DW_HY * DW_HX * 64 * 4;
     static bool attr_set[UD_MAX_DEVICES];
     if (!ud_attr_once(attr_set)) {

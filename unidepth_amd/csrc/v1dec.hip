@@ -195,6 +195,92 @@ __global__ __launch_bounds__(256) void attention_fewq_kernel(const float* q, con
   }
 }
 
+// The same attention split over chunks of 64 keys (grid = chunks x images, all T queries per block): the one-block-per-query kernel
+// above walks its 1200 keys with one key row per THREAD (2 KB apart: uncoalesced) and runs 64 blocks -- 842 us at bs = 16 for 39 MB
+// of K|V.  Here a wave reads one key row per instruction (coalesced), every block leaves an un-normalised partial
+// (max, sum, sum p V) in `part`, and fewq_merge_kernel combines the partials in ascending chunk order (deterministic).
+constexpr int FQ_CHUNK = 64;
+__global__ __launch_bounds__(256) void fewq_partial_kernel(const float* q, const half_t* kv, float* part, int T, int Nk, int D, float scale) {
+  extern __shared__ float sm[];                         // T*D scaled queries | T x 64 scores / probabilities
+  float* qs = sm;
+  float* sc = sm + T * D;
+  const int c = blockIdx.x, b = blockIdx.y, NC = gridDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int i = tid; i < T * D; i += 256) qs[i] = q[(size_t)b * T * D + i] * scale;
+  __syncthreads();
+  const half_t* kb = kv + (size_t)b * Nk * 2 * D;
+  for (int i = 0; i < 16; ++i) {
+    const int kl = wv * 16 + i, k = c * FQ_CHUNK + kl;
+    float s[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) s[t] = 0.f;
+    if (k < Nk) {
+      for (int d0 = lane * 8; d0 < D; d0 += 512) {
+        const half8 h = *(const half8*)(kb + (size_t)k * 2 * D + d0);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          if (t < T) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[t] = fmaf((float)h[e], qs[t * D + d0 + e], s[t]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      if (t < T) {
+        const float v = ud_wave_sum(s[t]);
+        if (lane == 0) sc[t * FQ_CHUNK + kl] = k < Nk ? v : -__builtin_inff();
+      }
+    }
+  }
+  __syncthreads();
+  float* pb = part + ((size_t)b * NC + c) * T * (D + 2);
+  for (int t = wv; t < T; t += 4) {
+    const float v = sc[t * FQ_CHUNK + lane];
+    float m = v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    const float pexp = v == -__builtin_inff() ? 0.f : __expf(v - m);
+    const float l = ud_wave_sum(pexp);
+    sc[t * FQ_CHUNK + lane] = pexp;
+    if (lane == 0) { pb[(size_t)t * (D + 2) + D] = m; pb[(size_t)t * (D + 2) + D + 1] = l; }
+  }
+  __syncthreads();
+  const int kn = min(FQ_CHUNK, Nk - c * FQ_CHUNK);
+  for (int d = tid; d < D; d += 256) {
+    float acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = 0.f;
+    const half_t* vcol = kb + (size_t)(c * FQ_CHUNK) * 2 * D + D + d;
+    for (int k = 0; k < kn; ++k) {
+      const float v = (float)vcol[(size_t)k * 2 * D];
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (t < T) acc[t] = fmaf(sc[t * FQ_CHUNK + k], v, acc[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      if (t < T) pb[(size_t)t * (D + 2) + d] = acc[t];
+  }
+}
+
+__global__ __launch_bounds__(256) void fewq_merge_kernel(const float* part, float* out, int T, int NC, int D) {
+  const int t = blockIdx.x, b = blockIdx.y;
+  const float* pb = part + (size_t)b * NC * T * (D + 2) + (size_t)t * (D + 2);
+  const size_t cs = (size_t)T * (D + 2);
+  float M = -__builtin_inff();
+  for (int c = 0; c < NC; ++c) M = fmaxf(M, pb[c * cs + D]);
+  float L = 0.f;
+  for (int c = 0; c < NC; ++c) L = fmaf(pb[c * cs + D + 1], __expf(pb[c * cs + D] - M), L);
+  const float inv = 1.0f / L;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float acc = 0.f;
+    for (int c = 0; c < NC; ++c) acc = fmaf(pb[c * cs + d], __expf(pb[c * cs + D] - M), acc);
+    out[((size_t)b * T + t) * D + d] = acc * inv;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ Nystrom pieces
 // landmark pooling (xformers AvgPool): [G, N, C] fp16 -> n segment means per group, fp16 (GEMM operand) and fp32
 __global__ __launch_bounds__(256) void segment_mean_kernel(const half_t* in, half_t* out16, float* out32, int N, int C, int n, int ldi, int ldo) {
@@ -213,51 +299,60 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(const half_t* in, hal
 }
 
 // batched fp32 matmul of small square-ish matrices, C = diag * I + alpha * A B  (A [G, M, K], B [G, K, N], row-major, all <= 128):
-// the Newton-Schulz pseudo-inverse iterations (xformers iterative_pinv) and pinv @ kernel_3.
+// the Newton-Schulz pseudo-inverse iterations (xformers iterative_pinv) and pinv @ kernel_3.  On the fp32 matrix pipe:
+// v_mfma_f32_32x32x2_f32 multiplies and accumulates in fp32 exactly like the fmaf chain over ascending k that the first version of
+// this kernel ran on the VALU (15 TFLOP/s, 17.9 us per launch of 64 matrices of 128^3) -- same bits, a tenth of the issue slots.
+// 64 x 64 output tile per block, one 32 x 32 quadrant per wave, K in steps of 16 through LDS ([k][m] / [k][n]: lane = row or column).
+typedef __attribute__((ext_vector_type(16))) float f32x16v;
 __global__ __launch_bounds__(256) void bmm_small_kernel(const float* A, const float* Bm, float* Cm, int M, int N, int K, float alpha, float diag) {
-  // 64 x 64 output tile per block, 4 x 4 per thread, K in steps of 16 through LDS
-  __shared__ float as[16][68], bs[16][68];
+  // K in rounds of 64 (one round for the 128-landmark matrices' halves): the operands of round r + 1 are fetched into registers
+  // while round r multiplies, so a 128-deep product pays two memory latencies, not eight (K steps of 16 took 17.9 us per launch
+  // with either the VALU or the matrix pipe doing the arithmetic: the loop was a chain of load -> barrier -> multiply)
+  constexpr int KS = 64;
+  __shared__ float as[KS][65], bs[KS][65];           // stride 65: the transposing A write (lane = k) is bank-conflict free
   const int g = blockIdx.z, tid = threadIdx.x;
-  const int tx = tid & 15, ty = tid >> 4;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int wm = (wv >> 1) * 32, wn = (wv & 1) * 32;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
   const float* a = A + (size_t)g * M * K;
   const float* b = Bm + (size_t)g * K * N;
-  float acc[4][4];
+  f32x16v acc;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int kk = lane >> 5, rc = lane & 31;
+  float ra[16], rb[16];
+  auto fetch = [&](int k0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-  for (int k0 = 0; k0 < K; k0 += 16) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < 16; ++e) {
       const int idx = tid + e * 256;
-      const int am = idx >> 4, ak = idx & 15;                 // A tile: 64 rows x 16 k (k fastest: coalesced 64-byte runs)
-      as[ak][am] = (m0 + am < M && k0 + ak < K) ? a[(size_t)(m0 + am) * K + k0 + ak] : 0.f;
-      const int bk = idx >> 6, bn = idx & 63;                 // B tile: 16 k x 64 columns
-      bs[bk][bn] = (k0 + bk < K && n0 + bn < N) ? b[(size_t)(k0 + bk) * N + n0 + bn] : 0.f;
+      const int am = idx >> 6, ak = idx & 63;                 // A tile: 64 rows x 64 k (k fastest: coalesced 256-byte runs)
+      ra[e] = (m0 + am < M && k0 + ak < K) ? a[(size_t)(m0 + am) * K + k0 + ak] : 0.f;
+      const int bk = idx >> 6, bn = idx & 63;                 // B tile: 64 k x 64 columns
+      rb[e] = (k0 + bk < K && n0 + bn < N) ? b[(size_t)(k0 + bk) * N + n0 + bn] : 0.f;
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += KS) {
+    __syncthreads();                                          // the previous round's fragments have been consumed
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int idx = tid + e * 256;
+      as[idx & 63][idx >> 6] = ra[e];
+      bs[idx >> 6][idx & 63] = rb[e];
     }
     __syncthreads();
+    if (k0 + KS < K) fetch(k0 + KS);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      float av[4], bv[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) av[i] = as[k][ty * 4 + i];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bv[j] = bs[k][tx * 4 + j];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
-    }
-    __syncthreads();
+    for (int k = 0; k < KS; k += 2)                           // lanes 0-31 feed k, lanes 32-63 k + 1
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[k + kk][wm + rc], bs[k + kk][wn + rc], acc, 0, 0, 0);
   }
+  // accumulator register r of lane l: row 8 (r / 4) + 4 (l / 32) + r % 4, column l % 32 of the wave's quadrant
+  const int col = n0 + wn + rc;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = m0 + ty * 4 + i, col = n0 + tx * 4 + j;
-      if (row < M && col < N) Cm[((size_t)g * M + row) * N + col] = alpha * acc[i][j] + (row == col ? diag : 0.f);
-    }
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + wm + 8 * (r >> 2) + 4 * kk + (r & 3);
+    if (row < M && col < N) Cm[((size_t)g * M + row) * N + col] = alpha * acc[r] + (row == col ? diag : 0.f);
+  }
 }
 
 // Z0 = K^T / max_j sum_i K[i, j]  (xformers iterative_pinv, exact 1 / ||K||_1 initialisation), K fp32 [G, n, n], n <= 256.  Block = group.
@@ -423,6 +518,15 @@ extern "C" int ud_v1_op(const UdV1Op* desc, void* stream) {
     }
     case UD_V1_ATTN_FEWQ: {      // a = q fp32 [B*T, D], b = kv fp16 [B*Nk, 2D], out fp32 [B*T, D]; i = B, T, Nk, D; f[0] = scale
       if (!d.a || !d.b || !d.out || i[0] <= 0 || i[1] <= 0 || i[1] > 8 || i[2] <= 0 || (i[3] & 7)) break;
+      if (d.c) {                 // c = scratch fp32 [B * ceil(Nk / 64) * T * (D + 2)]: key-chunked partials + merge
+        const int nc = (i[2] + FQ_CHUNK - 1) / FQ_CHUNK;
+        const int lds2 = (i[1] * i[3] + i[1] * FQ_CHUNK) * 4;
+        if (lds2 > 64 * 1024) break;
+        hipLaunchKernelGGL(fewq_partial_kernel, dim3(nc, i[0]), dim3(256), lds2, s, (const float*)d.a, (const half_t*)d.b, (float*)d.c, i[1], i[2], i[3], d.f[0]);
+        hipLaunchKernelGGL(fewq_merge_kernel, dim3(i[1], i[0]), dim3(256), 0, s, (const float*)d.c, (float*)d.out, i[1], nc, i[3]);
+        UD_CHECK_LAUNCH("ud_v1_op(attn_fewq, chunked) launch");
+        return UD_OK;
+      }
       const int lds = (i[2] + i[3] + 8) * 4;
       if (lds > 64 * 1024) break;
       hipLaunchKernelGGL(attention_fewq_kernel, dim3(i[1], i[0]), dim3(256), lds, s, (const float*)d.a, (const half_t*)d.b, (float*)d.out, i[1], i[2], i[3], d.f[0]);

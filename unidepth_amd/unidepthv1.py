@@ -658,7 +658,8 @@ class _FullPlan:
             cq = z(Mc, C, dtype=f32); cao = z(Mc, C, dtype=f32)
             ln32(cls_t, cn)
             lin32(cn, "cam.agg.q", cq, C, C, add=w["cam.pos"], ldadd=C, add_mod=4)
-            P.v1(L.UD_V1_ATTN_FEWQ, a=cq, b=kvc, out=cao, i=(B, 4, Nc + 4, C), f=(C ** -0.5,), tag="cam.aggregate")
+            fq_ws = z(B * (-(-(Nc + 4) // 64)) * 4 * (C + 2), dtype=f32)      # key-chunk partials of the few-query attention
+            P.v1(L.UD_V1_ATTN_FEWQ, a=cq, b=kvc, c=fq_ws, out=cao, i=(B, 4, Nc + 4, C), f=(C ** -0.5,), tag="cam.aggregate")
             lin32(cao, "cam.agg.out", cls_t, C, C, accumulate=1)
             mlp32("cam.agg.", cls_t, cls_t, 1)
             ckv = z(Mc, 2 * C, dtype=f32)
