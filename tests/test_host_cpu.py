@@ -225,3 +225,35 @@ def test_product_library_has_no_debug_switches():
     from unidepth_amd import _lib
     lib = ctypes.CDLL(_lib.LIB_PATH)
     assert not hasattr(lib, "ud_set_debug_flags")
+
+
+def test_eval_ops_argument_checks_mirror_the_reference_and_refuse_cpu_tensors():
+    """knn_points / ChamferDistance / RandomPatchExtractor (unidepth_amd/eval_ops.py): the reference's ValueErrors
+    (functions/knn.py:170-173,70; chamfer_distance.py:16-30,49-53) and no CPU path."""
+    import pytest
+    import torch
+    from unidepth_amd import eval_ops
+    a = torch.zeros(1, 4, 3)
+    with pytest.raises(ValueError, match="same batch dimension"):
+        eval_ops.knn_points(a, torch.zeros(2, 4, 3))
+    with pytest.raises(ValueError, match="same point dimension"):
+        eval_ops.knn_points(a, torch.zeros(1, 4, 2))
+    with pytest.raises(ValueError, match="1 or 2 norm"):
+        eval_ops.knn_points(a, a, norm=3)
+    with pytest.raises(RuntimeError, match="GPU tensors"):
+        eval_ops.knn_points(a, a)
+    with pytest.raises(RuntimeError, match="GPU tensors"):
+        eval_ops.RandomPatchExtractor()(torch.zeros(1, 1, 8, 8), torch.zeros(1, 2, 2), (3, 3))
+    cd = eval_ops.ChamferDistance()
+    with pytest.raises(ValueError, match="batch_reduction"):
+        cd(a, a, batch_reduction="max")
+    with pytest.raises(ValueError, match="point_reduction"):
+        cd(a, a, point_reduction="max")
+    with pytest.raises(ValueError, match="shape"):
+        cd(torch.zeros(4, 3), a)
+    with pytest.raises(ValueError, match="lengths"):
+        cd(a, a, x_lengths=torch.zeros(2, dtype=torch.int64))
+    idx = torch.tensor([[[1, 0], [2, 2]]])
+    x = torch.arange(6.0).view(1, 3, 2)
+    g = eval_ops.knn_gather(x, idx, lengths=torch.tensor([1]))          # slots k >= length are zero (functions/knn.py:238-247)
+    assert torch.equal(g[0, :, 0], x[0, [1, 2]]) and float(g[0, :, 1].abs().sum()) == 0.0
