@@ -107,6 +107,44 @@ def reference_chamfer_class(knn_mod):
     return mod.ChamferDistance
 
 
+def eval3d_case_inputs(name: str):
+    """(gts, preds, masks, thresholds) of the 3-D metric golden cases: 'small' needs no resampling, 'resampled' has more than
+    240 * 320 valid points, so eval_3d shrinks the maps with nearest-exact first (evaluation_depth.py:164-172)."""
+    seed, B, H, W, keep = {"small": (31, 2, 48, 64, 0.8), "resampled": (32, 2, 260, 340, 0.7)}[name]
+    g = torch.Generator().manual_seed(seed)
+    z = 1.0 + 4.0 * torch.rand(B, 1, H, W, generator=g)
+    yy, xx = torch.meshgrid(torch.linspace(-0.6, 0.6, H), torch.linspace(-0.8, 0.8, W), indexing="ij")
+    gts = torch.cat([xx[None, None] * z, yy[None, None] * z, z], 1)
+    preds = gts * (1.0 + 0.03 * torch.randn(B, 3, H, W, generator=g)) + 0.01 * torch.randn(B, 3, H, W, generator=g)
+    masks = torch.rand(B, 1, H, W, generator=g) < keep
+    thresholds = [0.0025, 0.01, 0.04, 0.16]
+    return gts, preds, masks, thresholds
+
+
+EVAL3D_CASES = ["small", "resampled"]
+
+
+def reference_eval_3d(knn_mod):
+    """utils/evaluation_depth.py with its chamfer import satisfied by the reference chamfer over the compiled reference K-NN."""
+    import types
+    cham_cls = reference_chamfer_class(knn_mod)
+    mod = types.ModuleType("unidepth.utils.chamfer_distance")
+    mod.ChamferDistance = cham_cls
+    saved = {k: sys.modules.get(k) for k in ("unidepth", "unidepth.utils", "unidepth.utils.chamfer_distance")}
+    sys.modules.setdefault("unidepth", types.ModuleType("unidepth"))
+    sys.modules.setdefault("unidepth.utils", types.ModuleType("unidepth.utils"))
+    sys.modules["unidepth.utils.chamfer_distance"] = mod
+    try:
+        ev = _load_file("_ref_evaluation_depth", os.path.join(ref_loader.REF_ROOT, "unidepth", "utils", "evaluation_depth.py"))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return ev.eval_3d
+
+
 def reference_extract_patches():
     ref_loader._prepare()
     with warnings.catch_warnings():
@@ -129,6 +167,11 @@ def main():
     p1, p2, l1, l2, _, _ = knn_case_inputs("d3_k5_ragged")
     cx, cy, ix, iy = cham(p1, p2, x_lengths=l1, y_lengths=l2)
     out["chamfer.cx"], out["chamfer.cy"], out["chamfer.ix"], out["chamfer.iy"] = cx.numpy(), cy.numpy(), ix.numpy(), iy.numpy()
+    ev3d = reference_eval_3d(knn)
+    for name in EVAL3D_CASES:
+        gts, preds, masks, th = eval3d_case_inputs(name)
+        for k, v in ev3d(gts, preds, masks, th).items():
+            out[f"eval3d.{name}.{k}"] = v.numpy()
     np.savez_compressed(os.path.join(GOLDEN, "eval_knn.npz"), **out)
     ep = reference_extract_patches()
     out = {}

@@ -44,7 +44,10 @@ def knn_points(p1: np.ndarray, p2: np.ndarray, lengths1=None, lengths2=None, nor
             for d in range(D):
                 diff = q[:, d:d + 1] - b[None, :, d]
                 dist = dist + (diff * diff if norm == 2 else np.abs(diff))       # two roundings, like the scalar C loop
-            order = np.argsort(dist, axis=1, kind="stable")[:, :K]      # stable: ties -> lower index first
+            if K == 1:
+                order = np.argmin(dist, axis=1)[:, None]                 # first minimum = lowest index among ties
+            else:
+                order = np.argsort(dist, axis=1, kind="stable")[:, :K]   # stable: ties -> lower index first
             kk = order.shape[1]
             dists[n, s:s + q.shape[0], :kk] = np.take_along_axis(dist, order, 1)
             idx[n, s:s + q.shape[0], :kk] = order
@@ -97,3 +100,30 @@ def extract_patches(tensor: np.ndarray, centers: np.ndarray, patch_size) -> np.n
                     if 0 <= y < padded.shape[2] and 0 <= x < padded.shape[3]:
                         out[b, n, :, i, j] = padded[b, :, y, x]
     return out.reshape(B, C, N, ph, pw).astype(tensor.dtype if tensor.dtype.kind == "f" else np.float32)
+
+
+def f1_score(t1: np.ndarray, t2: np.ndarray, thresholds) -> np.float32:
+    """utils/evaluation_depth.py:74-91 (thresholds against SQUARED distances, as the reference compares them)."""
+    d1, d2, _, _ = chamfer(t1, t2)
+    pr = np.array([np.float32((d1 < th).sum()) / np.float32(d1.size) for th in thresholds], np.float32)
+    rc = np.array([np.float32((d2 < th).sum()) / np.float32(d2.size) for th in thresholds], np.float32)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        f1 = 2 * pr * rc / (pr + rc)
+    f1 = np.where(np.isnan(f1), np.float32(0), f1).astype(np.float32)
+    return np.float32(np.trapezoid(f1.astype(np.float64)) / len(thresholds))
+
+
+def eval_3d(gts, preds, masks, thresholds):
+    """utils/evaluation_depth.py:160-182 for inputs that need no resampling (masks.sum() <= 240 * 320): per image MSE_3d, chamfer
+    and F1 over the masked points, each reduced by .mean().  gts / preds [B,3,H,W] float32, masks [B,1,H,W] bool."""
+    assert masks.sum() <= 240 * 320, "resampling branch: covered by the golden vectors only"
+    out = {"MSE_3d": [], "chamfer": [], "F1": []}
+    for gt, pred, mask in zip(gts, preds, masks):
+        if not mask.any():
+            continue
+        m = mask[0]
+        g, p = gt[:, m], pred[:, m]                                     # [3, P]
+        out["MSE_3d"].append(np.sqrt(((g - p).astype(np.float32) ** 2).sum(0)).mean(dtype=np.float32))
+        out["chamfer"].append(chamfer_dist(g.T[None], p.T[None]).mean(dtype=np.float32))
+        out["F1"].append(f1_score(g.T[None], p.T[None], thresholds))
+    return {k: np.array(v, np.float32) for k, v in out.items()}

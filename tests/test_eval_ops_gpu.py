@@ -131,3 +131,23 @@ def test_patch_extractor_matches_restatement(cfg):
     assert out16.dtype == torch.float16
     if N:
         assert np.array_equal(out16.cpu().numpy(), re_.extract_patches(t.half().numpy(), c.half().numpy(), ps))
+
+
+@pytest.mark.parametrize("name", mg.EVAL3D_CASES)
+def test_eval_3d_matches_reference_golden(golden_dir, name):
+    """eval_3d (utils/evaluation_depth.py:160-182) end to end -- nearest-exact resampling to ~240 x 320 valid points, masked point
+    sets, chamfer and F1 through ud_knn_points -- against what the reference computed with its own K-NN."""
+    from unidepth_amd import eval_ops
+    g = np.load(os.path.join(golden_dir, "eval_knn.npz"))
+    gts, preds, masks, th = mg.eval3d_case_inputs(name)
+    out = eval_ops.eval_3d(gts.cuda(), preds.cuda(), masks.cuda(), th)
+    assert set(out) == {"MSE_3d", "chamfer", "F1"}
+    for k, v in out.items():
+        assert np.allclose(v.cpu().numpy(), g[f"eval3d.{name}.{k}"], rtol=5e-6, atol=0), (k, v, g[f"eval3d.{name}.{k}"])
+    p1, p2 = gts[0].reshape(3, -1).t()[None].cuda(), preds[0].reshape(3, -1).t()[None].cuda()
+    a = eval_ops.auc(p1, p2, th)                                       # evaluation_depth.py:21-34
+    d1, d2 = re_.chamfer(p1.cpu().numpy(), p2.cpu().numpy())[:2] if name == "small" else (None, None)
+    if d1 is not None:
+        pr = torch.tensor([(d1 < t).sum() / d1.size for t in th], dtype=torch.float32)
+        rc = torch.tensor([(d2 < t).sum() / d2.size for t in th], dtype=torch.float32)
+        assert abs(float(a) - float(torch.trapz(pr, rc))) < 1e-6

@@ -64,3 +64,12 @@ def test_knn_restatement_matches_live_reference_build():
         d, i = re_.knn_points(p1.numpy(), p2.numpy(), None, l2.numpy(), norm, K)
         assert np.array_equal(d, r.dists.numpy()) and np.array_equal(i, r.idx.numpy())
     assert os.path.exists(build_ref_knn.SO_PATH)
+
+
+def test_eval3d_restatement_matches_reference_golden(gknn):
+    """MSE_3d / chamfer / F1 of utils/evaluation_depth.py:160-182 run by the reference itself (no-resampling case)."""
+    gts, preds, masks, th = mg.eval3d_case_inputs("small")
+    out = re_.eval_3d(gts.numpy(), preds.numpy(), masks.numpy(), th)
+    for k in ("MSE_3d", "chamfer", "F1"):
+        assert np.allclose(out[k], gknn[f"eval3d.small.{k}"], rtol=2e-6, atol=0), k
+    assert out["F1"].min() > 0.3 and out["F1"].max() < 0.9          # thresholds straddle the error level: the metric is informative

@@ -2,6 +2,7 @@
 
     knn_points, knn_gather          unidepth/ops/knn/functions/knn.py:113-196, 199-249  (forward; the KNN extension)
     ChamferDistance, chamfer_dist   unidepth/utils/chamfer_distance.py:60-159, unidepth/utils/evaluation_depth.py:12-18
+    auc, f1_score, DICT_METRICS_3D, eval_3d   unidepth/utils/evaluation_depth.py:21-34,74-91,109-125,160-182 (the 3-D metrics)
     RandomPatchExtractor            unidepth/ops/extract_patches/modules/patch_extractor.py:10-42 (forward)
 
 Same names, argument meaning and error behaviour; inference / evaluation only (no autograd: the reference's backward kernels are
@@ -125,6 +126,55 @@ def chamfer_dist(tensor1: torch.Tensor, tensor2: torch.Tensor) -> torch.Tensor:
     """(sqrt(d(x->y)) + sqrt(d(y->x))) / 2 per point, clouds of equal size (utils/evaluation_depth.py:12-18)."""
     d1, d2, _, _ = ChamferDistance()(tensor1, tensor2)
     return (torch.sqrt(d1) + torch.sqrt(d2)) / 2
+
+
+def _precision_recall(tensor1, tensor2, thresholds):
+    d1, d2, _, _ = ChamferDistance()(tensor1, tensor2)
+    precisions = torch.stack([(d1 < th).sum() / d1.numel() for th in thresholds]).to(tensor1.device)
+    recalls = torch.stack([(d2 < th).sum() / d2.numel() for th in thresholds]).to(tensor1.device)
+    return precisions, recalls
+
+
+def auc(tensor1: torch.Tensor, tensor2: torch.Tensor, thresholds) -> torch.Tensor:
+    """Area under the precision(recall) curve over the distance thresholds (utils/evaluation_depth.py:21-34).  As in the reference the
+    thresholds are compared with SQUARED distances (what knn_points returns)."""
+    precisions, recalls = _precision_recall(tensor1, tensor2, thresholds)
+    return torch.trapz(precisions, recalls)
+
+
+def f1_score(tensor1: torch.Tensor, tensor2: torch.Tensor, thresholds) -> torch.Tensor:
+    """Mean over thresholds of F1 = 2 P R / (P + R) (0 where undefined), trapezoid rule (utils/evaluation_depth.py:74-91)."""
+    precisions, recalls = _precision_recall(tensor1, tensor2, thresholds)
+    f1 = 2 * precisions * recalls / (precisions + recalls)
+    f1 = torch.where(torch.isnan(f1), torch.zeros_like(f1), f1)
+    return torch.trapz(f1) / len(thresholds)
+
+
+DICT_METRICS_3D = {                  # utils/evaluation_depth.py:109-125; gt / pred: [3, P] point sets of one image
+    "MSE_3d": lambda gt, pred, thresholds: torch.norm(gt - pred, dim=0, p=2),
+    "chamfer": lambda gt, pred, thresholds: chamfer_dist(gt.unsqueeze(0).permute(0, 2, 1), pred.unsqueeze(0).permute(0, 2, 1)),
+    "F1": lambda gt, pred, thresholds: f1_score(gt.unsqueeze(0).permute(0, 2, 1), pred.unsqueeze(0).permute(0, 2, 1), thresholds=thresholds),
+}
+
+
+def eval_3d(gts: torch.Tensor, preds: torch.Tensor, masks: torch.Tensor, thresholds=None):
+    """3-D metrics of a batch of point maps [B,3,H,W] under validity masks [B,1,H,W] (utils/evaluation_depth.py:160-182): maps are
+    nearest-exact resampled so that about 240 x 320 valid points remain per batch, then per image MSE_3d, chamfer and F1 on the
+    masked points.  The nearest-neighbour searches run in ud_knn_points."""
+    import torch.nn.functional as F
+    from collections import defaultdict
+    summary = defaultdict(list)
+    ratio = min(1.0, float((240 * 320 / masks.sum()) ** 0.5))
+    h_max, w_max = int(gts.shape[-2] * ratio), int(gts.shape[-1] * ratio)
+    gts = F.interpolate(gts, size=(h_max, w_max), mode="nearest-exact")
+    preds = F.interpolate(preds, size=(h_max, w_max), mode="nearest-exact")
+    masks = F.interpolate(masks.float(), size=(h_max, w_max), mode="nearest-exact").bool()
+    for gt, pred, mask in zip(gts, preds, masks):
+        if not torch.any(mask):
+            continue
+        for name, fn in DICT_METRICS_3D.items():
+            summary[name].append(fn(gt[:, mask.squeeze()], pred[:, mask.squeeze()], thresholds).mean())
+    return {name: torch.stack(vals, dim=0) for name, vals in summary.items()}
 
 
 class RandomPatchExtractor(torch.nn.Module):
