@@ -60,30 +60,30 @@ def knn_points(p1: torch.Tensor, p2: torch.Tensor, lengths1: Union[torch.Tensor,
 
 
 def knn_gather(x: torch.Tensor, idx: torch.Tensor, lengths: Union[torch.Tensor, None] = None) -> torch.Tensor:
-    """x_out[n, l, k] = x[n, idx[n, l, k]], zero where k >= lengths[n] (functions/knn.py:199-249).  Plain indexing: no kernel of ours."""
-    N, M, U = x.shape
-    _N, L, K = idx.shape
-    if N != _N:
+    """x_out[n, l, k] = x[n, idx[n, l, k]] for features x [N, M, U] and neighbour indices idx [N, L, K]; slots k >= lengths[n] (clouds
+    with fewer than K points) are zero (functions/knn.py:199-249).  Plain indexing: no kernel of ours."""
+    if x.shape[0] != idx.shape[0]:
         raise ValueError("x and idx must have same batch dimension.")
-    if lengths is None:
-        lengths = torch.full((N,), M, dtype=torch.int64, device=x.device)
-    x_out = x[:, :, None].expand(-1, -1, K, -1).gather(1, idx[:, :, :, None].expand(-1, -1, -1, U))
-    if lengths.min() < K:
-        mask = lengths[:, None] <= torch.arange(K, device=x.device)[None]
-        x_out[mask[:, None].expand(-1, L, -1)[:, :, :, None].expand(-1, -1, -1, U)] = 0.0
+    N, K = idx.shape[0], idx.shape[2]
+    batch = torch.arange(N, device=x.device).view(N, 1, 1)
+    x_out = x[batch, idx]                                              # [N, L, K, U]
+    if lengths is not None:
+        dead = torch.arange(K, device=x.device).view(1, 1, K) >= lengths.to(x.device).view(N, 1, 1)
+        x_out = x_out.masked_fill(dead.unsqueeze(-1), 0.0)
     return x_out
 
 
-def _handle_pointcloud_input(points, lengths, normals):
+def _check_cloud(points: torch.Tensor, lengths: Optional[torch.Tensor], normals: Optional[torch.Tensor]) -> torch.Tensor:
+    """Shape checks of one side of the Chamfer inputs (chamfer_distance.py:33-57); returns the lengths (full clouds when None)."""
     if points.ndim != 3:
         raise ValueError("Expected points to be of shape (N, P, D)")
-    if lengths is not None and (lengths.ndim != 1 or lengths.shape[0] != points.shape[0]):
-        raise ValueError("Expected lengths to be of shape (N,)")
     if lengths is None:
         lengths = torch.full((points.shape[0],), points.shape[1], dtype=torch.int64, device=points.device)
+    elif lengths.ndim != 1 or lengths.shape[0] != points.shape[0]:
+        raise ValueError("Expected lengths to be of shape (N,)")
     if normals is not None and normals.ndim != 3:
         raise ValueError("Expected normals to be of shape (N, P, 3")
-    return points, lengths, normals
+    return lengths
 
 
 class ChamferDistance(torch.nn.Module):
@@ -97,21 +97,19 @@ class ChamferDistance(torch.nn.Module):
             raise ValueError('batch_reduction must be one of ["mean", "sum"] or None')
         if point_reduction not in ["mean", "sum"]:
             raise ValueError('point_reduction must be one of ["mean", "sum"]')
-        x, x_lengths, x_normals = _handle_pointcloud_input(x, x_lengths, x_normals)
-        y, y_lengths, y_normals = _handle_pointcloud_input(y, y_lengths, y_normals)
-        N, P1, D = x.shape
-        P2 = y.shape[1]
-        if y.shape[0] != N or y.shape[2] != D:
+        x_lengths = _check_cloud(x, x_lengths, x_normals)
+        y_lengths = _check_cloud(y, y_lengths, y_normals)
+        N = x.shape[0]
+        if y.shape[0] != N or y.shape[2] != x.shape[2]:
             raise ValueError("y does not have the correct shape.")
         if weights is not None:
             if weights.size(0) != N:
                 raise ValueError("weights must be of shape (N,).")
-            if not (weights >= 0).all():
+            if bool((weights < 0).any()):
                 raise ValueError("weights cannot be negative.")
-            if weights.sum() == 0.0:
-                weights = weights.view(N, 1)
-                z = (x.sum((1, 2)) * weights)
-                return (z.sum() * 0.0, z.sum() * 0.0) if batch_reduction in ["mean", "sum"] else (z * 0.0, z * 0.0)
+            if float(weights.sum()) == 0.0:                      # all-zero weights: the reference returns zeros shaped by the reduction
+                zero = (x.sum((1, 2)) * weights.view(N)) * 0.0
+                return (zero.sum(), zero.sum()) if batch_reduction in ("mean", "sum") else (zero.view(N, 1), zero.view(N, 1))
         x_nn = knn_points(x, y, lengths1=x_lengths, lengths2=y_lengths, K=1)       # rows beyond a length are already zero
         y_nn = knn_points(y, x, lengths1=y_lengths, lengths2=x_lengths, K=1)
         cham_x = x_nn.dists[..., 0]
