@@ -257,3 +257,20 @@ def test_eval_ops_argument_checks_mirror_the_reference_and_refuse_cpu_tensors():
     x = torch.arange(6.0).view(1, 3, 2)
     g = eval_ops.knn_gather(x, idx, lengths=torch.tensor([1]))          # slots k >= length are zero (functions/knn.py:238-247)
     assert torch.equal(g[0, :, 0], x[0, [1, 2]]) and float(g[0, :, 1].abs().sum()) == 0.0
+
+
+def test_v1_host_shape_policy_and_position_embedding_match_the_oracle():
+    """UniDepthV1's integer shape policy (unidepthv1.py:29-47 _paddings / _shapes) and the sine position embedding constant
+    (layers/positional_encoding.py:14-57) on the engine's host side vs the restatement that is pinned on the reference."""
+    import torch
+    from oracle import restate_v1
+    from unidepth_amd import unidepthv1 as v1
+    for img in ((480, 640), (200, 360), (240, 320), (375, 1242), (1080, 1920), (500, 333), (31, 977), (462, 616)):
+        for net in ((462, 616), (480, 640)):
+            a, b = v1.v1_shapes(img, net), restate_v1.v1_shapes(img, net)
+            assert a[0] == b[0] and a[2] == b[2] and abs(a[1] - b[1]) < 1e-12, (img, net, a, b)
+            (nh, nw), _, (pl, pr, pt, pb) = a
+            assert nh + pt + pb == net[0] and nw + pl + pr == net[1] and min(pl, pr, pt, pb) >= 0
+    for (h, w, npf) in ((30, 40, 256), (29, 39, 256), (15, 20, 64)):
+        a, b = v1.pos_embed_sine(h, w, npf), restate_v1.pos_embed_sine(h, w, npf)
+        assert a.shape == b.shape and torch.allclose(a.reshape(-1), b.reshape(-1), atol=1e-6, rtol=0)
