@@ -11,7 +11,8 @@ qk = torch.randn(B * Np, 2 * D, generator=g).half().cuda()
 vt = torch.randn(B, H, 64, kvld, generator=g).half().cuda()
 o = torch.zeros(B * Np, D, dtype=torch.half, device="cuda")
 P = ops.Program()
-P.attention(Q=qk, K=qk.data_ptr() + D * 2, Vt=vt, O=o, B=B, H=H, Nq=N, Nk=N, ldq=2 * D, ldk=2 * D, ldo=D, kv_ld=kvld, q_rows_per_img=Np, k_rows_per_img=Np, scale=0.125)
+P.attention(Q=qk, K=qk.data_ptr() + D * 2, Vt=vt, O=o, B=B, H=H, Nq=N, Nk=N, ldq=2 * D, ldk=2 * D, ldo=D, kv_ld=kvld, q_rows_per_img=Np, k_rows_per_img=Np, scale=0.125,
+            q_prescaled=int(os.environ.get("UD_ATTN_PRE", "1")))     # 1 = the engine's default: scale * log2(e) already folded into Q
 for _ in range(3): P.run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
