@@ -35,6 +35,10 @@ def main():
     out["knn_ms"] = round(ms, 3)
     out["pairs_per_s"] = round(P * P / ms * 1e3, 0)
     out["valu_tflops"] = round(P * P * 8 / ms * 1e3 / 1e12, 2)          # 3 sub + 3 mul + 2 add per pair (compare/select not counted)
+    # the kernel is bound by the fp32 vector pipe; its arithmetic may not be fused (bit-exact distances), so the ceiling is the packed
+    # NON-FMA rate: half of the 157.3 TFLOP/s packed-FMA vector peak (MI355X_MICROARCH.md)
+    out["roofline"] = {"bound": "valu_f32", "achieved": out["valu_tflops"], "peak": 78.6, "unit": "TFLOP/s (fp32 add/mul, no FMA)",
+                       "frac": round(out["valu_tflops"] / 78.6, 3), "flop_per_launch": 8.0 * P * P, "avg_launch_us": round(ms * 1e3, 1)}
     out["chamfer_ms"] = round(gpu_ms(lambda: eval_ops.chamfer_dist(xd, yd)), 3)
     for K in (4, 8):
         out[f"knn_k{K}_ms"] = round(gpu_ms(lambda: eval_ops.knn_points(xd, yd, K=K), 3), 3)
