@@ -13,6 +13,7 @@ from __future__ import annotations
 import json
 import math
 import os
+from collections import OrderedDict
 from typing import List, Optional
 
 import torch
@@ -277,7 +278,8 @@ class UniDepthV1:
         self._sd = None
         self._w = None
         self._device = torch.device("cpu")
-        self._plans: dict = {}
+        self._plans = OrderedDict()                 # LRU: a plan owns all activation buffers of its signature (same policy as UniDepthV2)
+        self.max_plans = max(1, int(os.environ.get("UNIDEPTH_MAX_PLANS", "4")))
 
     # ---- checkpoint I/O (same HF layout as V2) ----
     @classmethod
@@ -349,10 +351,11 @@ class UniDepthV1:
     def _enc_plan(self, B, Hn, Wn) -> _EncPlan:
         key = ("enc", B, Hn, Wn)
         if key not in self._plans:
-            while len(self._plans) >= 4:
-                self._plans.pop(next(iter(self._plans)))
+            while len(self._plans) >= self.max_plans:
+                self._plans.popitem(last=False)
             with torch.cuda.device(self._device):
                 self._plans[key] = _EncPlan(self, B, Hn, Wn)
+        self._plans.move_to_end(key)
         return self._plans[key]
 
     # ---- encoder seam (backbones/convnext.py:447-458) ----
@@ -419,11 +422,16 @@ class UniDepthV1:
     def _full_plan(self, *sig) -> "_FullPlan":
         key = ("full",) + tuple(sig)
         if key not in self._plans:
-            while len(self._plans) >= 3:
-                self._plans.pop(next(iter(self._plans)))
+            while len(self._plans) >= self.max_plans:
+                self._plans.popitem(last=False)
             with torch.cuda.device(self._device):
                 self._plans[key] = _FullPlan(self, *sig)
+        self._plans.move_to_end(key)
         return self._plans[key]
+
+    def clear_plans(self) -> None:
+        """Drop every cached launch program and its activation buffers (they are rebuilt on the next call)."""
+        self._plans.clear()
 
     @torch.no_grad()
     def infer(self, rgbs: torch.Tensor, intrinsics=None, skip_camera: bool = False):
