@@ -37,7 +37,8 @@ def test_chamfer_matches_reference_golden(golden_dir):
 
 
 @pytest.mark.parametrize("shape", [(1, 5000, 7000, 3, 1, 2), (2, 300, 20000, 3, 1, 2), (1, 1000, 3000, 3, 8, 2), (2, 257, 1025, 4, 2, 1),
-                                   (1, 500, 900, 7, 16, 2), (1, 300, 600, 20, 3, 2), (1, 100, 5000, 3, 32, 2)])
+                                   (1, 500, 900, 7, 16, 2), (1, 300, 600, 20, 3, 2), (1, 100, 5000, 3, 32, 2),
+                                   (1, 200, 300, 32, 2, 2), (2, 100, 1000, 1, 1, 2), (1, 64, 700, 9, 1, 1), (3, 1, 1, 3, 1, 2)])
 def test_knn_points_matches_restatement_at_larger_sizes(shape):
     """Includes the K = 1 path that splits P2 across blocks (small P1, large P2) and merges through the packed atomic."""
     from unidepth_amd import eval_ops
