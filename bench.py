@@ -40,6 +40,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0      # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARCH.md
+# what the matrix pipes SUSTAIN on random fp16 operands (power / clock limited): the MFMA-only instruction stream of tools/ubench/gemm4w,
+# 1462 TFLOP/s with random operands vs 2118 with constant ones (profiles/r02_mfma_attainable.txt).  Reported beside the datasheet fraction.
+MFMA_ATTAINABLE_TFLOPS = 1460.0
 HBM_PEAK_GBS = 8000.0
 
 
@@ -309,11 +312,14 @@ def kernel_timing(torch, model, fl, B, dump=""):
         "roofline": {"bound": "mfma", "kernel": dom + " (v_mfma_f32_16x16x32_f16)",
                      "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                     "attainable_peak_random_operands": MFMA_ATTAINABLE_TFLOPS, "frac_of_attainable": round(achieved / MFMA_ATTAINABLE_TFLOPS, 4),
+                     "attainable_source": "profiles/r02_mfma_attainable.txt (MFMA-only stream, random fp16 operands, power-limited clocks)",
                      "flop_per_launch": round(d["flops"] / d["launches"], 1),
                      "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 3),
                      "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"], 1)},
         "roofline_enc_attention_mlp": {"achieved": round(enc_fl / (enc_ms * 1e-3) / 1e12, 2), "peak": MFMA_PEAK_TFLOPS,
                                        "unit": "TFLOP/s", "frac": round(enc_fl / (enc_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                       "frac_of_attainable": round(enc_fl / (enc_ms * 1e-3) / 1e12 / MFMA_ATTAINABLE_TFLOPS, 4),
                                        "ms_per_step": round(enc_ms, 4)},
         "kernel_breakdown": breakdown,
     }
