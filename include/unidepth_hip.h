@@ -93,6 +93,15 @@ typedef struct UdGemm {
   void* splitk_ws;
   void* splitk_cnt;
   int Hsrc, Wsrc;              /* UD_A_CONV3_REFLECT_UP: size of the low-resolution source image */
+  /* Split-fp16 products by K concatenation (no second kernel): the reduction index may run PAST the stored width of one operand and
+   * wraps around once.  Dense A: a_wrap = stored columns of A (multiple of 64), column k of the product reads A[:, k - a_wrap] for
+   * k >= a_wrap; conv A-modes: a_wrap = stored channels per pixel (multiple of 8), `Cin` = channels the K index is decoded with
+   * (e.g. 2 * a_wrap), channel c >= a_wrap reads channel c - a_wrap.  w_wrap: the same for W (dense A only).  0 = no wrap.
+   * Use: W' = [W_hi | W_lo] (W_lo = fp16(W - W_hi), packed once at load time), K' = 2 K, a_wrap = K gives A W_hi^T + A W_lo^T = A W^T
+   * with W exact to ~22 bits -- the weights' fp16 rounding is a SYSTEMATIC perturbation of the model (it shifts the predicted camera
+   * and the log-depth of every pixel coherently; tools/v1_precision_study.py), unlike the activations' rounding which averages out.
+   * Three terms [A_hi | A_lo | A_hi] x [W_hi | W_hi | W_lo] (a_wrap = 2 K) give an fp32-class product. */
+  int a_wrap, w_wrap;
 } UdGemm;
 
 int ud_gemm_f16(const UdGemm* desc, void* stream);

@@ -394,6 +394,85 @@ def test_gemm_conv3x3_big_tiles(ops, hint, Cin, Cout, H, W):
     assert rel(l16.view(B, rows_img, Cout)[:, :H * W].float(), F.leaky_relu(want, 0.01)) < 1e-3
 
 
+def _split16(w):
+    hi = w.half()
+    return hi, (w - hi.float()).half()
+
+
+@pytest.mark.parametrize("M,N,K,hint", [(300, 128, 64, 0), (1000, 384, 320, 0), (5000, 1024, 1024, 0), (2600, 1024, 2048, 3), (3000, 1152, 384, 2),
+                                           (11000, 1024, 256, 8), (256, 512, 1024, 7), (200, 256, 512, 6), (1000, 64, 192, 0), (900, 4, 128, 0)])
+def test_gemm_split_weights_by_k_wrap(ops, M, N, K, hint):
+    """UdGemm.a_wrap: W' = [W_hi | W_lo] along K, A read twice -> A W_hi^T + A W_lo^T in one fp32 accumulator.  With fp16-exact
+    activations the result must agree with the fp32 weights to fp32 accuracy (no trace of the weights' fp16 rounding), in every
+    kernel family (128-row 2-stage / 4-stage ring / K split across CUs, 192/256-row persistent, row-balanced)."""
+    A = rnd(M, K, seed=1).half()
+    W = rnd(N, K, scale=K ** -0.5, seed=2)
+    hi, lo = _split16(W)
+    Ws = torch.cat([hi, lo], dim=1).contiguous()
+    bias = rnd(N, seed=3)
+    ref = (A.double() @ W.double().t() + bias.double()).float()
+    out = torch.zeros(M, N, device="cuda")
+    kw = dict(A=A, W=Ws, bias=bias, out=out, M=M, N=N, K=2 * K, lda=K, ldw=2 * K, ldc=N, epi=ops.UD_EPI_F32, tile_hint=hint, a_wrap=K)
+    if hint == 7:
+        kw.update(splitk_ws=torch.empty(256 * 16384, device="cuda"), splitk_cnt=torch.zeros(128, dtype=torch.int32, device="cuda"))
+    ops.gemm(**kw)
+    torch.cuda.synchronize()
+    assert rel(out, ref) < 3e-6, rel(out, ref)
+    single = torch.zeros(M, N, device="cuda")
+    ops.gemm(A=A, W=hi.contiguous(), bias=bias, out=single, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, epi=ops.UD_EPI_F32, tile_hint=0 if hint == 7 else hint)
+    torch.cuda.synchronize()
+    assert rel(single, ref) > 20 * rel(out, ref)          # the single-term product carries the weights' rounding (~2e-4)
+
+
+def test_gemm_split_weights_as_a_operand(ops):
+    """UdGemm.w_wrap: the packed weight is the A operand (V^T = W_v X^T, grouped over images), the activations wrap around."""
+    G, C, Nk, K = 3, 128, 200, 256
+    Wv = rnd(C, K, scale=K ** -0.5, seed=2)
+    hi, lo = _split16(Wv)
+    Ws = torch.cat([hi, lo], dim=1).contiguous()
+    X = rnd(G, Nk, K, seed=1).half()
+    Nkp = 256
+    vt = torch.zeros(G, C, Nkp, dtype=torch.half, device="cuda")
+    ops.gemm(A=Ws, W=X, out=vt, M=C, N=Nk, K=2 * K, lda=2 * K, ldw=K, ldc=Nkp, epi=ops.UD_EPI_F16, groups=G, gA=0, gW=Nk * K, gOut=C * Nkp, w_wrap=K)
+    ref = torch.einsum("ck,gnk->gcn", Wv.double(), X.double()).float()
+    torch.cuda.synchronize()
+    assert rel(vt[..., :Nk].float(), ref) < 4e-4           # fp16 output rounding only (2^-12 rms)
+    assert (vt[..., Nk:] == 0).all()
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W,hint", [(64, 128, 9, 11, 0), (64, 64, 20, 17, 0), (128, 256, 30, 41, 2), (64, 4, 24, 31, 0), (256, 256, 20, 20, 3)])
+def test_gemm_conv3x3_split_weights(ops, Cin, Cout, H, W, hint):
+    """3x3 implicit GEMM with split weights: per tap [W_hi(Cin) | W_lo(Cin)], K decoded with 2 Cin channels, channels >= Cin wrap."""
+    B = 2
+    rows_img = ((H * W + 7) // 8) * 8
+    x = rnd(B, rows_img, Cin, seed=1).half()
+    wt = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=2)
+    bias = rnd(Cout, seed=3)
+    r = wt.permute(0, 2, 3, 1).reshape(Cout, 9, Cin)
+    hi, lo = _split16(r)
+    Wg = torch.cat([hi, lo], dim=2).reshape(Cout, 18 * Cin).contiguous()
+    zeros = torch.zeros(256, dtype=torch.half, device="cuda")
+    M = B * rows_img
+    out = torch.zeros(M, Cout, device="cuda")
+    ops.gemm(A=x, W=Wg, bias=bias, out=out, zeros=zeros, M=M, N=Cout, K=18 * Cin, ldw=18 * Cin, ldc=Cout, amode=ops.UD_A_CONV3_ZERO, epi=ops.UD_EPI_F32,
+             Himg=H, Wimg=W, Cin=2 * Cin, cstride=Cin, coff=0, rows_img=rows_img, img_stride=rows_img * Cin, tile_hint=hint, a_wrap=Cin)
+    xin = x[:, :H * W].double().view(B, H, W, Cin).permute(0, 3, 1, 2)
+    ref = F.conv2d(xin, wt.double(), bias.double(), padding=1).permute(0, 2, 3, 1).reshape(B, H * W, Cout).float()
+    torch.cuda.synchronize()
+    assert rel(out.view(B, rows_img, Cout)[:, :H * W], ref) < 3e-6
+
+
+def test_gemm_wrap_rejects_bad_arguments(ops):
+    A = rnd(128, 64, seed=1).half(); W = rnd(128, 128, seed=2).half(); out = torch.zeros(128, 128, device="cuda")
+    base = dict(A=A, W=W, out=out, M=128, N=128, K=128, lda=64, ldw=128, ldc=128, epi=ops.UD_EPI_F32)
+    for bad in (dict(a_wrap=32), dict(a_wrap=64, w_wrap=64), dict(a_wrap=-64), dict(w_wrap=32)):
+        with pytest.raises(RuntimeError):
+            ops.gemm(**base, **bad)
+    base["K"] = 192
+    with pytest.raises(RuntimeError):                      # one wrap only: 2 * a_wrap >= K
+        ops.gemm(**dict(base, ldw=192, W=rnd(128, 192, seed=2).half()), a_wrap=64)
+
+
 @pytest.mark.parametrize("k", [1, 2, 4])
 def test_gemm_d2s_convtranspose(ops, k):
     B, Hin, Win, Cin, Co = 2, 5, 7, 64, 64

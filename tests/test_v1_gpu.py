@@ -232,7 +232,7 @@ def test_v1_preprocess_points_camera(ops):
 
 
 # ------------------------------------------------------------------------------------------- whole UniDepthV1.infer()
-def _v1_check(out, ref, tag, bar=2e-3):
+def _v1_check(out, ref, tag, bar=1e-3):
     o = {k: v.float().cpu() for k, v in out.items()}
     st = {"depth": ((o["depth"] - ref["depth"]).abs() / ref["depth"].abs().clamp_min(1e-6)).mean().item(),
           "K": ((o["intrinsics"] - ref["intrinsics"]).abs() / ref["intrinsics"].abs().clamp_min(1.0)).max().item(),
@@ -262,6 +262,29 @@ def test_v1_infer_vs_oracle(B, H, W, withK, skip):
     out2 = model.infer(rgb.cuda(), K, skip_camera=skip)
     for k in out:
         assert torch.equal(out[k], out2[k]), k
+
+
+def test_v1_infer_config4_bs16_vs_oracle():
+    """BASELINE.json configs[3] at its stated batch: 16 images of 640x480 in one call, every image against the fp32 oracle at the
+    north-star bar (depth ARel <= 1e-3 per image, not only on the batch mean)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from unidepth_amd import UniDepthV1
+    cfg = synth_v1.load_config_v1()
+    sd = synth_v1.make_synthetic_checkpoint_v1(cfg, 211)
+    rgb = torch.randint(0, 256, (16, 3, 480, 640), dtype=torch.uint8, generator=torch.Generator().manual_seed(9))
+    model = UniDepthV1(cfg).load_state_dict(sd).to("cuda").eval()
+    out = model.infer(rgb.cuda())
+    torch.cuda.synchronize()
+    orc = restate_v1.OracleV1(cfg, sd)
+    worst = 0.0
+    for i in range(0, 16, 4):                                  # the oracle in chunks of 4 images (memory / time on the host)
+        ref = orc.infer(rgb[i:i + 4])
+        d = ((out["depth"][i:i + 4].cpu() - ref["depth"]).abs() / ref["depth"].abs().clamp_min(1e-6)).mean(dim=(1, 2, 3))
+        k = ((out["intrinsics"][i:i + 4].cpu() - ref["intrinsics"]).abs() / ref["intrinsics"].abs().clamp_min(1.0)).amax(dim=(1, 2))
+        worst = max(worst, float(d.max()))
+        assert float(d.max()) <= 1e-3 and float(k.max()) <= 1e-3, (i, d.tolist(), k.tolist())
+    print(f"v1 config4 bs=16 640x480: worst per-image depth ARel {worst:.2e}")
 
 
 def test_v1_decoder_taps_vs_oracle():

@@ -31,7 +31,7 @@ class UdGemm(C.Structure):
         ("groups", i32),
         ("gA", i64), ("gW", i64), ("gBias", i64), ("gOut", i64), ("gOut2", i64), ("gW2", i64),
         ("b2_g1", f32), ("post_add_g1", f32), ("tile_hint", i32),
-        ("splitk_ws", vp), ("splitk_cnt", vp), ("Hsrc", i32), ("Wsrc", i32),
+        ("splitk_ws", vp), ("splitk_cnt", vp), ("Hsrc", i32), ("Wsrc", i32), ("a_wrap", i32), ("w_wrap", i32),
     ]
 
 
@@ -171,6 +171,10 @@ def _load():
     lib.ud_last_error.argtypes = []
     lib.ud_last_error.restype = C.c_char_p
     for i, st in enumerate([UdGemm, UdLayerNorm, UdAttention, UdPreprocess, UdRayEmbed, UdUpsample2x, UdResizeAC, UdFinalize, UdLinearF32, UdDwConv7, UdV1Op, UdKnn, UdExtractPatches]):
+        # UNIDEPTH_HIP_LIB_ALLOW_OLDER (tools/ab_bench.sh only): an older build passed via UNIDEPTH_HIP_LIB may know a PREFIX of a descriptor
+        # (fields are only ever appended); anything else is a hard error
+        if os.environ.get("UNIDEPTH_HIP_LIB_ALLOW_OLDER") and "UNIDEPTH_HIP_LIB" in os.environ and 0 < lib.ud_struct_size(i) <= C.sizeof(st):
+            continue
         if lib.ud_struct_size(i) != C.sizeof(st):
             raise ImportError(f"ctypes mirror of {st.__name__} is out of sync with include/unidepth_hip.h "
                               f"({C.sizeof(st)} vs {lib.ud_struct_size(i)} bytes)")

@@ -362,17 +362,22 @@ __device__ __forceinline__ void gemm_body(const UdGemm& p, char* smem, int m0, i
     bptr[i] = W + (size_t)n * p.ldw + cs * 8;
   }
 
+  // split-fp16 products by K concatenation (UdGemm.a_wrap / w_wrap): the K index wraps around once inside the narrower operand
+  const int a_wt = p.a_wrap > 0 ? (AMODE == UD_A_DENSE ? p.a_wrap >> 6 : p.a_wrap) : 0x7fffffff;
+  const int w_wt = p.w_wrap > 0 ? p.w_wrap >> 6 : 0x7fffffff;
   auto issue = [&](int kt, int stage) {
     char* sb = smem + stage * C::STAGE_BYTES;
+    const int kb = kt >= w_wt ? kt - w_wt : kt;
 #pragma unroll
     for (int i = 0; i < C::A_INSTR; ++i) {
       const half_t* src;
       if constexpr (AMODE == UD_A_DENSE) {
-        src = aptr[i] + kt * 64;
+        src = aptr[i] + (kt >= a_wt ? kt - a_wt : kt) * 64;
       } else {
         const int kc = kt * 8 + a_csrc[i];                       // 8-channel chunk index along K = (tap, cin)
         const int tap = (int)(((float)kc + 0.5f) * inv_cc);
-        const int cch = (kc - tap * (p.Cin >> 3)) << 3;
+        int cch = (kc - tap * (p.Cin >> 3)) << 3;
+        cch = cch >= a_wt ? cch - a_wt : cch;
         const int t3 = (tap * 11) >> 5;                           // tap / 3 for tap < 12
         int yy = cl[i].y + t3 - 1;
         int xx = cl[i].x + (tap - t3 * 3) - 1;
@@ -388,7 +393,7 @@ __device__ __forceinline__ void gemm_body(const UdGemm& p, char* smem, int m0, i
       ud_glds16(src, sb + (wv * C::A_INSTR + i) * 1024);
     }
 #pragma unroll
-    for (int i = 0; i < C::B_INSTR; ++i) ud_glds16(bptr[i] + kt * 64, sb + C::A_BYTES + (wv * C::B_INSTR + i) * 1024);
+    for (int i = 0; i < C::B_INSTR; ++i) ud_glds16(bptr[i] + kb * 64, sb + C::A_BYTES + (wv * C::B_INSTR + i) * 1024);
   };
 
   // ---------------- fragment read geometry ----------------
@@ -728,19 +733,24 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
       pb[i] = ((unsigned)n * (unsigned)p.ldw + csrc * 8) * 2u;
     }
   };
+  // split-fp16 products by K concatenation (UdGemm.a_wrap / w_wrap): the K index wraps around once inside the narrower operand
+  const int a_wt = p.a_wrap > 0 ? (AMODE == UD_A_DENSE ? p.a_wrap >> 6 : p.a_wrap) : 0x7fffffff;
+  const int w_wt = p.w_wrap > 0 ? p.w_wrap >> 6 : 0x7fffffff;
   auto issue = [&](int kt, int stg, int mh) {
     char* sb = smem + stg * C::STAGE + wv * 1024;
     if constexpr (AMODE == UD_A_DENSE) {
+      const int ka = kt >= a_wt ? kt - a_wt : kt;
 #pragma unroll
       for (int i = 0; i < C::A_LOADS; ++i)
-        if (i < mh) ud_bufl16(rA, pa[i], kt * 128, sb + i * 8192);
+        if (i < mh) ud_bufl16(rA, pa[i], ka * 128, sb + i * 8192);
     } else {
       // implicit-GEMM gather: this lane's 16-byte chunk = 8 channels of tap (kc / (Cin/8)); one tap decode per K-tile;
       // padding taps use an offset beyond the descriptor's range and read as zeros
       static_assert(AMODE != UD_A_CONV3_REFLECT, "large-tile kernel: zero-padded convolutions only");
       const int kc = kt * 8 + csrc;
       const int tap = (int)(((float)kc + 0.5f) * inv_cc);
-      const int cch = (kc - tap * (p.Cin >> 3)) << 3;
+      int cch = (kc - tap * (p.Cin >> 3)) << 3;
+      cch = cch >= a_wt ? cch - a_wt : cch;
       const int t3 = (tap * 11) >> 5;
       const int dy = t3 - 1, dx = tap - t3 * 3 - 1;
 #pragma unroll
@@ -752,8 +762,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
         ud_bufl16(rA, off, 0, sb + i * 8192);
       }
     }
+    {
+      const int kb = kt >= w_wt ? kt - w_wt : kt;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ud_bufl16(rW, pb[i], kt * 128, sb + C::A_BYTES + i * 8192);
+      for (int i = 0; i < 4; ++i) ud_bufl16(rW, pb[i], kb * 128, sb + C::A_BYTES + i * 8192);
+    }
   };
 
   // ---------------- fragment read offsets inside a stage: row-major [row][64 halves], chunk index swizzled by (row >> 1) & 7
@@ -1465,7 +1478,7 @@ int launch_conv_tile(const UdGemm& d, hipStream_t s) {
 
 // eligibility: dense images (rows_img == H*W), N in {32, 64}, Cin multiple of 64, weights laid out [N][tap*Cin + ci]
 inline bool conv_tile_ok(const UdGemm& d) {
-  return d.amode != UD_A_DENSE && (d.N == 32 || d.N == 64) && (d.Cin & 63) == 0 && d.rows_img == d.Himg * d.Wimg &&
+  return d.amode != UD_A_DENSE && d.a_wrap == 0 && (d.N == 32 || d.N == 64) && (d.Cin & 63) == 0 && d.rows_img == d.Himg * d.Wimg &&
          d.M % d.rows_img == 0 && d.bias != nullptr && d.tile_hint != 1 && d.Himg >= 2 && d.Wimg >= 2 &&
          (d.epi == UD_EPI_HEAD || (d.epi == UD_EPI_F16 && d.act != UD_ACT_GELU && d.rows_in == 0 && d.add == nullptr && (d.ldc & 3) == 0));
 }
@@ -1545,6 +1558,13 @@ extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!d.A || !d.W || !d.out || d.M <= 0 || d.N <= 0 || d.K <= 0 || (d.K & 63) || (d.N & 3)) {
     ud_set_error("ud_gemm_f16: bad argument (need K % 64 == 0, N % 4 == 0)");
+    return UD_ERR_BAD_ARG;
+  }
+  if (d.a_wrap < 0 || d.w_wrap < 0 || (d.amode == UD_A_DENSE ? (d.a_wrap & 63) : (d.a_wrap & 7)) || (d.w_wrap & 63) ||
+      (d.a_wrap && d.w_wrap) || (d.w_wrap && d.amode != UD_A_DENSE) || (d.a_wrap && d.amode == UD_A_DENSE && 2 * d.a_wrap < d.K) ||
+      (d.w_wrap && 2 * d.w_wrap < d.K) || (d.a_wrap && d.amode != UD_A_DENSE && 2 * d.a_wrap < d.Cin) ||
+      ((d.a_wrap || d.w_wrap) && (d.amode == UD_A_CONV3_REFLECT_UP || d.groups > 1 && d.amode != UD_A_DENSE))) {
+    ud_set_error("ud_gemm_f16: bad a_wrap / w_wrap (one operand may wrap, once: 2 * wrap >= K resp. Cin; dense: multiple of 64, conv: of 8)");
     return UD_ERR_BAD_ARG;
   }
   if (d.amode == UD_A_CONV3_REFLECT_UP && d.epi != UD_EPI_HEAD) {

@@ -94,7 +94,12 @@ class Program:
     def gemm(self, **kw):
         g = max(1, kw.get("groups", 0))
         n = kw["N"]
-        tag, flops = kw.pop("tag", None), kw.pop("flops", 2.0 * kw["M"] * n * kw["K"] * g)
+        # algorithmic reduction length: a split-fp16 product (a_wrap / w_wrap: K concatenation, include/unidepth_hip.h) multiplies
+        # every (m, n, k) of the layer two or three times -- that is the price of the precision, not additional algorithmic work
+        k_alg = kw["K"]
+        if kw.get("a_wrap") or kw.get("w_wrap"):
+            k_alg = kw["K"] * kw["a_wrap"] // kw["Cin"] if kw.get("amode", 0) else (kw.get("a_wrap") or kw.get("w_wrap"))
+        tag, flops = kw.pop("tag", None), kw.pop("flops", 2.0 * kw["M"] * n * k_alg * g)
         tiles = -(-kw["M"] // 128) * -(-n // 128)
         if (g == 1 and kw.get("amode", 0) == UD_A_DENSE and kw.get("epi", 0) in (UD_EPI_F16, UD_EPI_F32) and tiles <= 128
                 and kw["K"] >= 1024 and kw["K"] % 128 == 0 and "splitk_ws" not in kw):
@@ -119,7 +124,7 @@ class Program:
         # algorithmic HBM bytes (every operand element once): A (conv modes: the image, not the 9x gathered rows), W, outputs,
         # + the old fp32 values of an accumulating epilogue
         m, k = kw["M"], kw["K"]
-        a_bytes = 2.0 * m * (kw["Cin"] if amode else k) * (1 if kw.get("gA", 1) else 1.0 / g)
+        a_bytes = 2.0 * m * ((kw.get("a_wrap") or kw["Cin"]) if amode else (kw.get("a_wrap") or k)) * (1 if kw.get("gA", 1) else 1.0 / g)
         o_bytes = {UD_EPI_F16: 2.0, UD_EPI_QKV: 2.0, UD_EPI_F32: 4.0, UD_EPI_D2S: 4.0, UD_EPI_HEAD: 4.0 / max(n, 1)}[epi] * m * n
         if epi in (UD_EPI_F32, UD_EPI_D2S):
             o_bytes = (0.0 if kw.get("accumulate", 0) == 2 else 4.0 * m * n) + (4.0 * m * n if kw.get("accumulate", 0) or epi == UD_EPI_D2S else 0.0)

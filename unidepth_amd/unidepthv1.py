@@ -28,12 +28,38 @@ def _rup(x, m):
     return (x + m - 1) // m * m
 
 
-def _padk16(w: torch.Tensor) -> torch.Tensor:
+# Weight precision.  fp16-rounding the weights is a SYSTEMATIC perturbation of the model: it moves the predicted camera and the
+# log-depth of every pixel coherently, where the activations' rounding averages out (tools/v1_precision_study.py: with fp16 x fp16
+# operands depth ARel 1.3-1.6e-3 and K error 5e-4 against the fp32 reference; with exact weights 7e-4 and 6e-5).  The reference runs
+# UniDepthV1 in fp32 (no autocast, unidepthv1.py:287-373), so every weight goes to the matrix pipes as TWO fp16 terms,
+# W = W_hi + W_lo, concatenated along K: [W_hi | W_lo] against A read twice (UdGemm.a_wrap) -- A W_hi^T + A W_lo^T in one fp32
+# accumulator, the weights exact to ~22 bits.  UNIDEPTH_V1_WSPLIT=0 keeps single fp16 weights (A/B of the cost).
+WSPLIT = os.environ.get("UNIDEPTH_V1_WSPLIT", "1") != "0"
+
+
+def _padk16(w: torch.Tensor, split: Optional[bool] = None) -> torch.Tensor:
+    """[N, K] fp32 -> fp16 GEMM operand, K zero-padded to a multiple of 64; split: [hi | lo] halves of the padded width each."""
+    split = WSPLIT if split is None else split
     n, k = w.shape
     kp = _rup(k, 64)
-    out = w.new_zeros(n, kp)
-    out[:, :k] = w
-    return out.to(torch.float16).contiguous()
+    hi = w.to(torch.float16)
+    out = torch.zeros(n, 2 * kp if split else kp, dtype=torch.float16)
+    out[:, :k] = hi
+    if split:
+        out[:, kp:kp + k] = (w - hi.to(torch.float32)).to(torch.float16)
+    return out.contiguous()
+
+
+def _wk(Wt: torch.Tensor, K: int, conv_cin: int = 0) -> dict:
+    """Descriptor fields of a GEMM whose W operand is a packed weight: K = width of the A operand (conv: 9 * Cin rounded up);
+    a split weight is twice as wide and A wraps around (dense: after K columns; conv: after Cin channels of every tap)."""
+    if conv_cin:
+        split = Wt.shape[1] >= 18 * conv_cin
+        return dict(K=Wt.shape[1], ldw=Wt.shape[1], Cin=2 * conv_cin if split else conv_cin, **({"a_wrap": conv_cin} if split else {}))
+    if Wt.shape[1] == 2 * K:
+        return dict(K=2 * K, ldw=2 * K, a_wrap=K)
+    assert Wt.shape[1] == K, (tuple(Wt.shape), K)
+    return dict(K=K, ldw=K)
 
 
 def pack_convnext(config: dict, sd: dict, device) -> dict:
@@ -70,13 +96,29 @@ def pack_convnext(config: dict, sd: dict, device) -> dict:
     return w
 
 
+def _ak(Wt: torch.Tensor, K: int) -> dict:
+    """Like _wk for a GEMM whose *A* operand is the packed weight (V^T = W_v X^T): the activations (W operand) wrap around."""
+    if Wt.shape[1] == 2 * K:
+        return dict(K=2 * K, lda=2 * K, w_wrap=K)
+    assert Wt.shape[1] == K, (tuple(Wt.shape), K)
+    return dict(K=K, lda=K)
+
+
 def _fold_ln(w, b, g, beta):
     b0 = b if b is not None else w.new_zeros(w.shape[0])
     return w * g[None, :], b0 + w @ beta
 
 
-def _conv3_rows(w):                          # [Cout, Cin, 3, 3] -> [Cout, 9*Cin], k = (ky*3 + kx)*Cin + ci
-    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+def _conv3_rows(w, split: Optional[bool] = None):
+    """[Cout, Cin, 3, 3] -> [Cout, 9*Cin], k = (ky*3 + kx)*Cin + ci; split: fp32 [Cout, 9 * 2 * Cin] with the (hi | lo) fp16 terms of every
+    tap side by side (both exactly representable in fp16, so the later fp16 cast is exact)."""
+    split = WSPLIT if split is None else split
+    r = w.permute(0, 2, 3, 1).reshape(w.shape[0], 9, -1)
+    if not split:
+        return r.reshape(w.shape[0], -1)
+    hi = r.to(torch.float16).to(torch.float32)
+    lo = (r - hi).to(torch.float16).to(torch.float32)
+    return torch.cat([hi, lo], dim=2).reshape(w.shape[0], -1)
 
 
 def pack_v1_decoder(config: dict, sd: dict, device) -> dict:
@@ -190,12 +232,13 @@ def pack_v1_decoder(config: dict, sd: dict, device) -> dict:
             g = f[src + "gamma"]
             p16(dst + "fc2.w", f[src + "pwconv2.weight"] * g[:, None]); p32(dst + "fc2.b", f[src + "pwconv2.bias"] * g)
         p16(f"{nm}.up0.w", f[f"{dl}{nm}.up.0.weight"].reshape(d // 2, d)); p32(f"{nm}.up0.b", f[f"{dl}{nm}.up.0.bias"])
-        p16(f"{nm}.up2.w", _conv3_rows(f[f"{dl}{nm}.up.2.weight"])); p32(f"{nm}.up2.b", f[f"{dl}{nm}.up.2.bias"])
+        w[f"{nm}.up2.w"] = _padk16(_conv3_rows(f[f"{dl}{nm}.up.2.weight"]), split=False).to(device); p32(f"{nm}.up2.b", f[f"{dl}{nm}.up.2.bias"])
     for nm, d in (("out8", C // 2), ("out4", C // 4), ("out2", C // 8)):
-        rows = torch.zeros(4, 9 * d)
-        rows[0] = _conv3_rows(f[f"{dl}{nm}.weight"])[0]
+        r0 = _conv3_rows(f[f"{dl}{nm}.weight"])[0]
+        rows = torch.zeros(4, r0.numel())
+        rows[0] = r0
         bias = torch.zeros(4); bias[0] = f[f"{dl}{nm}.bias"][0]
-        p16(f"{nm}.w", rows); p32(f"{nm}.b", bias)
+        w[f"{nm}.w"] = _padk16(rows, split=False).to(device); p32(f"{nm}.b", bias)
     return w
 
 
@@ -223,7 +266,7 @@ class _EncPlan:
         patches = z(rows, 64)
         P.patchify4(self.img, patches, B, Hn, Wn, 64)
         x0 = z(rows, dims[0], dtype=f32)
-        P.gemm(A=patches, W=w["stem.w"], bias=w["stem.b"], out=x0, M=rows, N=dims[0], K=64, lda=64, ldw=64, ldc=dims[0], epi=UD_EPI_F32, tag="stem")
+        P.gemm(A=patches, W=w["stem.w"], bias=w["stem.b"], out=x0, M=rows, N=dims[0], lda=64, ldc=dims[0], epi=UD_EPI_F32, tag="stem", **_wk(w["stem.w"], 64))
         x = z(rows, dims[0], dtype=f32)
         P.layernorm(x=x0, y=x, rows=rows, D=dims[0], ldx=dims[0], ldy=dims[0], eps=1e-6, rows_per_img=rows, in_rows_per_img=rows,
                     out_rows_per_img=rows, out_f32=1, gamma=w["stem.g"], beta=w["stem.beta"])
@@ -239,8 +282,8 @@ class _EncPlan:
                 col = z(rows, 4 * Cp)
                 P.layernorm_patchify2(x, col, B, H, W, Cp, 4 * Cp, 1e-6)
                 xn = z(rows, C, dtype=f32)
-                P.gemm(A=col, W=w[f"ds.{s}.w"], bias=w[f"ds.{s}.b"], out=xn, M=rows, N=C, K=4 * Cp, lda=4 * Cp, ldw=4 * Cp, ldc=C, epi=UD_EPI_F32,
-                       tag=f"downsample.{s}")
+                P.gemm(A=col, W=w[f"ds.{s}.w"], bias=w[f"ds.{s}.b"], out=xn, M=rows, N=C, lda=4 * Cp, ldc=C, epi=UD_EPI_F32,
+                       tag=f"downsample.{s}", **_wk(w[f"ds.{s}.w"], 4 * Cp))
                 x, H, W = xn, Ho, Wo
             y = z(rows, C, dtype=f32)
             xh = z(rows, C)
@@ -249,10 +292,10 @@ class _EncPlan:
             for i in range(dep):
                 P.dwconv7(x=x, w=w[f"blk.{s}.{i}.dw.w"], bias=w[f"blk.{s}.{i}.dw.b"], y=y, B=B, H=H, W=W, C=C, ldx=C, ldy=C, tag=f"dwconv.s{s}")
                 P.layernorm(x=y, y=xh, rows=rows, D=C, ldx=C, ldy=C, eps=1e-6, rows_per_img=rows, in_rows_per_img=rows, out_rows_per_img=rows)
-                P.gemm(A=xh, W=w[f"blk.{s}.{i}.fc1.w"], bias=w[f"blk.{s}.{i}.fc1.b"], out=hid, M=rows, N=4 * C, K=C, lda=C, ldw=C, ldc=4 * C,
-                       epi=UD_EPI_F16, act=UD_ACT_GELU, tag=f"enc.fc1.s{s}")
-                P.gemm(A=hid, W=w[f"blk.{s}.{i}.fc2.w"], bias=w[f"blk.{s}.{i}.fc2.b"], out=x, M=rows, N=C, K=4 * C, lda=4 * C, ldw=4 * C, ldc=C,
-                       epi=UD_EPI_F32, accumulate=1, tag=f"enc.fc2.s{s}")
+                P.gemm(A=xh, W=w[f"blk.{s}.{i}.fc1.w"], bias=w[f"blk.{s}.{i}.fc1.b"], out=hid, M=rows, N=4 * C, lda=C, ldc=4 * C,
+                       epi=UD_EPI_F16, act=UD_ACT_GELU, tag=f"enc.fc1.s{s}", **_wk(w[f"blk.{s}.{i}.fc1.w"], C))
+                P.gemm(A=hid, W=w[f"blk.{s}.{i}.fc2.w"], bias=w[f"blk.{s}.{i}.fc2.b"], out=x, M=rows, N=C, lda=4 * C, ldc=C,
+                       epi=UD_EPI_F32, accumulate=1, tag=f"enc.fc2.s{s}", **_wk(w[f"blk.{s}.{i}.fc2.w"], 4 * C))
                 P.max_(smax, x, rows * C, i == 0)
                 if blk >= nblk - 4:                        # the decoder reads the class tokens of the LAST four blocks (decoder.py:375-377)
                     cbuf = z(B, C, dtype=f32)
@@ -585,8 +628,8 @@ class _FullPlan:
             P.layernorm(x=src, y=dst, rows=rows, D=D, ldx=D, ldy=D, eps=eps, **dict(dict(rows_per_img=rows, in_rows_per_img=rows, out_rows_per_img=rows), **kw))
 
         def gemm(A, Wn_, out, M, N, K, bias=True, **kw):
-            P.gemm(A=A, W=w[Wn_ + ".w"], out=out, M=M, N=N, K=K, lda=kw.pop("lda", K), ldw=w[Wn_ + ".w"].shape[1], ldc=kw.pop("ldc", N),
-                   **({"bias": w[Wn_ + ".b"]} if bias else {}), tag=kw.pop("tag", "v1." + Wn_), **kw)
+            P.gemm(A=A, W=w[Wn_ + ".w"], out=out, M=M, N=N, lda=kw.pop("lda", K), ldc=kw.pop("ldc", N),
+                   **({"bias": w[Wn_ + ".b"]} if bias else {}), tag=kw.pop("tag", "v1." + Wn_), **_wk(w[Wn_ + ".w"], K), **kw)
 
         def mlp(stream, pre, rows, D, hid_mult, accumulate=1, out=None, n_out=None):
             """x (+)= fc2(GELU(fc1(LN(x))))  (layers/mlp.py:27-35; LayerScale folded into fc2)."""
@@ -723,8 +766,8 @@ class _FullPlan:
             kw = dict(add=add_k, ldadd=C, rows_in=Nk, rows_out=Nk) if add_k is not None else {}
             gemm(ctxn, pre + "k", k, B * Nk, C, C, epi=UD_EPI_F16, **kw)
             # V^T[b] = Wv ctxn[b]^T (operands swapped: no transpose pass); its bias is added after P V (softmax rows sum to one)
-            P.gemm(A=w[pre + "v.w"], W=ctxn, out=vt, M=C, N=Nk, K=C, lda=C, ldw=C, ldc=Nkp, epi=UD_EPI_F16, groups=B, gA=0, gW=Nk * C, gOut=C * Nkp,
-                   tag="v1." + pre + "vT")
+            P.gemm(A=w[pre + "v.w"], W=ctxn, out=vt, M=C, N=Nk, ldw=C, ldc=Nkp, epi=UD_EPI_F16, groups=B, gA=0, gW=Nk * C, gOut=C * Nkp,
+                   tag="v1." + pre + "vT", **_ak(w[pre + "v.w"], C))
             S = z(B * hw, Nk, dtype=f32)
             P.gemm(A=q, W=k, out=S, M=hw, N=Nk, K=C, lda=C, ldw=C, ldc=Nk, epi=UD_EPI_F32, groups=B, gA=hw * C, gW=Nk * C, gOut=hw * Nk, tag="v1." + pre + "qk")
             Pm = z(B * hw, Nkp)
@@ -751,7 +794,7 @@ class _FullPlan:
             xn = z(Mt, C); q = z(Mt, C); k = z(Mt, C); vt = z(B, heads, 64, hwk); ao = z(Mt, C)
             ln(lat, xn, Mt, C)
             gemm(xn, pre + "q", q, Mt, C, C, epi=UD_EPI_F16, add=e16, ldadd=C)
-            P.gemm(A=xn, W=w[pre + "kv.w"], bias=w[pre + "kv.b"], out=k, out2=vt, M=Mt, N=2 * C, K=C, lda=C, ldw=C, ldc=C, epi=UD_EPI_QKV, vsplit=C,
+            P.gemm(A=xn, W=w[pre + "kv.w"], bias=w[pre + "kv.b"], out=k, out2=vt, M=Mt, N=2 * C, lda=C, ldc=C, epi=UD_EPI_QKV, vsplit=C, **_wk(w[pre + "kv.w"], C),
                    tok_per_img=hw, kv_ld=hwk, heads_v=heads, tag="v1." + pre + "kv")
             P.attention(Q=q, K=k, Vt=vt, O=ao, B=B, H=heads, Nq=hw, Nk=hw, ldq=C, ldk=C, ldo=C, kv_ld=hwk, q_rows_per_img=hw, k_rows_per_img=hw,
                         scale=(C // heads) ** -0.5, tag="v1.l16.attn")
@@ -779,17 +822,15 @@ class _FullPlan:
             u1 = z(B * 4 * n, Cl // 2)
             P.resize_ac(in_=u0, out=u1, G=1, B=B, Hin=hh, Win=ww, Hout=2 * hh, Wout=2 * ww, C=Cl // 2)                  # UpsamplingBilinear2d = align_corners
             nxt = z(B * 4 * n, Cl // 2, dtype=f32); nxt16 = z(B * 4 * n, Cl // 2)
-            kp = w[f"{nm}.up2.w"].shape[1]
-            P.gemm(A=u1, W=w[f"{nm}.up2.w"], bias=w[f"{nm}.up2.b"], out=nxt, out2=nxt16, zeros=zeros, M=B * 4 * n, N=Cl // 2, K=kp, ldw=kp, ldc=Cl // 2,
-                   ldc2=Cl // 2, amode=UD_A_CONV3_ZERO, epi=UD_EPI_F32, Himg=2 * hh, Wimg=2 * ww, Cin=Cl // 2, cstride=Cl // 2, coff=0, rows_img=4 * n,
+            P.gemm(A=u1, W=w[f"{nm}.up2.w"], bias=w[f"{nm}.up2.b"], out=nxt, out2=nxt16, zeros=zeros, M=B * 4 * n, N=Cl // 2, ldc=Cl // 2, **_wk(w[f"{nm}.up2.w"], 0, Cl // 2),
+                   ldc2=Cl // 2, amode=UD_A_CONV3_ZERO, epi=UD_EPI_F32, Himg=2 * hh, Wimg=2 * ww, cstride=Cl // 2, coff=0, rows_img=4 * n,
                    img_stride=4 * n * (Cl // 2), tag=f"v1.{nm}.conv3")
             return nxt, nxt16
 
         def out_conv(nm, x16, hh, ww, Cl):
             o = z(B * hh * ww, 4, dtype=f32)
-            kp = w[nm + ".w"].shape[1]
-            P.gemm(A=x16, W=w[nm + ".w"], bias=w[nm + ".b"], out=o, zeros=zeros, M=B * hh * ww, N=4, K=kp, ldw=kp, ldc=4, amode=UD_A_CONV3_ZERO, epi=UD_EPI_F32,
-                   act=L.UD_ACT_CLAMPEXP, Himg=hh, Wimg=ww, Cin=Cl, cstride=Cl, coff=0, rows_img=hh * ww, img_stride=hh * ww * Cl, tag="v1." + nm)
+            P.gemm(A=x16, W=w[nm + ".w"], bias=w[nm + ".b"], out=o, zeros=zeros, M=B * hh * ww, N=4, ldc=4, amode=UD_A_CONV3_ZERO, epi=UD_EPI_F32, **_wk(w[nm + ".w"], 0, Cl),
+                   act=L.UD_ACT_CLAMPEXP, Himg=hh, Wimg=ww, cstride=Cl, coff=0, rows_img=hh * ww, img_stride=hh * ww * Cl, tag="v1." + nm)
             return o
 
         # ---------------- Nystrom attention block (layers/nystrom_attention.py:22-84; xformers NystromAttention, 128 landmarks -- PARITY UNPINNED)
@@ -801,7 +842,8 @@ class _FullPlan:
             ln(x, xn, M, Cl)
             gemm(xn, pre + "q", q, M, Cl, Cl, epi=UD_EPI_F16, add=e_tok, ldadd=Cl)
             gemm(xn, pre + "k", k, M, Cl, Cl, epi=UD_EPI_F16)
-            P.gemm(A=w[pre + "v.w"], W=xn, out=vt, M=Cl, N=n, K=Cl, lda=Cl, ldw=Cl, ldc=npad, epi=UD_EPI_F16, groups=B, gA=0, gW=n * Cl, gOut=Cl * npad, tag="v1.nys.vT")
+            P.gemm(A=w[pre + "v.w"], W=xn, out=vt, M=Cl, N=n, ldw=Cl, ldc=npad, epi=UD_EPI_F16, groups=B, gA=0, gW=n * Cl, gOut=Cl * npad, tag="v1.nys.vT",
+                   **_ak(w[pre + "v.w"], Cl))
             ql = z(B * Lm, Cl); kl = z(B * Lm, Cl)
             P.v1(L.UD_V1_SEGMENT_MEAN, a=q, out=ql, i=(B, n, Cl, Lm, Cl, Cl), tag="landmarks")
             P.v1(L.UD_V1_SEGMENT_MEAN, a=k, out=kl, i=(B, n, Cl, Lm, Cl, Cl), tag="landmarks")
