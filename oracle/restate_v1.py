@@ -92,9 +92,22 @@ class OracleConvNeXt:
 # and the reference cannot execute without it.  `nystrom_attention()` below restates the PUBLISHED algorithm of that class
 # (Xiong et al. 2021 as implemented by xformers: segment-mean landmarks, three softmax kernels, 6 Newton-Schulz iterations for the
 # pseudo-inverse with the exact 1/||K||_1 initialisation, no skip connection, no dropout at inference) applied per head over the
-# token axis.  The reference hands xformers [b, n, h, d] tensors; how the pinned-nowhere xformers version treats that layout cannot be
-# checked offline, so per-head token attention is an interpretation, not a pin.  Everything else of the decoder is pinned by running
-# the reference's own decoder with this function plugged in as xformers' NystromAttention (oracle/stubs/xformers).
+# token axis.  Everything else of the decoder is pinned by running the reference's own decoder with this function plugged in as
+# xformers' NystromAttention (oracle/stubs/xformers).
+#
+# What exactly is ASSUMED about the un-reproducible call (layers/nystrom_attention.py:59-62,81):
+#   * the reference passes q, k, v as 4-D [b, n, h, d] (einops "b n (h d) -> b n h d") and reads the result back as "b n h d";
+#   * this restatement takes that to MEAN: for every (image b, head h) independently, Nystrom attention of the n tokens' d-wide
+#     q / k / v rows -- landmarks = means over 128 consecutive token segments (xformers AvgPool rule for n % 128 != 0: the first
+#     128 - n % 128 segments hold floor(n / 128) tokens, the others one more), kernels softmax(q kl^T / sqrt d), softmax(ql kl^T / sqrt d),
+#     softmax(ql k^T / sqrt d) v, pseudo-inverse by 6 Newton-Schulz steps from Z0 = K^T / max column sum (per matrix);
+#   * xformers' module is written for 3-D [N, S, hs] inputs (heads folded into the batch by its MultiHeadDispatch); with a 4-D input
+#     its `seq_len = k.size(-2)` reads the HEAD count and its AvgPool reads x.shape[2] (= h) as the head width, so what the deployed
+#     build really computes for the reference's layout may be something else (e.g. a shape error, or a degenerate attention across the
+#     h heads of each token).  Without the package this cannot be decided here.
+# Single-source risk on the ALGORITHM is removed by tests/test_oracle_nystrom_cpu.py: nystrom_attention / iterative_pinv /
+# segment_means agree to fp32 round-off with Hugging Face's independent NystromformerSelfAttention (installed: transformers).  The LAYOUT
+# question stays open, so parity of layers_8 / layers_4 with released weights is UNPINNED and the engine warns (unidepth_amd/hub.py).
 # =====================================================================================================================
 def real_sh_deg8(xyz: torch.Tensor) -> torch.Tensor:
     """Real spherical harmonics up to degree 8 at unit vectors xyz [..., 3] -> [..., 81], Y_n^m at index n(n+1)+m, Condon-Shortley

@@ -1,0 +1,111 @@
+"""Triangulation of the restated Nystrom attention (oracle/restate_v1.py: nystrom_attention / iterative_pinv / segment_means) against an
+INDEPENDENT implementation of the same published algorithm (Xiong et al. 2021) that is installed here: Hugging Face's
+transformers/models/nystromformer/modeling_nystromformer.py (NystromformerSelfAttention: landmark means, three softmax kernels,
+`iterative_inv`).  xformers -- whose NystromAttention the reference actually calls (layers/nystrom_attention.py:44-46,81) -- is not
+installed and not vendored, so this does NOT pin the oracle to the reference ("parity unpinned" stays); it removes the single-source
+risk on the algorithm itself: two independent statements agree to fp32 round-off."""
+import math
+
+import pytest
+import torch
+
+from oracle import restate_v1
+
+hf = pytest.importorskip("transformers.models.nystromformer.modeling_nystromformer")
+
+
+def _hf_module(heads, d, n_tokens, landmarks, init="exact"):
+    from transformers import NystromformerConfig
+    cfg = NystromformerConfig(hidden_size=heads * d, num_attention_heads=heads, num_landmarks=landmarks, segment_means_seq_len=n_tokens,
+                              conv_kernel_size=3, attention_probs_dropout_prob=0.0)
+    m = hf.NystromformerSelfAttention(cfg).eval()
+    m.conv_kernel_size = None      # no depth-wise conv residual on V: xformers' NystromAttention default (conv_kernel_size=None), what the reference builds
+    m.init_option = init           # "original": one global 1 / max column sum for the whole batch; anything else: per matrix (xformers' default)
+    return m
+
+
+def _hf_attention(q, k, v, landmarks, init="exact"):
+    """q, k, v [B, H, N, d] through HF's forward with its q/k/v projections replaced by the given tensors."""
+    B, H, N, d = q.shape
+    m = _hf_module(H, d, N, landmarks, init)
+    class Const(torch.nn.Module):
+        def __init__(self, t):
+            super().__init__()
+            self.t = t.permute(0, 2, 1, 3).reshape(B, N, H * d)
+
+        def forward(self, hs):
+            return self.t
+    m.query, m.key, m.value = Const(q), Const(k), Const(v)
+    with torch.no_grad():
+        out = m(torch.zeros(B, N, H * d))[0]                         # [B, N, H*d]
+    return out.view(B, N, H, d).permute(0, 2, 1, 3)
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm()).item()
+
+
+@pytest.mark.parametrize("B,H,N,d,L", [(2, 4, 1024, 64, 128), (1, 2, 4096, 64, 128), (3, 4, 512, 32, 64)])
+def test_nystrom_matches_hf_divisible(B, H, N, d, L):
+    g = torch.Generator().manual_seed(N + H)
+    q, k, v = (torch.randn(B, H, N, d, generator=g) for _ in range(3))
+    ours = restate_v1.nystrom_attention(q.reshape(B * H, N, d), k.reshape(B * H, N, d), v.reshape(B * H, N, d), L).reshape(B, H, N, d)
+    ref = _hf_attention(q, k, v, L)
+    assert rel(ours, ref) < 2e-5, rel(ours, ref)
+
+
+def test_iterative_pinv_matches_hf_both_initialisations():
+    g = torch.Generator().manual_seed(3)
+    k2 = torch.softmax(torch.randn(2, 4, 128, 128, generator=g) * 2.0, dim=-1)
+    m = _hf_module(4, 64, 1024, 128, init="exact")
+    assert rel(restate_v1.iterative_pinv(k2.reshape(8, 128, 128)).reshape(2, 4, 128, 128), m.iterative_inv(k2)) < 1e-5
+    # the conservative "original" initialisation takes ONE coefficient for the whole batch: identical for a single matrix
+    m.init_option = "original"
+    one = k2[:1, :1]
+    assert rel(restate_v1.iterative_pinv(one.reshape(1, 128, 128)), m.iterative_inv(one).reshape(1, 128, 128)) < 1e-5
+    # and it is a pseudo-inverse: K Z K ~ K after the six iterations on a well-conditioned kernel
+    kk = torch.softmax(torch.randn(1, 128, 128, generator=g) * 4.0, dim=-1)
+    z = restate_v1.iterative_pinv(kk, 30)
+    assert rel(kk @ z @ kk, kk) < 1e-3
+
+
+@pytest.mark.parametrize("N,L", [(4256, 128), (1064 * 16, 128), (130, 128), (255, 128)])
+def test_segment_means_non_divisible(N, L):
+    """xformers' AvgPool rule for N % L != 0 (nystrom.py AvgPool.forward): the first L - N % L landmarks average floor(N / L) tokens,
+    the remaining N % L average one token more, in sequence order -- against an explicit loop."""
+    g = torch.Generator().manual_seed(N)
+    x = torch.randn(2, N, 8, generator=g)
+    got = restate_v1.segment_means(x, L)
+    seg, n_round = N // L, L - N % L
+    want, t = [], 0
+    for i in range(L):
+        ln = seg if i < n_round else seg + 1
+        want.append(x[:, t:t + ln].mean(dim=1))
+        t += ln
+    assert t == N
+    assert torch.allclose(got, torch.stack(want, dim=1), atol=1e-6)
+
+
+def test_nystrom_non_divisible_composes_hf_pieces():
+    """N = 4256 (the 1/8-resolution token count of the 462x616 network image) is not a multiple of 128: HF's reshape cannot form the
+    landmarks, so the three kernels are formed here with HF's scaling and HF's `iterative_inv` on the restated landmarks."""
+    B, H, N, d, L = 1, 4, 4256, 64, 128
+    g = torch.Generator().manual_seed(11)
+    q, k, v = (torch.randn(B * H, N, d, generator=g) for _ in range(3))
+    ours = restate_v1.nystrom_attention(q, k, v, L)
+    m = _hf_module(H, d, L * (N // L), L)
+    s = 1.0 / math.sqrt(math.sqrt(d))
+    qs, ks = q * s, k * s
+    ql, kl = restate_v1.segment_means(qs, L), restate_v1.segment_means(ks, L)
+    k1 = torch.softmax(qs @ kl.transpose(-1, -2), dim=-1)
+    k2 = torch.softmax(ql @ kl.transpose(-1, -2), dim=-1)
+    k3 = torch.softmax(ql @ ks.transpose(-1, -2), dim=-1)
+    ref = (k1 @ m.iterative_inv(k2.reshape(B, H, L, L)).reshape(B * H, L, L)) @ (k3 @ v)
+    assert rel(ours, ref) < 2e-5
+
+
+def test_nystrom_equals_full_attention_when_landmarks_cover_every_token():
+    g = torch.Generator().manual_seed(5)
+    q, k, v = (torch.randn(2, 128, 64, generator=g) for _ in range(3))
+    full = torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1) @ v
+    assert rel(restate_v1.nystrom_attention(q, k, v, 128), full) < 1e-6

@@ -1,4 +1,4 @@
-"""unidepth_amd -- MI355X (gfx950) native engine for the UniDepthV2 `infer()` path.
+"""unidepth_amd -- MI355X (gfx950) native engine for the UniDepth `infer()` paths (UniDepthV2 on DINOv2 ViT-S/B/L; UniDepthV1 on ConvNeXt-L).
 
 Public surface mirrors the reference (lpiccinelli-eth/UniDepth, unidepth/models/__init__.py):
     from unidepth_amd import UniDepthV2
@@ -14,7 +14,7 @@ def __getattr__(name):
     if name == "UniDepthV2":
         from .unidepthv2 import UniDepthV2
         return UniDepthV2
-    if name in ("UniDepthV1", "UniDepth"):            # hubconf-style entry point / the V1 family (not built: fails loudly)
+    if name in ("UniDepthV1", "UniDepth"):            # hubconf-style entry point / the V1 family (ConvNeXt-L; see hub.py for the Nystrom caveat)
         from . import hub
         return getattr(hub, name)
     raise AttributeError(name)

@@ -1,8 +1,14 @@
 """`UniDepth(version, backbone, pretrained)` entry point with the reference's hubconf signature (hubconf.py:25-41): builds the
 engine class for the version from the shipped architecture config and, if `pretrained`, fetches `pytorch_model.bin` from the
 `lpiccinelli/unidepth-<version>-<backbone>` hub repository (needs network access or a warm huggingface cache).
-The V2 ViT backbones run end to end; `v1` / `cnvnxtl` builds the engine's UniDepthV1 (encoder half implemented, see unidepthv1.py);
-`v2old` and the V1 ViT-L variant raise NotImplementedError."""
+The V2 ViT backbones and `v1` / `cnvnxtl` (UniDepthV1 on ConvNeXt-L: encoder + decoder, unidepthv1.py) run end to end on the engine;
+`v2old` and the V1 ViT-L variant raise NotImplementedError.
+
+UniDepthV1 caveat (parity UNPINNED for its two Nystrom stages): the reference computes `layers_8` / `layers_4` with
+xformers' NystromAttention, a dependency that is neither vendored nor pinned, and hands it 4-D [b, n, h, d] tensors
+(layers/nystrom_attention.py:59-62,81).  The engine implements the published algorithm per head over tokens; whether the deployed
+xformers build does the same for that layout has not been checked against a run of the real package.  Loading RELEASED V1 weights
+therefore warns (UniDepthV1.nystrom_caveat_acknowledged = True, or UNIDEPTH_V1_ACK_NYSTROM=1, silences it)."""
 from __future__ import annotations
 
 import json
@@ -14,7 +20,7 @@ BACKBONES = {"v1": ["vitl14", "cnvnxtl"], "v2": ["vitl14", "vitb14", "vits14"], 
 _CFG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs")      # architecture configs of the V2 ViT-S/B/L checkpoints
 
 
-from .unidepthv1 import UniDepthV1  # noqa: E402,F401  (ConvNeXt-L encoder on the engine; the V1 decoder is still missing and infer() says so)
+from .unidepthv1 import UniDepthV1  # noqa: E402,F401  (ConvNeXt-L encoder + V1 decoder on the engine; Nystrom stages: see the caveat above)
 
 
 def UniDepth(version: str = "v2", backbone: str = "vitl14", pretrained: bool = True):

@@ -317,6 +317,12 @@ class UniDepthV1:
             raise NotImplementedError(f"UniDepthV1 pixel_encoder {name!r}: only the ConvNeXt-L backbone (config_v1_cnvnxtl) is implemented on this engine")
         self._arch = dict(CONVNEXT[name])
         self._arch["output_idx"] = list(config["model"]["pixel_encoder"].get("output_idx", [3, 6, 33, 36]))
+        ends = [sum(self._arch["depths"][:i + 1]) for i in range(4)]
+        if self._arch["output_idx"] != ends:
+            # the encoder program takes the element-wise max over WHOLE stages and the class tokens of the last four blocks
+            raise NotImplementedError(f"UniDepthV1 pixel_encoder.output_idx {self._arch['output_idx']}: only the stage ends {ends} are implemented")
+        # PARITY UNPINNED for the Nystrom stages (see hub.py / oracle/restate_v1.py): warn once per model when it first runs infer()
+        self.nystrom_caveat_acknowledged = os.environ.get("UNIDEPTH_V1_ACK_NYSTROM", "0") == "1"
         self.image_shape = list(config["data"]["image_shape"])                         # unidepthv1.py:444
         self._sd = None
         self._w = None
@@ -482,6 +488,14 @@ class UniDepthV1:
         [3,3] / [B,3,3] of the INPUT image, skip_camera (use the given camera instead of running the camera head)
         -> {"intrinsics" [B,3,3], "points" [B,3,H,W], "depth" [B,1,H,W]} at the input resolution."""
         self._ensure_packed()
+        if not self.nystrom_caveat_acknowledged:
+            import warnings
+            warnings.warn("UniDepthV1 on the MI355X engine: the two Nystrom attention stages (layers_8 / layers_4) implement the published algorithm "
+                          "per head over tokens; the reference delegates them to the un-vendored, un-pinned xformers NystromAttention with 4-D "
+                          "[b, n, h, d] inputs and that call has not been reproduced offline -- parity with RELEASED V1 weights is UNPINNED "
+                          "(everything else is pinned to the reference).  Set model.nystrom_caveat_acknowledged = True or "
+                          "UNIDEPTH_V1_ACK_NYSTROM=1 to silence this.", RuntimeWarning, stacklevel=2)
+            self.nystrom_caveat_acknowledged = True
         if rgbs.ndim == 3:
             rgbs = rgbs.unsqueeze(0)
         if intrinsics is not None and intrinsics.ndim == 2:
