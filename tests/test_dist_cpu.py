@@ -22,13 +22,13 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, B, q):
+def _worker(rank, world, port, B, q, algo=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from unidepth_amd.dist import infer_data_parallel, shard_bounds
     g = torch.Generator().manual_seed(0)
     rgb = torch.randint(0, 256, (B, 3, 6, 5), dtype=torch.uint8, generator=g)
-    out = infer_data_parallel(_FakeModel(), rgb, keys=("depth", "intrinsics"))
+    out = infer_data_parallel(_FakeModel(), rgb, keys=("depth", "intrinsics"), gather_algo=algo)
     ref = _FakeModel().infer(rgb)
     ok = all(torch.equal(out[k], ref[k]) for k in ("depth", "intrinsics")) and out["depth"].shape[0] == B
     bounds = shard_bounds(B, world)
@@ -51,6 +51,23 @@ def test_data_parallel_gather_gloo(B):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+@pytest.mark.parametrize("world,B", [(2, 5), (3, 7)])
+def test_data_parallel_direct_all_pairs_gather_gloo(world, B):
+    """The all-pairs form of the exchange step (world-1 sends + receives in one group instead of all_gather_into_tensor; what a
+    fully-connected xGMI node wants) returns the same bits, incl. uneven shards and an odd world size."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, q, "direct")) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(r, True) for r in range(world)]
 
 
 def test_shard_bounds():

@@ -32,6 +32,10 @@ def test_bench_two_ranks_rccl():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4
     assert d["rccl"]["world_size"] == 2 and d["rccl"]["ranks_seen"] == [0, 1] and d["rccl"]["all_blocks_valid"]
     assert d["rccl"]["backend"].startswith("rccl") and d["rccl"]["gathered_bytes_per_rank_per_step"] == 2 * (2 * 252 * 336 + 9) * 4
+    # two distinct devices, both forms of the exchange step ran and agree bit for bit, RCCL's own log was captured
+    assert d["rccl"]["distinct_devices"] == 2 and d["rccl"]["algos_bit_identical"]
+    assert set(d["rccl"]["gather_alone_ms_by_algo"]) == {"collective", "direct"}
+    assert d["rccl"]["rccl_log"] and d["rccl"]["rccl_log"].get("lines", 0) > 0
 
 
 def test_bench_self_launch_two_ranks_shared_gpu():

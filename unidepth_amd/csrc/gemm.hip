@@ -1336,6 +1336,9 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const UdGemm p) {
           int hp, cpos, iy, ix;
           bool ok;
           halo_coord(i, hp, cpos, iy, ix, ok);
+          // a tile overhanging the bottom / right border reflects halo rows far ABOVE the patch (2 Himg - 2 - iy < ylo): those feed unused
+          // outputs only, but their source pixels are not in the staged patch -- write zeros instead of reading LDS out of range
+          ok = ok && iy >= ylo && iy <= yhi && ix >= xlo && ix <= xhi;
           half8 o8;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o8[e] = (half_t)0.f;

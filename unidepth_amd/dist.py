@@ -17,15 +17,46 @@ def shard_bounds(n_images: int, world: int) -> List[Tuple[int, int]]:
     return [(min(r * per, n_images), min((r + 1) * per, n_images)) for r in range(world)]
 
 
-def all_gather_batch(t: torch.Tensor, counts: List[int], group=None) -> torch.Tensor:
-    """All-gather tensors whose dim 0 differs per rank (counts[r] rows on rank r): pad to max, one all_gather_into_tensor,
+# How the one exchange step is issued.  xGMI on an MI355X node is a full mesh of point-to-point links (7 x ~153 GB/s per GPU, no
+# switch): a RING all-gather forwards every block over world-1 hops, each hop bound by ONE link, so an S-byte-per-rank gather costs
+# ~ (world-1) S / 153 GB/s; the DIRECT form -- every rank sends its block to each peer over that peer's own link, all links busy at
+# once -- costs ~ S / 153 GB/s (0.65 ms against 4.6 ms for 100 MB).  "collective" leaves the choice to RCCL
+# (all_gather_into_tensor: ring / tree / its own direct kernels per message size); "direct" spells the all-pairs exchange out as
+# world-1 sends + world-1 receives inside one ncclGroupStart / End (dist.batch_isend_irecv) -- no copy through an intermediate rank.
+GATHER_ALGOS = ("collective", "direct")
+DEFAULT_GATHER_ALGO = "collective"
+
+
+def all_gather_direct(out: torch.Tensor, mine: torch.Tensor, group=None) -> None:
+    """out [world * n, ...] <- every rank's `mine` [n, ...] (same shape on all ranks), as an all-pairs send / receive group."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = mine.shape[0]
+    out[rank * n:(rank + 1) * n].copy_(mine)
+    ops = []
+    for k in range(1, world):                          # peer order rotated per rank: every step of the group pairs distinct links
+        dst, src = (rank + k) % world, (rank - k) % world
+        ops.append(dist.P2POp(dist.isend, mine, dist.get_global_rank(group, dst) if group is not None else dst, group))
+        ops.append(dist.P2POp(dist.irecv, out[src * n:(src + 1) * n], dist.get_global_rank(group, src) if group is not None else src, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+
+def all_gather_batch(t: torch.Tensor, counts: List[int], group=None, algo: Optional[str] = None) -> torch.Tensor:
+    """All-gather tensors whose dim 0 differs per rank (counts[r] rows on rank r): pad to max, one exchange (`algo`: see GATHER_ALGOS),
     trim.  Works on any backend (RCCL on GPUs, gloo on CPU for the tests)."""
+    algo = algo or DEFAULT_GATHER_ALGO
+    if algo not in GATHER_ALGOS:
+        raise ValueError(f"gather algo {algo!r}: one of {GATHER_ALGOS}")
     world = dist.get_world_size(group)
     mx = max(counts)
     pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     pad[: t.shape[0]] = t
     buf = torch.empty((world * mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(buf, pad, group=group)
+    if algo == "direct":
+        all_gather_direct(buf, pad, group)
+    else:
+        dist.all_gather_into_tensor(buf, pad, group=group)
     if all(c == mx for c in counts):
         return buf
     return torch.cat([buf[r * mx: r * mx + counts[r]] for r in range(world)], dim=0)
@@ -45,7 +76,7 @@ def _camera_count(camera) -> int:
 
 
 def infer_data_parallel(model, rgb: torch.Tensor, camera=None, keys: Optional[Iterable[str]] = ("depth", "confidence", "intrinsics"),
-                        group=None, **kw) -> Dict[str, torch.Tensor]:
+                        group=None, gather_algo: Optional[str] = None, **kw) -> Dict[str, torch.Tensor]:
     """Every rank passes the SAME global batch `rgb` [B,3,H,W] (any device); rank r runs infer() on its contiguous shard and
     all ranks return the gathered global outputs for `keys` (None = all seven).  A single camera broadcasts; a per-image
     camera batch is sharded like the images."""
@@ -73,7 +104,7 @@ def infer_data_parallel(model, rgb: torch.Tensor, camera=None, keys: Optional[It
         # ONE collective for all requested outputs: per-image rows are concatenated, gathered, and split again
         widths = [int(torch.Size(out[k].shape[1:]).numel()) for k in packable]
         packed = torch.cat([out[k].reshape(out[k].shape[0], wdt) for k, wdt in zip(packable, widths)], dim=1)
-        g = all_gather_batch(packed.contiguous(), counts, group)
+        g = all_gather_batch(packed.contiguous(), counts, group, gather_algo)
         off = 0
         for k, wdt in zip(packable, widths):
             res[k] = g[:, off:off + wdt].reshape((g.shape[0],) + tuple(out[k].shape[1:]))
@@ -84,7 +115,7 @@ def infer_data_parallel(model, rgb: torch.Tensor, camera=None, keys: Optional[It
         if k == "rays" and rays_shared:
             res[k] = t[:1] if t.shape[0] else model.infer(rgb[:1], camera, **kw)["rays"][:1]   # identical on every rank, nothing to exchange
             continue
-        res[k] = all_gather_batch(t.contiguous(), counts, group)
+        res[k] = all_gather_batch(t.contiguous(), counts, group, gather_algo)
     return res
 
 
@@ -170,6 +201,10 @@ def infer_mixed(model, images: List[torch.Tensor], cameras: Optional[List[Option
     if inflight > 1 and hasattr(model, "_plans") and images and images[0].is_cuda:
         from .pipeline import InferPipeline
         pipe = InferPipeline(model, depth=inflight)
+    if hasattr(model, "reserve_plans"):
+        # every (micro-batch size, shape, camera mode) of this rank may land on every pipeline slot: keep the whole cycle cached
+        sigs = {(len(idx), s, bool(cameras is not None and any(cameras[i] is not None for i in idx))) for (s, idx), r in zip(micro, owner) if r == rank}
+        model.reserve_plans(len(sigs) * max(1, inflight) + 2)
     submitted = []
     for (s, idx), r in zip(micro, owner):
         if r != rank:

@@ -400,8 +400,7 @@ class UniDepthV1:
     def _enc_plan(self, B, Hn, Wn) -> _EncPlan:
         key = ("enc", B, Hn, Wn)
         if key not in self._plans:
-            while len(self._plans) >= self.max_plans:
-                self._plans.popitem(last=False)
+            self._evict()
             with torch.cuda.device(self._device):
                 self._plans[key] = _EncPlan(self, B, Hn, Wn)
         self._plans.move_to_end(key)
@@ -471,15 +470,22 @@ class UniDepthV1:
     def _full_plan(self, *sig) -> "_FullPlan":
         key = ("full",) + tuple(sig)
         if key not in self._plans:
-            while len(self._plans) >= self.max_plans:
-                self._plans.popitem(last=False)
+            self._evict()
             with torch.cuda.device(self._device):
                 self._plans[key] = _FullPlan(self, *sig)
         self._plans.move_to_end(key)
         return self._plans[key]
 
+    def _evict(self) -> None:
+        if len(self._plans) >= self.max_plans:
+            torch.cuda.synchronize(self._device)          # the evicted program may still be queued on another stream
+            while len(self._plans) >= self.max_plans:
+                self._plans.popitem(last=False)
+
     def clear_plans(self) -> None:
         """Drop every cached launch program and its activation buffers (they are rebuilt on the next call)."""
+        if self._plans and self._device.type == "cuda":
+            torch.cuda.synchronize(self._device)
         self._plans.clear()
 
     @torch.no_grad()

@@ -138,7 +138,7 @@ class _Plan:
         self.enc_first = len(P)
         lvl = 0
         for i in range(a["depth"]):
-            P.layernorm(x=x, y=xn, rows=M, D=D, ldx=D, ldy=D, eps=1e-6, rows_per_img=M, in_rows_per_img=M, out_rows_per_img=M)
+            P.layernorm(x=x, y=xn, rows=M, D=D, ldx=D, ldy=D, eps=1e-6, rows_per_img=M, in_rows_per_img=M, out_rows_per_img=M, tag="enc.ln")
             P.gemm(A=xn, W=w[f"enc.{i}.qkv.w"], bias=w[f"enc.{i}.qkv.b"], out=qk, out2=vt, M=M, N=3 * D, K=D, lda=D, ldw=D,
                    ldc=2 * D, epi=UD_EPI_QKV, vsplit=2 * D, tok_per_img=Np, kv_ld=Nkp, heads_v=heads, tag="enc.qkv",
                    flops=2.0 * B * N * 3 * D * D)
@@ -154,7 +154,7 @@ class _Plan:
                         kv_ld=Nkp, q_rows_per_img=Np, k_rows_per_img=Np, scale=(D // heads) ** -0.5, q_prescaled=1, tag="enc.attn")
             P.gemm(A=ao, W=w[f"enc.{i}.proj.w"], bias=w[f"enc.{i}.proj.b"], out=x, M=M, N=D, K=D, lda=D, ldw=D, ldc=D,
                    epi=UD_EPI_F32, accumulate=1, tag="enc.proj", flops=2.0 * B * N * D * D)
-            P.layernorm(x=x, y=xn, rows=M, D=D, ldx=D, ldy=D, eps=1e-6, rows_per_img=M, in_rows_per_img=M, out_rows_per_img=M)
+            P.layernorm(x=x, y=xn, rows=M, D=D, ldx=D, ldy=D, eps=1e-6, rows_per_img=M, in_rows_per_img=M, out_rows_per_img=M, tag="enc.ln")
             P.gemm(A=xn, W=w[f"enc.{i}.fc1.w"], bias=w[f"enc.{i}.fc1.b"], out=hid, M=M, N=4 * D, K=D, lda=D, ldw=D, ldc=4 * D,
                    epi=UD_EPI_F16, act=UD_ACT_GELU, tag="enc.fc1", flops=8.0 * B * N * D * D)
             P.gemm(A=hid, W=w[f"enc.{i}.fc2.w"], bias=w[f"enc.{i}.fc2.b"], out=x, M=M, N=D, K=4 * D, lda=4 * D, ldw=4 * D, ldc=D,
@@ -407,7 +407,14 @@ class UniDepthV2:
 
     def clear_plans(self):
         """Drop every cached launch plan (device activation buffers of all (batch, shape, camera, slot) signatures seen so far)."""
+        if self._plans and self._device.type == "cuda":
+            torch.cuda.synchronize(self._device)          # programs of these plans may still be queued on pipeline streams
         self._plans.clear()
+
+    def reserve_plans(self, n: int):
+        """Make room for `n` distinct plan signatures visited cyclically (dist.infer_mixed knows its set up front: micro-batch sizes x
+        shapes x camera modes x pipeline slots); an LRU smaller than the cycle would rebuild a ~2.6 GB plan on every call."""
+        self.max_plans = max(self.max_plans, int(n))
 
     def state_dict(self):
         return dict(self._sd)
@@ -479,8 +486,13 @@ class UniDepthV2:
         if plan is None:
             # a plan owns the full activation set of its signature (~2.6 GB for ViT-L at bs=8): the cache is an LRU of `max_plans`
             # entries, so a stream of many image shapes (KITTI / nuScenes style) cannot grow device memory without bound
-            while len(self._plans) >= max(1, self.max_plans):
-                self._plans.popitem(last=False)
+            if len(self._plans) >= max(1, self.max_plans):
+                # the evicted plan's buffers go back to the caching allocator of whatever stream allocated them, while its launch
+                # program may still be queued on ANOTHER stream (pipeline slots): drain the device first -- rare, and a plan rebuild
+                # costs far more than this sync
+                torch.cuda.synchronize(self._device)
+                while len(self._plans) >= max(1, self.max_plans):
+                    self._plans.popitem(last=False)
             with torch.cuda.device(self._device):
                 plan = _Plan(self, B, H, W, cam_nb, is_u8, normalize, bounds, gt_mode, net)
             self._plans[key] = plan
