@@ -102,6 +102,21 @@ typedef struct UdGemm {
    * and the log-depth of every pixel coherently; tools/v1_precision_study.py), unlike the activations' rounding which averages out.
    * Three terms [A_hi | A_lo | A_hi] x [W_hi | W_hi | W_lo] (a_wrap = 2 K) give an fp32-class product. */
   int a_wrap, w_wrap;
+  /* LayerNorm folded into a producer / consumer pair of GEMMs (large-tile kernel, dense A; reference metadinov2/block.py:85-89 norm1 /
+   * norm2 between `x += proj(..)` / `x += fc2(..)` and the following qkv / fc1 Linear): no second pass over the fp32 stream.
+   *   producer (UD_EPI_F32): row_stats_out [M][N / 64][2] fp32 = (sum, sum of squares) of the STORED fp32 row values over every
+   *     64-column slab (one entry per wave of the tile; fixed order: bit-reproducible); out2 = the raw fp16 copy of the row.
+   *   ud_row_stats_finalize: [M][slabs][2] -> [M][2] = (rstd, -mean * rstd), slabs <= 16 summed in one fixed butterfly order.
+   *   consumer (UD_EPI_F16 / UD_EPI_QKV): A = the raw fp16 copy, row_stats_in = the finalized [M][2]; the epilogue stores
+   *     act(rstd * acc - mean * rstd * wsum[n] + bias[n]), wsum[n] = sum_k W[n, k] over the fp16-ROUNDED weights (the LayerNorm's affine
+   *     folded into W / bias as before): rstd (x - mean) W^T = rstd (x W^T - mean 1 W^T).  fp16(x) carries the same 2^-11 relative
+   *     rounding as fp16(LN(x)) when |mean| <~ std, which holds for residual streams (tap tests).  At most 4 tiles per workgroup.
+   *   ln_slabs / ln_D / ln_eps are read by ud_row_stats_finalize's caller only (kept in the descriptor for program recording). */
+  float* row_stats_out;
+  const float* row_stats_in;
+  const float* wsum;
+  int ln_slabs, ln_D;
+  float ln_eps;
 } UdGemm;
 
 int ud_gemm_f16(const UdGemm* desc, void* stream);
@@ -127,6 +142,10 @@ typedef struct UdLayerNorm {
                            * image (out_row_off + p): `features + pos_embed` ahead of an MLP's norm (unidepthv1/decoder.py:80-83). */
 } UdLayerNorm;
 int ud_layernorm_f32_f16(const UdLayerNorm* desc, void* stream);
+
+/* partial (sum, sum of squares) pairs of UdGemm.row_stats_out [M][slabs][2] -> stats [M][2] = (rstd, -mean * rstd) with mean = S1 / D,
+ * rstd = rsqrt(max(S2 / D - mean^2, 0) + eps) (biased variance, F.layer_norm): what UdGemm.row_stats_in consumes. */
+int ud_row_stats_finalize(const float* partials, float* stats, int M, int slabs, int D, float eps, void* stream);
 
 /* ---- fp32 small-M linear layer (camera head only) ---------------------------------------------------------
  * out[m, n] (+)= act(sum_k x[m,k] W[n,k] + bias[n] + add[m % add_mod, n]),  everything fp32, exact-erf GELU.
@@ -344,6 +363,7 @@ void ud_program_destroy(UdProgram*);
 int ud_program_size(const UdProgram*);
 int ud_program_add_gemm(UdProgram*, const UdGemm*);
 int ud_program_add_layernorm(UdProgram*, const UdLayerNorm*);
+int ud_program_add_row_stats_finalize(UdProgram*, const float* partials, float* stats, int M, int slabs, int D, float eps);
 int ud_program_add_attention(UdProgram*, const UdAttention*);
 int ud_program_add_linear_f32(UdProgram*, const UdLinearF32*);
 int ud_program_add_attention_small_f32(UdProgram*, const float* q, const float* kv, float* out, int B, int T, int H, int C, float scale);

@@ -394,6 +394,105 @@ def test_gemm_conv3x3_big_tiles(ops, hint, Cin, Cout, H, W):
     assert rel(l16.view(B, rows_img, Cout)[:, :H * W].float(), F.leaky_relu(want, 0.01)) < 1e-3
 
 
+def _ln_fold_pair(ops, x0, A1, W1, b1, W2, b2, hint1, hint2, epi2, D, eps=1e-6):
+    """x = x0 + A1 W1^T + b1 (producer: raw fp16 copy + row partial sums), then epi2(LN(x) W2^T + b2) through the folded consumer."""
+    M = x0.shape[0]
+    x = x0.clone()
+    x16 = torch.zeros(M, D, dtype=torch.half, device="cuda")
+    stats = torch.zeros(M, D // 64, 2, device="cuda")
+    K1 = A1.shape[1]
+    ops.gemm(A=A1, W=W1, bias=b1, out=x, out2=x16, M=M, N=D, K=K1, lda=K1, ldw=K1, ldc=D, ldc2=D, epi=ops.UD_EPI_F32, accumulate=1,
+             tile_hint=hint1, row_stats_out=stats)
+    N2 = W2.shape[0]
+    wsum = W2.double().sum(dim=1).float().contiguous()
+    fin = torch.zeros(M, 2, device="cuda")
+    ops.row_stats_finalize(stats, fin, M, D // 64, D, eps)
+    lnc = dict(row_stats_in=fin, wsum=wsum, ln_slabs=D // 64, ln_D=D, ln_eps=eps)
+    if epi2 == ops.UD_EPI_F16:
+        out = torch.zeros(M, N2, dtype=torch.half, device="cuda")
+        ops.gemm(A=x16, W=W2, bias=b2, out=out, M=M, N=N2, K=D, lda=D, ldw=D, ldc=N2, epi=ops.UD_EPI_F16, act=ops.UD_ACT_GELU, tile_hint=hint2, **lnc)
+        return x, x16, stats, out, None
+    Dq = N2 // 3
+    Np = 1376
+    B = M // Np
+    qk = torch.zeros(M, 2 * Dq, dtype=torch.half, device="cuda")
+    vt = torch.zeros(B, Dq // 64, 64, 1408, dtype=torch.half, device="cuda")
+    ops.gemm(A=x16, W=W2, bias=b2, out=qk, out2=vt, M=M, N=N2, K=D, lda=D, ldw=D, ldc=2 * Dq, epi=ops.UD_EPI_QKV, vsplit=2 * Dq, tok_per_img=Np,
+             kv_ld=1408, heads_v=Dq // 64, tile_hint=hint2, **lnc)
+    return x, x16, stats, qk, vt
+
+
+@pytest.mark.parametrize("D,hint1,hint2", [(1024, 3, 8), (1024, 2, 3), (768, 3, 2), (384, 2, 3)])
+def test_gemm_layernorm_fold_fc1(ops, D, hint1, hint2):
+    """LayerNorm folded into a producer / consumer pair (UdGemm.row_stats_out / row_stats_in): proj-like accumulate writes the raw fp16
+    copy and 64-column partial sums, the fc1-like consumer normalises in its epilogue.  Against fp32 torch: x, the partial sums, and
+    GELU(LN(x) W^T + b); edge tiles in M (M is not a multiple of 192 / 256), ViT-S/B/L widths (6 / 12 / 16 slabs)."""
+    M = 4 * 1376 + 32
+    x0 = rnd(M, D, seed=1) * (1.0 + 3.0 * (torch.arange(D, device="cuda") % 97 == 0))          # a few large channels, like a real residual stream
+    x0 = x0 + 0.3                                                                                # non-zero row mean
+    A1 = rnd(M, D, seed=2).half(); W1 = rnd(D, D, scale=D ** -0.5, seed=3).half(); b1 = rnd(D, seed=4)
+    W2 = rnd(4 * D, D, scale=D ** -0.5, seed=5).half(); b2 = rnd(4 * D, seed=6)
+    x, x16, stats, out, _ = _ln_fold_pair(ops, x0, A1, W1, b1, W2, b2, hint1, hint2, ops.UD_EPI_F16, D)
+    torch.cuda.synchronize()
+    xr = x0 + A1.float() @ W1.float().t() + b1
+    assert rel(x, xr) < 2e-5 and rel(x16.float(), xr) < 4e-4
+    sl = x.view(M, D // 64, 64)
+    assert rel(stats[..., 0], sl.sum(-1)) < 1e-5 and rel(stats[..., 1], (sl * sl).sum(-1)) < 1e-5
+    ref = F.gelu(F.layer_norm(x, (D,), eps=1e-6) @ W2.float().t() + b2)
+    assert rel(out.float(), ref) < 1.5e-3, rel(out.float(), ref)
+    # against the classic path (LayerNorm kernel -> fp16 xn -> GEMM): same accuracy class
+    xn = torch.zeros(M, D, dtype=torch.half, device="cuda")
+    ops.layernorm(x=x, y=xn, rows=M, D=D, ldx=D, ldy=D, eps=1e-6, rows_per_img=M, in_rows_per_img=M, out_rows_per_img=M)
+    out_c = torch.zeros_like(out)
+    ops.gemm(A=xn, W=W2, bias=b2, out=out_c, M=M, N=4 * D, K=D, lda=D, ldw=D, ldc=4 * D, epi=ops.UD_EPI_F16, act=ops.UD_ACT_GELU)
+    torch.cuda.synchronize()
+    assert rel(out.float(), ref) < 1.5 * rel(out_c.float(), ref) + 1e-4
+
+
+def test_gemm_layernorm_fold_qkv_and_schedules_are_bit_identical(ops):
+    """The folded consumer with the Q|K / V^T epilogue, and: every tile schedule (192-row list, 256-row list, row-balanced) and every
+    position of an image in the batch give the same BITS per row (one summation order for a row's statistics, the same fma order in
+    the straight-line and the edge-tile epilogues)."""
+    D, B, Np = 1024, 4, 1376
+    M = B * Np
+    x0 = rnd(M, D, seed=1) + 0.2
+    A1 = rnd(M, D, seed=2).half(); W1 = rnd(D, D, scale=D ** -0.5, seed=3).half(); b1 = rnd(D, seed=4)
+    W2 = rnd(3 * D, D, scale=D ** -0.5, seed=5).half(); b2 = rnd(3 * D, seed=6)
+    base = _ln_fold_pair(ops, x0, A1, W1, b1, W2, b2, 3, 3, ops.UD_EPI_QKV, D)
+    torch.cuda.synchronize()
+    x, _, _, qk, vt = base
+    ref = F.layer_norm(x, (D,), eps=1e-6) @ W2.float().t() + b2
+    assert rel(qk.float(), ref[:, :2 * D]) < 1.5e-3
+    want = ref[:, 2 * D:].view(B, Np, D // 64, 64).permute(0, 2, 3, 1)
+    assert rel(vt[..., vt_cols(Np)].float(), want) < 1.5e-3
+    for h1, h2 in ((2, 2), (3, 8), (2, 3)):
+        other = _ln_fold_pair(ops, x0, A1, W1, b1, W2, b2, h1, h2, ops.UD_EPI_QKV, D)
+        torch.cuda.synchronize()
+        for a, b in zip(base, other):
+            assert torch.equal(a, b), (h1, h2)
+    # images rotated by one position in the batch: every row keeps its bits
+    rot = lambda t: torch.roll(t.view(B, Np, -1), 1, dims=0).reshape(M, -1).contiguous()
+    moved = _ln_fold_pair(ops, rot(x0), rot(A1), W1, b1, W2, b2, 3, 3, ops.UD_EPI_QKV, D)
+    torch.cuda.synchronize()
+    assert torch.equal(rot(base[0]), moved[0]) and torch.equal(rot(base[3]), moved[3])
+    assert torch.equal(torch.roll(base[4], 1, dims=0), moved[4])
+    # fc1-like consumer on the same producer: tile list vs row-balanced schedule
+    W3 = rnd(4 * D, D, scale=D ** -0.5, seed=7).half(); b3 = rnd(4 * D, seed=8)
+    f_a = _ln_fold_pair(ops, x0, A1, W1, b1, W3, b3, 3, 2, ops.UD_EPI_F16, D)
+    f_b = _ln_fold_pair(ops, x0, A1, W1, b1, W3, b3, 3, 8, ops.UD_EPI_F16, D)
+    torch.cuda.synchronize()
+    assert torch.equal(f_a[3], f_b[3])
+
+
+def test_gemm_layernorm_fold_rejects_unsupported(ops):
+    A = rnd(256, 64, seed=1).half(); W = rnd(128, 64, seed=2).half(); out = torch.zeros(256, 128, dtype=torch.half, device="cuda")
+    st = torch.zeros(256, 2, device="cuda"); ws = torch.zeros(128, device="cuda")
+    with pytest.raises(RuntimeError):          # too small for the large-tile kernel
+        ops.gemm(A=A, W=W, out=out, M=256, N=128, K=64, lda=64, ldw=64, ldc=128, epi=ops.UD_EPI_F16, row_stats_in=st, wsum=ws, ln_slabs=2, ln_D=128, ln_eps=1e-6)
+    with pytest.raises(RuntimeError):          # statistics only from the fp32 epilogue
+        ops.gemm(A=A, W=W, out=out, M=256, N=128, K=64, lda=64, ldw=64, ldc=128, epi=ops.UD_EPI_F16, row_stats_out=st)
+
+
 def _split16(w):
     hi = w.half()
     return hi, (w - hi.float()).half()

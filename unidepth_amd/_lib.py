@@ -32,6 +32,7 @@ class UdGemm(C.Structure):
         ("gA", i64), ("gW", i64), ("gBias", i64), ("gOut", i64), ("gOut2", i64), ("gW2", i64),
         ("b2_g1", f32), ("post_add_g1", f32), ("tile_hint", i32),
         ("splitk_ws", vp), ("splitk_cnt", vp), ("Hsrc", i32), ("Wsrc", i32), ("a_wrap", i32), ("w_wrap", i32),
+        ("row_stats_out", fp), ("row_stats_in", fp), ("wsum", fp), ("ln_slabs", i32), ("ln_D", i32), ("ln_eps", f32),
     ]
 
 
@@ -114,6 +115,8 @@ def _load():
         "ud_gemm_pick": [P(UdGemm)],
         "ud_layernorm_f32_f16": [P(UdLayerNorm), vp],
         "ud_attention_f16": [P(UdAttention), vp],
+        "ud_row_stats_finalize": [vp, vp, i32, i32, i32, f32, vp],
+        "ud_program_add_row_stats_finalize": [vp, vp, vp, i32, i32, i32, f32],
         "ud_linear_f32": [P(UdLinearF32), vp],
         "ud_attention_small_f32": [vp, vp, vp, i32, i32, i32, i32, f32, vp],
         "ud_program_add_linear_f32": [vp, P(UdLinearF32)],

@@ -29,6 +29,9 @@ __device__ unsigned long long* ud_trace_ptr = nullptr;
 
 namespace {
 
+constexpr int UD_LNC_TILES = 4;                  // tiles per workgroup the folded-LayerNorm consumer holds statistics for
+constexpr int UD_LNC_PLANE = UD_LNC_TILES * 256; // floats per plane of its LDS table: [tiles][256] rstd, then [tiles][256] -mean * rstd
+
 template <int BN_, int WM_, int WN_>
 struct Cfg {
   static constexpr int BM = 128, BN = BN_, BK = 64, WM = WM_, WN = WN_;
@@ -57,6 +60,41 @@ struct ConvLane {
 // residual-as-accumulator-init: for `out += A W^T` epilogues the old fp32 values are loaded into the accumulators BEFORE the
 // K loop (overlapping the first operand DMA) instead of being re-read in the epilogue, where every tile of a one-round GEMM
 // would hit HBM at the same moment; the epilogue then only writes.
+// ---- LayerNorm folded into a producer / consumer pair of GEMMs (UdGemm.row_stats_out / row_stats_in, include/unidepth_hip.h).
+// Every formula below is written with explicit fma / add order and shared by the straight-line and the edge-tile epilogues: an
+// element's bits must not depend on which path its tile took (batch-permutation equivariance of infer(), bit-identical schedules).
+__device__ __forceinline__ void ud_row_stats_acc(const f32x4 v, float& s1, float& s2) {     // one lane's 4 columns of a 16-column tile
+  s1 += (v[0] + v[1]) + (v[2] + v[3]);
+  s2 = __builtin_fmaf(v[0], v[0], s2);
+  s2 = __builtin_fmaf(v[1], v[1], s2);
+  s2 = __builtin_fmaf(v[2], v[2], s2);
+  s2 = __builtin_fmaf(v[3], v[3], s2);
+}
+__device__ __forceinline__ void ud_row_stats_store(const UdGemm& p, float s1, float s2, int m, int nbase, int lane, bool ok) {
+  // the 4 lanes (lane & 15, lane >> 4 = 0..3) of a row hold its 64-column slab in 16-column pieces: (s[0] + s[1]) + (s[2] + s[3])
+  s1 += __shfl_xor(s1, 16, 64);
+  s2 += __shfl_xor(s2, 16, 64);
+  s1 += __shfl_xor(s1, 32, 64);
+  s2 += __shfl_xor(s2, 32, 64);
+  if (ok && nbase < p.N && (lane >> 4) == 0) {
+    f32x2 o;
+    o[0] = s1; o[1] = s2;
+    *(f32x2*)(p.row_stats_out + ((size_t)m * (p.N >> 6) + (nbase >> 6)) * 2) = o;
+  }
+}
+// consumer: out = rstd * (x W^T - mean wsum) + bias as two fmas in this order: fma(acc, rstd, fma(nmr, wsum, bias)), nmr = -mean * rstd.
+// (Starting the accumulators at -mean * wsum instead -- one fma in the epilogue -- makes all of them live from the top of the tile,
+// where the zero-initialised ones come to life one MFMA phase at a time: 70-350 spilled registers in the Q|K / V^T instantiations.)
+__device__ __forceinline__ float ud_ln_apply(float acc, float rs, float nmr, float ws, float bias) {
+  return __builtin_fmaf(acc, rs, __builtin_fmaf(nmr, ws, bias));
+}
+__device__ __forceinline__ f32x4 ud_ln_apply4(f32x4 acc, float rs, float nmr, f32x4 ws, f32x4 bias) {
+  f32x4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = ud_ln_apply(acc[r], rs, nmr, ws[r], bias[r]);
+  return o;
+}
+
 template <int TM, int TN, int TMA>      // TM row tiles used of an accumulator array of TMA (deduced)
 __device__ __forceinline__ void gemm_preload_acc(const UdGemm& p, f32x4 (&acc)[TMA][TN], int mbase, int nbase, int lane, const char* out) {
 #pragma unroll
@@ -94,9 +132,11 @@ __device__ __forceinline__ f32x4 ud_act4_t(f32x4 v) {      // GELU on packed fp3
 
 // ACT = activation of the fp16 output (EPI_F16/QKV) or of the fp16 copy (EPI_F32/D2S), resolved ONCE per kernel by
 // gemm_epilogue below: a per-element switch on the runtime value compiled to ~700 scalar branches in the unrolled epilogue.
+// lnst: LayerNorm-folded consumer (UD_EPI_F16 / UD_EPI_QKV): rstd of the wave's rows, lnst[r] = row mbase + r (LDS)
 template <int TM, int TN, int EPI, bool SWAP, bool PRELOADED, int ACT, int TMA>
 __device__ __forceinline__ void gemm_epilogue_impl(const UdGemm& p, f32x4 (&acc)[TMA][TN], int mbase, int nbase, int lane, const float* bias,
-                                                   char* out, char* out2, const float* w2, float b2, float post_add, char* stage) {
+                                                   char* out, char* out2, const float* w2, float b2, float post_add, char* stage,
+                                                   const float* lnst = nullptr) {
   if constexpr (!SWAP) {
     // V^T tiles of UD_EPI_QKV: lane owns tokens mb..mb+3 (one image: tok_per_img % 4 == 0) for column n.
     static_assert(EPI == UD_EPI_QKV, "non-swapped orientation only for V^T");
@@ -115,8 +155,17 @@ __device__ __forceinline__ void gemm_epilogue_impl(const UdGemm& p, f32x4 (&acc)
         const int nv = n - p.vsplit;
         const int hd = nv >> 6, d = nv & 63;
         half4 h;
+        if (lnst) {
+          const float wsn = p.wsum[n];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[i][j][r] + bv);
+          for (int r = 0; r < 4; ++r) {
+            const int lr = i * 16 + 4 * (lane >> 4) + r;
+            h[r] = (half_t)ud_ln_apply(acc[i][j][r], lnst[lr], lnst[UD_LNC_PLANE + lr], wsn, bv);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[r] = (half_t)(acc[i][j][r] + bv);
+        }
         // V^T key order inside every aligned 16-key group: 4-key blocks [0, 2, 1, 3] (include/unidepth_hip.h, UD_EPI_QKV)
         const int tp = (t & ~15) | ((t & 4) << 1) | ((t & 8) >> 1);
         *(half4*)(vt + (((size_t)img * p.heads_v + hd) * 64 + d) * p.kv_ld + tp) = h;
@@ -206,6 +255,7 @@ __device__ __forceinline__ void gemm_epilogue_impl(const UdGemm& p, f32x4 (&acc)
         }
         continue;
       }
+      float rs1 = 0.f, rs2 = 0.f;                   // row statistics of the stored fp32 values (UD_EPI_F32 producer of a folded LayerNorm)
       if constexpr (EPI == UD_EPI_D2S) {
         // m -> (img, y, x) on the input grid
         const int img = m / p.d2s_rows_in_img;
@@ -242,7 +292,10 @@ __device__ __forceinline__ void gemm_epilogue_impl(const UdGemm& p, f32x4 (&acc)
         const int nb = nbase + j * 16 + 4 * (lane >> 4);
         if (!mok || nb >= p.N) continue;
         f32x4 v = acc[i][j];
-        if (bias) {
+        if (lnst) {
+          const int lr = i * 16 + (lane & 15);
+          v = ud_ln_apply4(v, lnst[lr], lnst[UD_LNC_PLANE + lr], *(const f32x4*)(p.wsum + nb), bias ? *(const f32x4*)(bias + nb) : (f32x4){0.f, 0.f, 0.f, 0.f});
+        } else if (bias) {
           const f32x4 bv = *(const f32x4*)(bias + nb);
           v += bv;
         }
@@ -270,6 +323,7 @@ __device__ __forceinline__ void gemm_epilogue_impl(const UdGemm& p, f32x4 (&acc)
             for (int r = 0; r < 4; ++r) v[r] = ud_clampexp(v[r]);
           }
           if (p.accumulate != 2) *(f32x4*)dst = v;     // accumulate == 2: the fp32 stream dies here, only the fp16 copy is consumed
+          ud_row_stats_acc(v, rs1, rs2);
           if (out2) {
             half4 h;
 #pragma unroll
@@ -278,20 +332,24 @@ __device__ __forceinline__ void gemm_epilogue_impl(const UdGemm& p, f32x4 (&acc)
           }
         }
       }
+      if constexpr (EPI == UD_EPI_F32 && TN == 4) {
+        if (p.row_stats_out) ud_row_stats_store(p, rs1, rs2, orow, nbase, lane, mok);
+      }
     }
   }
 }
 
 template <int TM, int TN, int EPI, bool SWAP, bool PRELOADED = false, int TMA = TM>
 __device__ __forceinline__ void gemm_epilogue(const UdGemm& p, f32x4 (&acc)[TMA][TN], int mbase, int nbase, int lane, const float* bias,
-                                              char* out, char* out2, const float* w2, float b2, float post_add, char* stage) {
+                                              char* out, char* out2, const float* w2, float b2, float post_add, char* stage,
+                                              const float* lnst = nullptr) {
   const int a = (EPI == UD_EPI_F16 || EPI == UD_EPI_QKV) ? p.act : p.act2;
   if constexpr (EPI == UD_EPI_HEAD || EPI == UD_EPI_QKV) {
-    gemm_epilogue_impl<TM, TN, EPI, SWAP, PRELOADED, UD_ACT_NONE>(p, acc, mbase, nbase, lane, bias, out, out2, w2, b2, post_add, stage);
+    gemm_epilogue_impl<TM, TN, EPI, SWAP, PRELOADED, UD_ACT_NONE>(p, acc, mbase, nbase, lane, bias, out, out2, w2, b2, post_add, stage, lnst);
   } else if constexpr (EPI == UD_EPI_F16) {
-    if (a == UD_ACT_GELU) gemm_epilogue_impl<TM, TN, EPI, SWAP, PRELOADED, UD_ACT_GELU>(p, acc, mbase, nbase, lane, bias, out, out2, w2, b2, post_add, stage);
-    else if (a == UD_ACT_LRELU) gemm_epilogue_impl<TM, TN, EPI, SWAP, PRELOADED, UD_ACT_LRELU>(p, acc, mbase, nbase, lane, bias, out, out2, w2, b2, post_add, stage);
-    else gemm_epilogue_impl<TM, TN, EPI, SWAP, PRELOADED, UD_ACT_NONE>(p, acc, mbase, nbase, lane, bias, out, out2, w2, b2, post_add, stage);
+    if (a == UD_ACT_GELU) gemm_epilogue_impl<TM, TN, EPI, SWAP, PRELOADED, UD_ACT_GELU>(p, acc, mbase, nbase, lane, bias, out, out2, w2, b2, post_add, stage, lnst);
+    else if (a == UD_ACT_LRELU) gemm_epilogue_impl<TM, TN, EPI, SWAP, PRELOADED, UD_ACT_LRELU>(p, acc, mbase, nbase, lane, bias, out, out2, w2, b2, post_add, stage, lnst);
+    else gemm_epilogue_impl<TM, TN, EPI, SWAP, PRELOADED, UD_ACT_NONE>(p, acc, mbase, nbase, lane, bias, out, out2, w2, b2, post_add, stage, lnst);
   } else {
     if (a == UD_ACT_LRELU) gemm_epilogue_impl<TM, TN, EPI, SWAP, PRELOADED, UD_ACT_LRELU>(p, acc, mbase, nbase, lane, bias, out, out2, w2, b2, post_add, stage);
     else gemm_epilogue_impl<TM, TN, EPI, SWAP, PRELOADED, UD_ACT_NONE>(p, acc, mbase, nbase, lane, bias, out, out2, w2, b2, post_add, stage);
@@ -628,6 +686,8 @@ struct BigCfg {
 };
 
 template <bool B> struct BoolTag { static constexpr bool value = B; };
+constexpr int LNC_TILES = UD_LNC_TILES;
+constexpr int LNC_LDS = 2 * UD_LNC_PLANE * 4;    // the two planes, behind the operand ring
 
 // two packed-fp16 dwords of column tiles j / j+1 -> 8 consecutive columns per lane (see the layout note in the kernel)
 __device__ __forceinline__ void ud_pair16(unsigned& a, unsigned& b) {
@@ -667,10 +727,17 @@ __device__ __forceinline__ void ud_interleave_reads() {
 // rounds, the third one 69 % full), every column of 256 outputs gets floor(256 / tiles_n) workgroups and each of them a contiguous
 // span of ceil(M / 64) / that many 64-row units (+-1), cut into tiles of 64 * {2, 3, 4} rows of near-equal height (fc1: 704 rows =
 // 256 + 256 + 192 per CU): all CUs finish together.  A tile of 64 * MHC rows runs the MHC-instantiation of the tile body.
-template <int MH, int EPI, int AMODE, bool BAL = false>
+// LNC (consumer of a folded LayerNorm, UdGemm.row_stats_in): A holds the RAW fp16 rows; the per-row (rstd, -mean) of ALL tiles of the
+// workgroup's list (at most LNC_TILES: the host checks) are copied to LDS tables at kernel start, before any accumulator is live; per
+// tile the accumulators start at -mean * wsum[n] and the epilogue multiplies by rstd -- no register lives across the K loop or the
+// epilogues for it.  (A first version reduced the producer's 16 partial pairs per row here, per tile: 32 live registers across the
+// epilogue, 55-340 spilled registers in the Q|K / V^T instantiations, +14..16 us per launch -- slower than the LayerNorm kernel it
+// replaced; the reduction is now ud_row_stats_finalize, one thread per row.)
+template <int MH, int EPI, int AMODE, bool BAL = false, bool LNC = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using C = BigCfg<MH>;
+  static_assert(!LNC || (AMODE == UD_A_DENSE && (EPI == UD_EPI_F16 || EPI == UD_EPI_QKV)), "LayerNorm-folded consumer: dense A, fp16 outputs");
   constexpr int BM = C::BM;
   constexpr int TM = 2 * MH;
   const int tid = threadIdx.x;
@@ -781,6 +848,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
 
   constexpr bool ACC_EPI = (EPI == UD_EPI_F32);        // `out (+)= ...`: old values are preloaded into the accumulators
 
+  // ---------------- LNC: (rstd, -mean) of the rows of EVERY tile this workgroup will visit, parked in LDS once at kernel start
+  float* const lds_rstd = (float*)(smem + 2 * C::STAGE);        // [LNC_TILES][256] rstd, then [LNC_TILES][256] -mean * rstd
+  float* const lds_nm = lds_rstd + UD_LNC_PLANE;
+  int tl = 0;                                                    // local index of the current tile = its table
+
   int m0, n0, mhc = MH;
   int t = blockIdx.x;          // classic: index into the tile list; balanced: index of the tile inside this workgroup's row span
   int bal_k = 0, bal_tb = 0, bal_te = 0, bal_u0 = 0, bal_n0 = 0;
@@ -827,6 +899,26 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   tile_at(t, m0, n0, mhc);
   setup(m0, n0, mhc);
   issue(0, 0, mhc);
+  if constexpr (LNC) {
+    // fill the statistics tables by LDS-DMA (4 bytes per lane, lane-linear destination = 64 consecutive rows of one plane): no VGPR holds
+    // them and nothing waits here -- they land under the first tile's K loop (its vmcnt(0) + barrier per K-tile cover them) and are
+    // first read by the first epilogue.  (Loading them through registers before the first barrier cost 10-15 us per launch.)
+    const ud_rsrc_t rS = ud_make_rsrc(p.row_stats_in, (unsigned)p.M * 8u);
+#pragma unroll
+    for (int k = 0; k < LNC_TILES; ++k) {
+      const int tt = t + k * (BAL ? 1 : (int)gridDim.x);
+      if (tt < (BAL ? bal_k : nblk) && wv < 4) {
+        int tm0, tn0, tmh;
+        tile_at(tt, tm0, tn0, tmh);
+        if (wv < tmh) {
+          int m = tm0 + wv * 64 + lane;
+          m = m < p.M ? m : p.M - 1;
+          ud_bufl4(rS, (unsigned)m * 8u, 0, lds_rstd + k * 256 + wv * 64);
+          ud_bufl4(rS, (unsigned)m * 8u + 4u, 0, lds_nm + k * 256 + wv * 64);
+        }
+      }
+    }
+  }
 
   int trace_tile = 0;
   bool first = true;
@@ -945,6 +1037,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
       kloop(BoolTag<true>{});
     }
     UD_STAMP(2);
+    const float* const lnst = LNC ? lds_rstd + tl * 256 + wm * (BMC / 2) : nullptr;   // rstd of the wave's rows
 
     // =================================== epilogue ===================================
     // Accumulator layout (SWAP): lane owns row mbase + 16 i + (lane & 15), columns nbase + 16 j + 4 q .. + 3, q = lane >> 4.
@@ -962,18 +1055,29 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
         fast = full && (p.ldc & 7) == 0;
         if (fast) {
           const int act = p.act;
-          f32x4 bv[4];
+          f32x4 bv[4], ws[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(p.bias + nbase + j * 16 + 4 * fq);
+          if constexpr (LNC) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ws[j] = *(const f32x4*)(p.wsum + nbase + j * 16 + 4 * fq);
+          }
           half_t* o = (half_t*)p.out + (size_t)(mbase + frow) * p.ldc + nbase + 16 * (fq & 1) + 8 * (fq >> 1);
           auto body = [&](auto ACT) {
             constexpr int AC = decltype(ACT)::value;
 #pragma unroll
             for (int i = 0; i < TMC; ++i) {
               unsigned w[4][2];
+              float rs = 0.f, nmr = 0.f;
+              if constexpr (LNC) {
+                rs = lnst[i * 16 + frow];
+                nmr = lnst[UD_LNC_PLANE + i * 16 + frow];
+              }
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                const f32x4 v = acc[i][j] + bv[j];
+                f32x4 v;
+                if constexpr (LNC) v = ud_ln_apply4(acc[i][j], rs, nmr, ws[j], bv[j]);
+                else v = acc[i][j] + bv[j];
                 if constexpr (AC == UD_ACT_GELU) {
                   const f32x2 g0 = ud_gelu_erf2((f32x2){v[0], v[1]}), g1 = ud_gelu_erf2((f32x2){v[2], v[3]});
                   w[j][0] = ud_pack2(g0[0], g0[1]);
@@ -1006,15 +1110,26 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
             for (int j = 0; j < 4; ++j) {
               const int n = nbase + j * 16 + frow;
               const float bvn = p.bias[n];
+              float wsn = 0.f;
+              if constexpr (LNC) wsn = p.wsum[n];
               const int nv = n - p.vsplit;
               half_t* vrow = vt + (size_t)((nv >> 6) * 64 + (nv & 63)) * p.kv_ld;
 #pragma unroll
               for (int ip = 0; ip < MHC; ++ip) {
                 unsigned w0[2], w1[2];
+                if constexpr (LNC) {                               // the lane's tokens: rows 16 (2 ip) + 4 fq + r and 16 more
+                  const f32x4 r0 = *(const f32x4*)(lnst + (2 * ip) * 16 + 4 * fq), q0 = *(const f32x4*)(lnst + UD_LNC_PLANE + (2 * ip) * 16 + 4 * fq);
+                  const f32x4 r1 = *(const f32x4*)(lnst + (2 * ip) * 16 + 4 * fq + 16), q1 = *(const f32x4*)(lnst + UD_LNC_PLANE + (2 * ip) * 16 + 4 * fq + 16);
+                  w0[0] = ud_pack2(ud_ln_apply(acc[2 * ip][j][0], r0[0], q0[0], wsn, bvn), ud_ln_apply(acc[2 * ip][j][1], r0[1], q0[1], wsn, bvn));
+                  w0[1] = ud_pack2(ud_ln_apply(acc[2 * ip][j][2], r0[2], q0[2], wsn, bvn), ud_ln_apply(acc[2 * ip][j][3], r0[3], q0[3], wsn, bvn));
+                  w1[0] = ud_pack2(ud_ln_apply(acc[2 * ip + 1][j][0], r1[0], q1[0], wsn, bvn), ud_ln_apply(acc[2 * ip + 1][j][1], r1[1], q1[1], wsn, bvn));
+                  w1[1] = ud_pack2(ud_ln_apply(acc[2 * ip + 1][j][2], r1[2], q1[2], wsn, bvn), ud_ln_apply(acc[2 * ip + 1][j][3], r1[3], q1[3], wsn, bvn));
+                } else {
                 w0[0] = ud_pack2(acc[2 * ip][j][0] + bvn, acc[2 * ip][j][1] + bvn);
                 w0[1] = ud_pack2(acc[2 * ip][j][2] + bvn, acc[2 * ip][j][3] + bvn);
                 w1[0] = ud_pack2(acc[2 * ip + 1][j][0] + bvn, acc[2 * ip + 1][j][1] + bvn);
                 w1[1] = ud_pack2(acc[2 * ip + 1][j][2] + bvn, acc[2 * ip + 1][j][3] + bvn);
+                }
                 // half-wave exchange between row tiles 2ip / 2ip+1: lane q ends up with tokens {4 (q & 1) .. +3, 8 + 4 (q & 1) .. +3}
                 // of row tile 2ip + (q >> 1), i.e. one 16-byte chunk of the [0, 2, 1, 3] block order of that 16-token group
                 ud_pair32(w0[0], w1[0]);
@@ -1043,10 +1158,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
 #pragma unroll
         for (int i = 0; i < TMC; ++i) {
           unsigned w[4][2];
+          float rs1 = 0.f, rs2 = 0.f;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const f32x4 v = acc[i][j] + bv[j];
             if (wr32) *(f32x4*)(o + (size_t)(i * 16) * p.ldc + j * 16) = v;
+            ud_row_stats_acc(v, rs1, rs2);
             if (o2) {
               f32x4 a = v;
               if (lre) {
@@ -1067,6 +1184,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
               *(u32x4*)(o2 + (size_t)(i * 16) * p.ldc2 + jp * 32) = s;
             }
           }
+          if (p.row_stats_out) ud_row_stats_store(p, rs1, rs2, mbase + i * 16 + frow, nbase, eln, true);
         }
       }
     }
@@ -1129,10 +1247,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
       // generic path: edge tiles, row remaps, `add` operands, depth-to-space (8-byte fp16 stores, per-element bounds checks)
       constexpr bool PRE = ACC_EPI;            // the residual is already inside the accumulators (in-loop or preloaded)
       if constexpr (EPI == UD_EPI_QKV) {
-        if (swap) gemm_epilogue<TMC, 4, EPI, true, PRE>(p, acc, mbase, nbase, eln, p.bias, (char*)p.out, (char*)p.out2, nullptr, 0.f, 0.f, nullptr);
-        else gemm_epilogue<TMC, 4, EPI, false, PRE>(p, acc, mbase, nbase, eln, p.bias, (char*)p.out, (char*)p.out2, nullptr, 0.f, 0.f, nullptr);
+        if (swap) gemm_epilogue<TMC, 4, EPI, true, PRE>(p, acc, mbase, nbase, eln, p.bias, (char*)p.out, (char*)p.out2, nullptr, 0.f, 0.f, nullptr, lnst);
+        else gemm_epilogue<TMC, 4, EPI, false, PRE>(p, acc, mbase, nbase, eln, p.bias, (char*)p.out, (char*)p.out2, nullptr, 0.f, 0.f, nullptr, lnst);
       } else {
-        gemm_epilogue<TMC, 4, EPI, true, PRE>(p, acc, mbase, nbase, eln, p.bias, (char*)p.out, (char*)p.out2, nullptr, 0.f, 0.f, nullptr);
+        gemm_epilogue<TMC, 4, EPI, true, PRE>(p, acc, mbase, nbase, eln, p.bias, (char*)p.out, (char*)p.out2, nullptr, 0.f, 0.f, nullptr, lnst);
       }
     }
     UD_STAMP(3);
@@ -1152,22 +1270,23 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
     m0 = m0n;
     n0 = n0n;
     mhc = mhn;
+    ++tl;
   }
 }
 
-template <int MH, int EPI, int AMODE>
+template <int MH, int EPI, int AMODE, bool LNC = false>
 int launch256(const UdGemm& d, hipStream_t s) {
   constexpr int BM = BigCfg<MH>::BM;
   const int tiles = ((d.N + 255) >> 8) * ((d.M + BM - 1) / BM);
-  const int lds = 2 * BigCfg<MH>::STAGE;
+  const int lds = 2 * BigCfg<MH>::STAGE + (LNC ? LNC_LDS : 0);
   static bool attr_set[UD_MAX_DEVICES];
   if (!ud_attr_once(attr_set)) {
-    if (hipFuncSetAttribute((const void*)gemm256_kernel<MH, EPI, AMODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)gemm256_kernel<MH, EPI, AMODE, false, LNC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       ud_set_error("ud_gemm_f16: cannot reserve the LDS ring of the large-tile kernel");
       return UD_ERR_LAUNCH;
     }
   }
-  hipLaunchKernelGGL((gemm256_kernel<MH, EPI, AMODE>), dim3(tiles < 256 ? tiles : 256), dim3(512), lds, s, d);
+  hipLaunchKernelGGL((gemm256_kernel<MH, EPI, AMODE, false, LNC>), dim3(tiles < 256 ? tiles : 256), dim3(512), lds, s, d);
   UD_CHECK_LAUNCH("ud_gemm_f16 (large tile) launch");
   return UD_OK;
 }
@@ -1192,19 +1311,19 @@ inline double bal_time(const UdGemm& d) {
   return 8.0 + (un * (30.0 / 4.0) + (k - 1) * 2.5) * ((double)d.K / 1024.0);
 }
 
-template <int EPI>
+template <int EPI, bool LNC = false>
 int launch256bal(const UdGemm& d, hipStream_t s) {
   const int tiles_n = (d.N + 255) >> 8;
   const int cpc = bal_cpc(d);
-  const int lds = 2 * BigCfg<4>::STAGE;
+  const int lds = 2 * BigCfg<4>::STAGE + (LNC ? LNC_LDS : 0);
   static bool attr_set[UD_MAX_DEVICES];
   if (!ud_attr_once(attr_set)) {
-    if (hipFuncSetAttribute((const void*)gemm256_kernel<4, EPI, UD_A_DENSE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)gemm256_kernel<4, EPI, UD_A_DENSE, true, LNC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       ud_set_error("ud_gemm_f16: cannot reserve the LDS ring of the large-tile kernel");
       return UD_ERR_LAUNCH;
     }
   }
-  hipLaunchKernelGGL((gemm256_kernel<4, EPI, UD_A_DENSE, true>), dim3(cpc * tiles_n), dim3(512), lds, s, d);
+  hipLaunchKernelGGL((gemm256_kernel<4, EPI, UD_A_DENSE, true, LNC>), dim3(cpc * tiles_n), dim3(512), lds, s, d);
   UD_CHECK_LAUNCH("ud_gemm_f16 (large tile, row-balanced) launch");
   return UD_OK;
 }
@@ -1242,8 +1361,26 @@ inline int pick_tiles(const UdGemm& d) {
   return which;
 }
 
+// tiles one workgroup of the large-tile kernel walks for this problem (the folded-LayerNorm consumer keeps one statistics table per tile)
+inline int big_tiles_per_wg(const UdGemm& d, int which) {
+  if (which == 8) {
+    const int cpc = bal_cpc(d);
+    const int U = (d.M + 63) >> 6;
+    return (((U + cpc - 1) / cpc) + 3) >> 2;
+  }
+  const int bm = which == 3 ? 192 : 256;
+  const int tiles = ((d.N + 255) >> 8) * ((d.M + bm - 1) / bm);
+  return (tiles + 255) / 256;
+}
+
 template <int EPI, int AMODE = UD_A_DENSE>
 int launch_big(const UdGemm& d, hipStream_t s, int which) {
+  if constexpr (AMODE == UD_A_DENSE && (EPI == UD_EPI_F16 || EPI == UD_EPI_QKV)) {
+    if (d.row_stats_in) {                 // consumer of a folded LayerNorm: separate instantiations (statistics table in LDS)
+      if (which == 8) return launch256bal<EPI, true>(d, s);
+      return which == 3 ? launch256<3, EPI, AMODE, true>(d, s) : launch256<4, EPI, AMODE, true>(d, s);
+    }
+  }
   if constexpr (AMODE == UD_A_DENSE && (EPI == UD_EPI_F16 || EPI == UD_EPI_F32 || EPI == UD_EPI_QKV)) {
     if (which == 8) return launch256bal<EPI>(d, s);
   }
@@ -1570,6 +1707,22 @@ extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
     ud_set_error("ud_gemm_f16: bad a_wrap / w_wrap (one operand may wrap, once: 2 * wrap >= K resp. Cin; dense: multiple of 64, conv: of 8)");
     return UD_ERR_BAD_ARG;
   }
+  if (d.row_stats_in) {
+    const int bt = d.amode == UD_A_DENSE ? pick_tiles(d) : 0;
+    if (d.amode != UD_A_DENSE || (d.epi != UD_EPI_F16 && d.epi != UD_EPI_QKV) || !d.wsum || d.add || d.rows_in || (d.N & 15) || bt == 0 ||
+        big_tiles_per_wg(d, bt) > LNC_TILES) {
+      ud_set_error("ud_gemm_f16: LayerNorm-folded consumer (row_stats_in) needs dense A, an fp16 epilogue without add / row remap, wsum, N % 16 == 0 "
+                   "and a problem the large-tile kernel takes with at most 4 tiles per workgroup (ud_gemm_pick >= 3)");
+      return UD_ERR_UNSUPPORTED;
+    }
+  }
+  if (d.row_stats_out) {
+    const int bt = d.amode == UD_A_DENSE || d.amode == UD_A_CONV3_ZERO ? pick_tiles(d) : 0;
+    if (d.epi != UD_EPI_F32 || (d.N & 63) || (bt == 0 && (d.N <= 64 || d.groups > 1))) {
+      ud_set_error("ud_gemm_f16: row_stats_out needs the fp32 epilogue, N % 64 == 0 and 64-column wave tiles (N > 64, no groups)");
+      return UD_ERR_UNSUPPORTED;
+    }
+  }
   if (d.amode == UD_A_CONV3_REFLECT_UP && d.epi != UD_EPI_HEAD) {
     ud_set_error("ud_gemm_f16: CONV3_REFLECT_UP is implemented for the HEAD epilogue only");
     return UD_ERR_UNSUPPORTED;
@@ -1645,6 +1798,7 @@ extern "C" int ud_gemm_pick(const UdGemm* desc) {
   if (conv_tile_ok(d) && (d.epi == UD_EPI_HEAD || d.epi == UD_EPI_F16)) return 5;
   if (d.epi != UD_EPI_HEAD) {
     const int bt = pick_tiles(d);
+    if (bt && d.row_stats_in && big_tiles_per_wg(d, bt) > LNC_TILES) return 0;      // the folded-LayerNorm consumer cannot take it
     if (bt) return bt;
   }
   if (d.N > 64 && d.epi != UD_EPI_D2S) {

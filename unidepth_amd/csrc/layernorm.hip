@@ -65,7 +65,42 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const UdLayerNorm p) {
   }
 }
 
+// the reduction step of a LayerNorm folded into two GEMMs (UdGemm.row_stats_out -> row_stats_in): 16 lanes per row, lane q loads the
+// (sum, sum of squares) pair of slab q (a wave reads 4 rows = 512 contiguous bytes), fixed butterfly order over the 16 lanes -- the same
+// order for every row wherever it sits, so results are bit-reproducible and independent of the image's position in the batch.
+// (One thread per row with a serial loop over its 16 strided pairs took 6.5 us for 11008 rows; this form is launch-bound.)
+__global__ __launch_bounds__(256) void row_stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats, int M, int slabs, float inv_d, float eps) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int m = gid >> 4, q = gid & 15;
+  f32x2 v = {0.f, 0.f};
+  if (m < M && q < slabs) v = *(const f32x2*)(part + ((size_t)m * slabs + q) * 2);
+  float s1 = v[0], s2 = v[1];
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  if (m < M && q == 0) {
+    const float mean = s1 * inv_d;
+    const float var = fmaxf(__builtin_fmaf(-mean, mean, s2 * inv_d), 0.0f);
+    f32x2 o;
+    o[0] = rsqrtf(var + eps);
+    o[1] = -mean * o[0];
+    *(f32x2*)(stats + 2 * (size_t)m) = o;
+  }
+}
+
 }  // namespace
+
+extern "C" int ud_row_stats_finalize(const float* partials, float* stats, int M, int slabs, int D, float eps, void* stream) {
+  if (!partials || !stats || M <= 0 || slabs <= 0 || slabs > 16 || D <= 0) {
+    ud_set_error("ud_row_stats_finalize: bad argument (1 <= slabs <= 16)");
+    return UD_ERR_BAD_ARG;
+  }
+  hipLaunchKernelGGL(row_stats_finalize_kernel, dim3((M + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, stats, M, slabs, 1.0f / (float)D, eps);
+  UD_CHECK_LAUNCH("ud_row_stats_finalize launch");
+  return UD_OK;
+}
 
 extern "C" int ud_layernorm_f32_f16(const UdLayerNorm* desc, void* stream) {
   const UdLayerNorm& d = *desc;

@@ -9,7 +9,7 @@
 void ud_set_error(const char* msg);
 
 namespace {
-enum Kind { K_LIN32, K_ATTS, K_GEMM, K_LN, K_ATTN, K_PRE, K_FILL, K_CAM, K_RAYS, K_RAYS_CAM, K_EMBED, K_UP2, K_RESIZE, K_FINAL, K_T, K_DW7, K_LNP2, K_PATCH4, K_MAX, K_MEAN, K_V1 };
+enum Kind { K_LIN32, K_ATTS, K_GEMM, K_LN, K_ATTN, K_PRE, K_FILL, K_CAM, K_RAYS, K_RAYS_CAM, K_EMBED, K_UP2, K_RESIZE, K_FINAL, K_T, K_DW7, K_LNP2, K_PATCH4, K_MAX, K_MEAN, K_V1, K_RSF };
 struct FillArgs { float* dst; const float* src; int n_img, rows_per_img, row_off, D, ld; };
 struct CamArgs { const float* raw; int raw_stride; float* intr4; float* K33; float* Kinv33; float* Kpost33; int B, Hn, Wn; float rf; int pad_l, pad_t; };
 struct RaysArgs { const float* Kinv33; float* rays; int nb, Hn, Wn, gt_mode; };
@@ -20,12 +20,13 @@ struct LnP2Args { const float* x; void* out; int B, H, W, C, ldo; float eps; };
 struct Patch4Args { const float* img; void* out; int B, H, W, ldo; };
 struct MaxArgs { float* dst; const float* src; long long n; int init; };
 struct MeanArgs { const float* x; float* out; int B, HW, C, ldo; };
+struct RsfArgs { const float* part; float* stats; int M, slabs, D; float eps; };
 struct Op {
   Kind kind;
   union {
     UdGemm gemm; UdLayerNorm ln; UdAttention attn; UdPreprocess pre; FillArgs fill; CamArgs cam; RaysArgs rays; RaysCamArgs rays_cam;
     UdRayEmbed embed; UdUpsample2x up2; UdResizeAC resize; UdFinalize fin; TArgs t; UdLinearF32 lin32; AttSArgs atts;
-    UdDwConv7 dw7; UdV1Op v1; LnP2Args lnp2; Patch4Args patch4; MaxArgs mx; MeanArgs mean;
+    UdDwConv7 dw7; UdV1Op v1; LnP2Args lnp2; Patch4Args patch4; MaxArgs mx; MeanArgs mean; RsfArgs rsf;
   };
   Op() {}
 };
@@ -96,6 +97,10 @@ int ud_program_add_spatial_mean(UdProgram* p, const float* x, float* out, int B,
 }
 
 int ud_program_add_v1_op(UdProgram* p, const UdV1Op* d) { ADD(K_V1, v1, *d) }
+int ud_program_add_row_stats_finalize(UdProgram* p, const float* partials, float* stats, int M, int slabs, int D, float eps) {
+  RsfArgs a = {partials, stats, M, slabs, D, eps};
+  ADD(K_RSF, rsf, a)
+}
 
 int ud_program_run(const UdProgram* p, int first, int last, void* stream) {
   if (!p || first < 0 || last > (int)p->ops.size() || first > last) { ud_set_error("ud_program_run: bad range"); return UD_ERR_BAD_ARG; }
@@ -123,6 +128,7 @@ int ud_program_run(const UdProgram* p, int first, int last, void* stream) {
       case K_PATCH4: rc = ud_patchify4_nchw(op.patch4.img, op.patch4.out, op.patch4.B, op.patch4.H, op.patch4.W, op.patch4.ldo, stream); break;
       case K_MAX: rc = ud_max_f32(op.mx.dst, op.mx.src, op.mx.n, op.mx.init, stream); break;
       case K_MEAN: rc = ud_spatial_mean_f32(op.mean.x, op.mean.out, op.mean.B, op.mean.HW, op.mean.C, op.mean.ldo, stream); break;
+      case K_RSF: rc = ud_row_stats_finalize(op.rsf.part, op.rsf.stats, op.rsf.M, op.rsf.slabs, op.rsf.D, op.rsf.eps, stream); break;
       case K_T: rc = ud_nhwc_to_nchw_f32(op.t.in, op.t.out, op.t.B, op.t.hw, op.t.C, op.t.ld, op.t.rows_per_img, stream); break;
     }
     if (rc != UD_OK) return rc;

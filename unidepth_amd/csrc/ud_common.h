@@ -31,6 +31,10 @@ __device__ __forceinline__ void ud_bufl16(ud_rsrc_t r, unsigned voff, int soff, 
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, soff, 0, 0);
 }
 
+__device__ __forceinline__ void ud_bufl4(ud_rsrc_t r, unsigned voff, int soff, void* lds_wave_base) {     // 4 B per lane: LDS = base + lane * 4
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 4, (int)voff, soff, 0, 0);
+}
+
 // exact-erf GELU (nn.GELU default), transcendental-free:  gelu(x) = x Phi(x) = max(x, 0) - u q(u),  u = min(|x|, 5),  q(u) = Phi(-u)
 // as a degree-13 polynomial in t = 0.4 u - 1 (Chebyshev interpolant of 0.5 erfc(u / sqrt 2) on [0, 5], monomial form, Horner in fp32).
 // |error| <= 2.6e-6 absolute for every x (fp32 emulation against the fp64 erfc form on 4M points; beyond |x| = 5 the tail is frozen

@@ -61,6 +61,10 @@ def layernorm(**kw):
     check(lib.ud_layernorm_f32_f16(C.byref(mk(UdLayerNorm, **kw)), cur_stream()), "ud_layernorm_f32_f16")
 
 
+def row_stats_finalize(partials, stats, M, slabs, D, eps):
+    check(lib.ud_row_stats_finalize(ptr(partials), ptr(stats), M, slabs, D, eps, cur_stream()), "ud_row_stats_finalize")
+
+
 def attention(**kw):
     check(lib.ud_attention_f16(C.byref(mk(UdAttention, **kw)), cur_stream()), "ud_attention_f16")
 
@@ -136,6 +140,11 @@ class Program:
     def layernorm(self, **kw):
         self._k(kw, "layernorm", 0.0, 6.0 * kw["rows"] * kw["D"])
         return check(lib.ud_program_add_layernorm(self.h, C.byref(mk(UdLayerNorm, **kw))))
+
+    def row_stats_finalize(self, partials, stats, M, slabs, D, eps, tag="row_stats_finalize"):
+        self.keep += [partials, stats]
+        self.meta.append(("row_stats_finalize", tag, 0.0, 8.0 * M * (slabs + 1)))
+        return check(lib.ud_program_add_row_stats_finalize(self.h, ptr(partials), ptr(stats), M, slabs, D, eps))
 
     def attention(self, **kw):
         self._k(kw, "attention", 4.0 * kw["B"] * kw["H"] * kw["Nq"] * kw["Nk"] * 64)

@@ -137,11 +137,35 @@ class _Plan:
         clsn = [z(_rup(B, 8), D, dtype=f32) for _ in range(4)]       # final-LN'd cls tokens stay fp32: they feed the fp32 camera head
         self.enc_first = len(P)
         lvl = 0
+        # LayerNorm folded into the neighbouring GEMMs (UdGemm.row_stats_out / row_stats_in): proj / fc2 write the raw fp16 copy of the
+        # residual stream and per-row partial sums with their fp32 accumulate, qkv / fc1 normalise in their epilogues -- no LayerNorm
+        # launch, no second pass over x.  Only where all four GEMMs run on the large-tile kernel (its epilogues hold the statistics
+        # code): bs >= 4 or so for ViT-L; smaller problems keep the LayerNorm kernel.  UNIDEPTH_LN_FOLD=0 turns it off (A/B).
+        slabs = D // 64
+        x16 = z(M, D)
+        rpart = z(M, slabs, 2, dtype=f32)                           # per 64-column slab (sum, sum of squares) written by proj / fc2
+        rstats = z(M, 2, dtype=f32)                                 # (rstd, -mean) per row
+
+        def _pick(**kw):
+            import ctypes as _C
+            return ops.lib.ud_gemm_pick(_C.byref(ops.mk(ops.UdGemm, **kw)))
+        big = all(_pick(A=xn, W=w[f"enc.0.{nm}.w"], out=xn, M=M, N=n_, K=k_, lda=k_, ldw=k_, ldc=n_, epi=e_, vsplit=2 * D, tok_per_img=Np,
+                        kv_ld=Nkp, heads_v=heads, out2=vt, accumulate=int(e_ == UD_EPI_F32),
+                        **(dict(row_stats_in=rstats, wsum=w[f"enc.0.{nm}.wsum"]) if nm in ("qkv", "fc1") else {})) in (3, 4, 8)
+                  for nm, n_, k_, e_ in (("qkv", 3 * D, D, UD_EPI_QKV), ("proj", D, D, UD_EPI_F32), ("fc1", 4 * D, D, UD_EPI_F16), ("fc2", D, 4 * D, UD_EPI_F32)))
+        fold = big and os.environ.get("UNIDEPTH_LN_FOLD", "1") != "0"
+        self.ln_fold = fold
+        lnc = dict(row_stats_in=rstats, ln_slabs=slabs, ln_D=D, ln_eps=1e-6)
         for i in range(a["depth"]):
-            P.layernorm(x=x, y=xn, rows=M, D=D, ldx=D, ldy=D, eps=1e-6, rows_per_img=M, in_rows_per_img=M, out_rows_per_img=M, tag="enc.ln")
-            P.gemm(A=xn, W=w[f"enc.{i}.qkv.w"], bias=w[f"enc.{i}.qkv.b"], out=qk, out2=vt, M=M, N=3 * D, K=D, lda=D, ldw=D,
-                   ldc=2 * D, epi=UD_EPI_QKV, vsplit=2 * D, tok_per_img=Np, kv_ld=Nkp, heads_v=heads, tag="enc.qkv",
-                   flops=2.0 * B * N * 3 * D * D)
+            if fold and i > 0:
+                P.gemm(A=x16, W=w[f"enc.{i}.qkv.w"], bias=w[f"enc.{i}.qkv.b"], out=qk, out2=vt, M=M, N=3 * D, K=D, lda=D, ldw=D,
+                       ldc=2 * D, epi=UD_EPI_QKV, vsplit=2 * D, tok_per_img=Np, kv_ld=Nkp, heads_v=heads, tag="enc.qkv",
+                       flops=2.0 * B * N * 3 * D * D, wsum=w[f"enc.{i}.qkv.wsum"], **lnc)
+            else:
+                P.layernorm(x=x, y=xn, rows=M, D=D, ldx=D, ldy=D, eps=1e-6, rows_per_img=M, in_rows_per_img=M, out_rows_per_img=M, tag="enc.ln")
+                P.gemm(A=xn, W=w[f"enc.{i}.qkv.w"], bias=w[f"enc.{i}.qkv.b"], out=qk, out2=vt, M=M, N=3 * D, K=D, lda=D, ldw=D,
+                       ldc=2 * D, epi=UD_EPI_QKV, vsplit=2 * D, tok_per_img=Np, kv_ld=Nkp, heads_v=heads, tag="enc.qkv",
+                       flops=2.0 * B * N * 3 * D * D)
             if i == 0:
                 def _qkv0():                                                    # [B, N, 3D] = Q | K | V (attention.py:53-55 layout)
                     cols = ((torch.arange(N) & ~15) | ((torch.arange(N) & 4) << 1) | ((torch.arange(N) & 8) >> 1) | (torch.arange(N) & 3)).to(dev)
@@ -152,13 +176,23 @@ class _Plan:
                 tap("blocks.0.attn.qkv", _qkv0)
             P.attention(Q=qk, K=qk.data_ptr() + D * 2, Vt=vt, O=ao, B=B, H=heads, Nq=N, Nk=N, ldq=2 * D, ldk=2 * D, ldo=D,
                         kv_ld=Nkp, q_rows_per_img=Np, k_rows_per_img=Np, scale=(D // heads) ** -0.5, q_prescaled=1, tag="enc.attn")
+            prod = dict(out2=x16, ldc2=D, row_stats_out=rpart) if fold else {}
             P.gemm(A=ao, W=w[f"enc.{i}.proj.w"], bias=w[f"enc.{i}.proj.b"], out=x, M=M, N=D, K=D, lda=D, ldw=D, ldc=D,
-                   epi=UD_EPI_F32, accumulate=1, tag="enc.proj", flops=2.0 * B * N * D * D)
-            P.layernorm(x=x, y=xn, rows=M, D=D, ldx=D, ldy=D, eps=1e-6, rows_per_img=M, in_rows_per_img=M, out_rows_per_img=M, tag="enc.ln")
-            P.gemm(A=xn, W=w[f"enc.{i}.fc1.w"], bias=w[f"enc.{i}.fc1.b"], out=hid, M=M, N=4 * D, K=D, lda=D, ldw=D, ldc=4 * D,
-                   epi=UD_EPI_F16, act=UD_ACT_GELU, tag="enc.fc1", flops=8.0 * B * N * D * D)
+                   epi=UD_EPI_F32, accumulate=1, tag="enc.proj", flops=2.0 * B * N * D * D, **prod)
+            if fold:
+                P.row_stats_finalize(rpart, rstats, M, slabs, D, 1e-6, tag="enc.ln")
+                P.gemm(A=x16, W=w[f"enc.{i}.fc1.w"], bias=w[f"enc.{i}.fc1.b"], out=hid, M=M, N=4 * D, K=D, lda=D, ldw=D, ldc=4 * D,
+                       epi=UD_EPI_F16, act=UD_ACT_GELU, tag="enc.fc1", flops=8.0 * B * N * D * D, wsum=w[f"enc.{i}.fc1.wsum"], **lnc)
+            else:
+                P.layernorm(x=x, y=xn, rows=M, D=D, ldx=D, ldy=D, eps=1e-6, rows_per_img=M, in_rows_per_img=M, out_rows_per_img=M, tag="enc.ln")
+                P.gemm(A=xn, W=w[f"enc.{i}.fc1.w"], bias=w[f"enc.{i}.fc1.b"], out=hid, M=M, N=4 * D, K=D, lda=D, ldw=D, ldc=4 * D,
+                       epi=UD_EPI_F16, act=UD_ACT_GELU, tag="enc.fc1", flops=8.0 * B * N * D * D)
+            last = i == a["depth"] - 1
+            prod2 = prod if not last else {}            # nothing consumes the last block's raw copy
             P.gemm(A=hid, W=w[f"enc.{i}.fc2.w"], bias=w[f"enc.{i}.fc2.b"], out=x, M=M, N=D, K=4 * D, lda=4 * D, ldw=4 * D, ldc=D,
-                   epi=UD_EPI_F32, accumulate=1, tag="enc.fc2", flops=8.0 * B * N * D * D)
+                   epi=UD_EPI_F32, accumulate=1, tag="enc.fc2", flops=8.0 * B * N * D * D, **prod2)
+            if fold and not last:
+                P.row_stats_finalize(rpart, rstats, M, slabs, D, 1e-6, tag="enc.ln")
             if i in (0, 5, 11, 17, 23) or i == a["depth"] - 1:
                 tap(f"block{i}", lambda: x.view(B, Np, D)[:, :N].clone())      # residual stream after block i
             if (i + 1) in a["output_idx"]:
@@ -490,7 +524,8 @@ class UniDepthV2:
                 # the evicted plan's buffers go back to the caching allocator of whatever stream allocated them, while its launch
                 # program may still be queued on ANOTHER stream (pipeline slots): drain the device first -- rare, and a plan rebuild
                 # costs far more than this sync
-                torch.cuda.synchronize(self._device)
+                if self._device.type == "cuda":
+                    torch.cuda.synchronize(self._device)
                 while len(self._plans) >= max(1, self.max_plans):
                     self._plans.popitem(last=False)
             with torch.cuda.device(self._device):

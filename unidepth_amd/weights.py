@@ -86,8 +86,13 @@ def pack(config: dict, sd: dict, device) -> dict:
     f = {k: v.detach().to(torch.float32).cpu() for k, v in sd.items()}
     out: dict = {}
 
-    def put16(name, w):
-        out[name] = _padk(w).to(torch.float16).contiguous().to(device)
+    def put16(name, w, wsum=False):
+        w16 = _padk(w).to(torch.float16).contiguous()
+        out[name] = w16.to(device)
+        if wsum:
+            # row sums of the ROUNDED weights: a LayerNorm folded into this GEMM's epilogue computes rstd (x W^T - mean 1 W^T), and the
+            # cancellation against the MFMA's x W^T is only exact with the very operand the matrix pipe multiplies (UdGemm.wsum)
+            out[name + "sum"] = w16.to(torch.float64).sum(dim=1).to(torch.float32).contiguous().to(device)
 
     def put32(name, v):
         out[name] = v.to(torch.float32).contiguous().to(device)
@@ -102,11 +107,11 @@ def pack(config: dict, sd: dict, device) -> dict:
         qc = (D // a["heads"]) ** -0.5 * LOG2E
         w, bb = w.clone(), bb.clone()
         w[:D] *= qc; bb[:D] *= qc
-        put16(f"enc.{i}.qkv.w", w); put32(f"enc.{i}.qkv.b", bb)
+        put16(f"enc.{i}.qkv.w", w, wsum=True); put32(f"enc.{i}.qkv.b", bb)
         g1 = f[b + "ls1.gamma"]
         put16(f"enc.{i}.proj.w", f[b + "attn.proj.weight"] * g1[:, None]); put32(f"enc.{i}.proj.b", f[b + "attn.proj.bias"] * g1)
         w, bb = _fold_ln(f[b + "mlp.fc1.weight"], f[b + "mlp.fc1.bias"], f[b + "norm2.weight"], f[b + "norm2.bias"])
-        put16(f"enc.{i}.fc1.w", w); put32(f"enc.{i}.fc1.b", bb)
+        put16(f"enc.{i}.fc1.w", w, wsum=True); put32(f"enc.{i}.fc1.b", bb)
         g2 = f[b + "ls2.gamma"]
         put16(f"enc.{i}.fc2.w", f[b + "mlp.fc2.weight"] * g2[:, None]); put32(f"enc.{i}.fc2.b", f[b + "mlp.fc2.bias"] * g2)
     gn, bn = f[pe + "norm.weight"], f[pe + "norm.bias"]
