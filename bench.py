@@ -370,7 +370,7 @@ def kernel_timing(torch, model, fl, B, dump=""):
                  for k, v in sorted(tot.items(), key=lambda kv: -kv[1]["ms"])}
     # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the json)
     traffic, traffic_src = None, None
-    for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if traffic is None and os.path.exists(tpath):
             short = dom.replace("Cfg<", "(anonymous namespace)::Cfg<")
