@@ -106,13 +106,21 @@ typedef struct UdGemm {
    * norm2 between `x += proj(..)` / `x += fc2(..)` and the following qkv / fc1 Linear): no second pass over the fp32 stream.
    *   producer (UD_EPI_F32): row_stats_out [M][N / 64][2] fp32 = (sum, sum of squares) of the STORED fp32 row values over every
    *     64-column slab (one entry per wave of the tile; fixed order: bit-reproducible); out2 = the raw fp16 copy of the row.
-   *   ud_row_stats_finalize: [M][slabs][2] -> [M][2] = (rstd, -mean * rstd), slabs <= 16 summed in one fixed butterfly order.
+   *   ud_row_stats_finalize: [M][slabs][2] -> [M][2] = (rstd, -mean * rstd), slabs <= 16 summed in one fixed butterfly order -- or
+   *     row_stats_final below: the same reduction inside the producer, no extra launch.
    *   consumer (UD_EPI_F16 / UD_EPI_QKV): A = the raw fp16 copy, row_stats_in = the finalized [M][2]; the epilogue stores
    *     act(rstd * acc - mean * rstd * wsum[n] + bias[n]), wsum[n] = sum_k W[n, k] over the fp16-ROUNDED weights (the LayerNorm's affine
    *     folded into W / bias as before): rstd (x - mean) W^T = rstd (x W^T - mean 1 W^T).  fp16(x) carries the same 2^-11 relative
    *     rounding as fp16(LN(x)) when |mean| <~ std, which holds for residual streams (tap tests).  At most 4 tiles per workgroup.
-   *   ln_slabs / ln_D / ln_eps are read by ud_row_stats_finalize's caller only (kept in the descriptor for program recording). */
+   *   ln_D / ln_eps: read by the producer when row_stats_final is set; ln_slabs: unused by the kernels (kept for program recording). */
+  int grp_rows;                /* internal (callers leave 0): set by ud_gemm_f16 when it runs a grouped problem -- `groups` GEMMs stacked along M --
+                                * as ONE tile list of the large-tile kernel: rows per group */
   float* row_stats_out;
+  float* row_stats_final;      /* producer, optional: [M][2] = (rstd, -mean * rstd) written by the producer ITSELF -- the last workgroup to finish a row
+                                * tile (one ticket per row tile in row_stats_ticket: ceil(M / 128) unsigned, zeroed ONCE by the caller, never reset)
+                                * reduces the partial sums of all column tiles in ascending slab order; replaces ud_row_stats_finalize (a ~7.5 us
+                                * launch).  Large-tile kernel, tile-list schedule, N <= 1024; uses ln_D / ln_eps. */
+  unsigned* row_stats_ticket;
   const float* row_stats_in;
   const float* wsum;
   int ln_slabs, ln_D;
@@ -121,7 +129,8 @@ typedef struct UdGemm {
 
 int ud_gemm_f16(const UdGemm* desc, void* stream);
 /* kernel the call above would pick (profiling labels): 0/1/2 = 128-row tiles with BN 128/64/32, 3 = 192x256, 4 = 256x256, 5 = halo-tile conv,
- * 6 / 7 = 128x128 tiles, 4-stage pipelined ring without / with the two-way K split */
+ * 6 / 7 = 128x128 tiles, 4-stage pipelined ring without / with the two-way K split, 8 = row-balanced 256-column schedule;
+ * + 16: folded-LayerNorm consumer instantiation, + 32: grouped problem run as one large-tile launch */
 int ud_gemm_pick(const UdGemm* desc);
 
 /* ---- LayerNorm (statistics only; the affine is folded into the consumer's weights at load time) ----

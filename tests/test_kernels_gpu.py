@@ -394,19 +394,29 @@ def test_gemm_conv3x3_big_tiles(ops, hint, Cin, Cout, H, W):
     assert rel(l16.view(B, rows_img, Cout)[:, :H * W].float(), F.leaky_relu(want, 0.01)) < 1e-3
 
 
-def _ln_fold_pair(ops, x0, A1, W1, b1, W2, b2, hint1, hint2, epi2, D, eps=1e-6):
-    """x = x0 + A1 W1^T + b1 (producer: raw fp16 copy + row partial sums), then epi2(LN(x) W2^T + b2) through the folded consumer."""
+_TICKETS = {}
+
+
+def _ln_fold_pair(ops, x0, A1, W1, b1, W2, b2, hint1, hint2, epi2, D, eps=1e-6, inkernel=True):
+    """x = x0 + A1 W1^T + b1 (producer: raw fp16 copy + row partial sums), then epi2(LN(x) W2^T + b2) through the folded consumer.
+    inkernel: the partial sums are reduced by the producer's last workgroup per row tile (row_stats_final); else by ud_row_stats_finalize."""
     M = x0.shape[0]
     x = x0.clone()
     x16 = torch.zeros(M, D, dtype=torch.half, device="cuda")
     stats = torch.zeros(M, D // 64, 2, device="cuda")
+    fin = torch.zeros(M, 2, device="cuda")
     K1 = A1.shape[1]
+    extra = {}
+    if inkernel:
+        # zeroed once per (problem, tiling), never reset: tickets count arrivals modulo the number of column tiles
+        tk = _TICKETS.setdefault((M, D, hint1), torch.zeros(M // 128 + 2, dtype=torch.int32, device="cuda"))
+        extra = dict(row_stats_final=fin, row_stats_ticket=tk, ln_D=D, ln_eps=eps)
     ops.gemm(A=A1, W=W1, bias=b1, out=x, out2=x16, M=M, N=D, K=K1, lda=K1, ldw=K1, ldc=D, ldc2=D, epi=ops.UD_EPI_F32, accumulate=1,
-             tile_hint=hint1, row_stats_out=stats)
+             tile_hint=hint1, row_stats_out=stats, **extra)
     N2 = W2.shape[0]
     wsum = W2.double().sum(dim=1).float().contiguous()
-    fin = torch.zeros(M, 2, device="cuda")
-    ops.row_stats_finalize(stats, fin, M, D // 64, D, eps)
+    if not inkernel:
+        ops.row_stats_finalize(stats, fin, M, D // 64, D, eps)
     lnc = dict(row_stats_in=fin, wsum=wsum, ln_slabs=D // 64, ln_D=D, ln_eps=eps)
     if epi2 == ops.UD_EPI_F16:
         out = torch.zeros(M, N2, dtype=torch.half, device="cuda")
@@ -438,6 +448,14 @@ def test_gemm_layernorm_fold_fc1(ops, D, hint1, hint2):
     assert rel(x, xr) < 2e-5 and rel(x16.float(), xr) < 4e-4
     sl = x.view(M, D // 64, 64)
     assert rel(stats[..., 0], sl.sum(-1)) < 1e-5 and rel(stats[..., 1], (sl * sl).sum(-1)) < 1e-5
+    # the in-kernel reduction (last workgroup per row tile) against the stand-alone reduction kernel and against torch
+    fin2 = torch.zeros(M, 2, device="cuda")
+    ops.row_stats_finalize(stats, fin2, M, D // 64, D, 1e-6)
+    x_b, _, _, out_b, _ = _ln_fold_pair(ops, x0, A1, W1, b1, W2, b2, hint1, hint2, ops.UD_EPI_F16, D, inkernel=False)
+    torch.cuda.synchronize()
+    mean, var = x.mean(-1), x.var(-1, unbiased=False)
+    assert rel(fin2[:, 0], torch.rsqrt(var + 1e-6)) < 1e-5 and rel(fin2[:, 1], -mean * torch.rsqrt(var + 1e-6)) < 1e-4
+    assert torch.equal(x, x_b) and rel(out.float(), out_b.float()) < 2e-4
     ref = F.gelu(F.layer_norm(x, (D,), eps=1e-6) @ W2.float().t() + b2)
     assert rel(out.float(), ref) < 1.5e-3, rel(out.float(), ref)
     # against the classic path (LayerNorm kernel -> fp16 xn -> GEMM): same accuracy class
@@ -491,6 +509,52 @@ def test_gemm_layernorm_fold_rejects_unsupported(ops):
         ops.gemm(A=A, W=W, out=out, M=256, N=128, K=64, lda=64, ldw=64, ldc=128, epi=ops.UD_EPI_F16, row_stats_in=st, wsum=ws, ln_slabs=2, ln_D=128, ln_eps=1e-6)
     with pytest.raises(RuntimeError):          # statistics only from the fp32 epilogue
         ops.gemm(A=A, W=W, out=out, M=256, N=128, K=64, lda=64, ldw=64, ldc=128, epi=ops.UD_EPI_F16, row_stats_out=st)
+
+
+def test_gemm_grouped_as_one_large_tile_launch(ops):
+    """Grouped problems whose groups are stacked along M (the decoder's x4 launches at bs = 8: 4 x [11008, 512] token streams) run as ONE
+    tile list of the 256 x 256 kernel (ud_gemm_pick & 32): fp16 + GELU, fp32 accumulate with the fp16 copy, and the Q|K / V^T epilogue
+    with all groups sharing one A (gA = 0) -- against per-group fp32 torch and bit-identical to the blockIdx.z form (tile_hint = 1)."""
+    import ctypes as C
+    G, Bn, Np, K = 4, 8, 1376, 512
+    M = Bn * Np
+    A = rnd(G, M, K, seed=1).half()
+    for N, act in ((512, 0), (2048, 1)):
+        W = rnd(G, N, K, scale=K ** -0.5, seed=2).half(); bias = rnd(G, N, seed=3)
+        kw = dict(A=A, W=W, bias=bias, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, epi=ops.UD_EPI_F16, act=act, groups=G, gA=M * K, gW=N * K, gBias=N, gOut=M * N)
+        out = torch.zeros(G, M, N, dtype=torch.half, device="cuda")
+        assert ops.lib.ud_gemm_pick(C.byref(ops.mk(ops.UdGemm, out=out, **kw))) == 4 + 32
+        ops.gemm(out=out, **kw)
+        ref = torch.einsum("gmk,gnk->gmn", A.float(), W.float()) + bias[:, None, :]
+        ref = F.gelu(ref) if act else ref
+        torch.cuda.synchronize()
+        assert rel(out.float(), ref) < 1e-3
+        out_z = torch.zeros_like(out)
+        ops.gemm(out=out_z, tile_hint=1, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(out, out_z)
+    # fp32 accumulate + fp16 copy, K = 2048
+    K2, N2 = 2048, 512
+    A2 = rnd(G, M, K2, seed=4).half(); W2 = rnd(G, N2, K2, scale=K2 ** -0.5, seed=5).half(); b2 = rnd(G, N2, seed=6)
+    x = rnd(G, M, N2, seed=7); x0 = x.clone(); x16 = torch.zeros(G, M, N2, dtype=torch.half, device="cuda")
+    ops.gemm(A=A2, W=W2, bias=b2, out=x, out2=x16, M=M, N=N2, K=K2, lda=K2, ldw=K2, ldc=N2, ldc2=N2, epi=ops.UD_EPI_F32, accumulate=1, groups=G,
+             gA=M * K2, gW=N2 * K2, gBias=N2, gOut=M * N2, gOut2=M * N2)
+    ref = x0 + torch.einsum("gmk,gnk->gmn", A2.float(), W2.float()) + b2[:, None, :]
+    torch.cuda.synchronize()
+    assert rel(x, ref) < 2e-5 and rel(x16.float(), ref) < 1e-3
+    # Q|K + V^T, one A for all groups
+    HC, kv_ld, Hd = 512, 1408, 8
+    Wkv = rnd(G, 2 * HC, K, scale=K ** -0.5, seed=8).half(); bkv = rnd(G, 2 * HC, seed=9)
+    kd = torch.zeros(G, M, HC, dtype=torch.half, device="cuda"); vtd = torch.zeros(G, Bn, Hd, 64, kv_ld, dtype=torch.half, device="cuda")
+    kw = dict(A=A[0], W=Wkv, bias=bkv, M=M, N=2 * HC, K=K, lda=K, ldw=K, ldc=HC, epi=ops.UD_EPI_QKV, vsplit=HC, tok_per_img=Np, kv_ld=kv_ld, heads_v=Hd,
+              groups=G, gA=0, gW=2 * HC * K, gBias=2 * HC, gOut=M * HC, gOut2=Bn * Hd * 64 * kv_ld)
+    assert ops.lib.ud_gemm_pick(C.byref(ops.mk(ops.UdGemm, out=kd, out2=vtd, **kw))) == 4 + 32
+    ops.gemm(out=kd, out2=vtd, **kw)
+    ref = torch.einsum("mk,gnk->gmn", A[0].float(), Wkv.float()) + bkv[:, None, :]
+    torch.cuda.synchronize()
+    assert rel(kd.float(), ref[..., :HC]) < 1e-3
+    want = ref[..., HC:].view(G, Bn, Np, Hd, 64).permute(0, 1, 3, 4, 2)
+    assert rel(vtd[..., vt_cols(Np)].float(), want) < 1e-3 and vt_unused_zero(vtd, Np)
 
 
 def _split16(w):

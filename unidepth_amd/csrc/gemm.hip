@@ -79,7 +79,10 @@ __device__ __forceinline__ void ud_row_stats_store(const UdGemm& p, float s1, fl
   if (ok && nbase < p.N && (lane >> 4) == 0) {
     f32x2 o;
     o[0] = s1; o[1] = s2;
-    *(f32x2*)(p.row_stats_out + ((size_t)m * (p.N >> 6) + (nbase >> 6)) * 2) = o;
+    // system-scope write-through: the workgroup that finishes the row tile LAST (another XCD, in general) reduces these right away
+    // (UdGemm.row_stats_final); same fence-free exchange as the two-way K split (sc0 sc1 stores, vmcnt(0), one ticket atomic)
+    float* dst = p.row_stats_out + ((size_t)m * (p.N >> 6) + (nbase >> 6)) * 2;
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 2" ::"v"(dst), "v"(o) : "memory");
   }
 }
 // consumer: out = rstd * (x W^T - mean wsum) + bias as two fmas in this order: fma(acc, rstd, fma(nmr, wsum, bias)), nmr = -mean * rstd.
@@ -733,7 +736,11 @@ __device__ __forceinline__ void ud_interleave_reads() {
 // epilogues for it.  (A first version reduced the producer's 16 partial pairs per row here, per tile: 32 live registers across the
 // epilogue, 55-340 spilled registers in the Q|K / V^T instantiations, +14..16 us per launch -- slower than the LayerNorm kernel it
 // replaced; the reduction is now ud_row_stats_finalize, one thread per row.)
-template <int MH, int EPI, int AMODE, bool BAL = false, bool LNC = false>
+// GRP: a grouped problem (UdGemm.groups: G independent GEMMs of equal shape whose A rows / output rows are stacked along M and whose
+// weights sit gW apart) run as ONE tile list over G * M rows: the group of a tile is m0 / grp_rows (grp_rows % tile height == 0, so no
+// tile straddles two groups) and only moves the W rows and the bias; with gA == 0 all groups read the same A.  The 128-row kernel runs
+// such problems as blockIdx.z slices at ~480 TFLOP/s (K = 512: four short K loops per CU); here they share the persistent tile stream.
+template <int MH, int EPI, int AMODE, bool BAL = false, bool LNC = false, bool GRP = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using C = BigCfg<MH>;
@@ -778,11 +785,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   unsigned pb[4];
   const float inv_cc = (AMODE != UD_A_DENSE) ? 1.0f / (float)(p.Cin >> 3) : 0.0f;
   auto setup = [&](int m0, int n0, int mh) {
+    int grp = 0;
+    if constexpr (GRP) grp = m0 / p.grp_rows;
 #pragma unroll
     for (int i = 0; i < C::A_LOADS; ++i) {
       if (i >= mh) continue;
       int m = m0 + lrow + 64 * i;
       m = m < p.M ? m : p.M - 1;
+      if constexpr (GRP) {
+        if (p.gA == 0) m -= grp * p.grp_rows;                      // every group multiplies the same A rows
+      }
       if constexpr (AMODE == UD_A_DENSE) {
         pa[i] = ((unsigned)m * (unsigned)p.lda + csrc * 8) * 2u;
       } else {
@@ -798,6 +810,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
       int n = n0 + lrow + 64 * i;
       n = n < p.N ? n : p.N - 1;
       pb[i] = ((unsigned)n * (unsigned)p.ldw + csrc * 8) * 2u;
+      if constexpr (GRP) pb[i] += (unsigned)grp * (unsigned)p.gW * 2u;
     }
   };
   // split-fp16 products by K concatenation (UdGemm.a_wrap / w_wrap): the K index wraps around once inside the narrower operand
@@ -1045,6 +1058,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
     // nbase + 16 (j + (q & 1)) + 8 (q >> 1): 16-byte stores, 64-byte row segments.  V^T tiles (!SWAP) own 4 consecutive rows
     // (tokens) per lane; the same exchange between row tiles i / i+1 gives 8 consecutive tokens starting at
     // (v_permlane32_swap between row tiles i / i+1 packs them in the V^T block order, see below).
+    const float* biasp = p.bias;
+    if constexpr (GRP) {
+      if (p.bias) biasp = p.bias + (long long)(m0 / p.grp_rows) * p.gBias;
+    }
     const bool full = (m0 + BMC <= p.M) && (n0 + 256 <= p.N) && p.rows_in == 0 && p.add == nullptr && p.bias != nullptr;
     bool fast = false;
     int eln = lane;
@@ -1057,7 +1074,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
           const int act = p.act;
           f32x4 bv[4], ws[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(p.bias + nbase + j * 16 + 4 * fq);
+          for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(biasp + nbase + j * 16 + 4 * fq);
           if constexpr (LNC) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) ws[j] = *(const f32x4*)(p.wsum + nbase + j * 16 + 4 * fq);
@@ -1109,7 +1126,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const int n = nbase + j * 16 + frow;
-              const float bvn = p.bias[n];
+              const float bvn = biasp[n];
               float wsn = 0.f;
               if constexpr (LNC) wsn = p.wsum[n];
               const int nv = n - p.vsplit;
@@ -1150,7 +1167,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
       if (fast) {
         f32x4 bv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(p.bias + nbase + j * 16 + 4 * fq);
+        for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(biasp + nbase + j * 16 + 4 * fq);
         float* o = (float*)p.out + (size_t)(mbase + frow) * p.ldc + nbase + 4 * fq;
         half_t* o2 = p.out2 ? (half_t*)p.out2 + (size_t)(mbase + frow) * p.ldc2 + nbase + 16 * (fq & 1) + 8 * (fq >> 1) : nullptr;
         const bool wr32 = p.accumulate != 2;   // accumulate == 2: the fp32 stream dies here, only the fp16 copy is consumed
@@ -1201,7 +1218,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
         const int Wout = p.d2s_Win * k;
         f32x4 bv[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(p.bias + o0 + j * 16 + 4 * fq);
+        for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(biasp + o0 + j * 16 + 4 * fq);
         const bool lre = p.act2 == UD_ACT_LRELU;
 #pragma unroll
         for (int i = 0; i < TMC; ++i) {
@@ -1247,10 +1264,50 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
       // generic path: edge tiles, row remaps, `add` operands, depth-to-space (8-byte fp16 stores, per-element bounds checks)
       constexpr bool PRE = ACC_EPI;            // the residual is already inside the accumulators (in-loop or preloaded)
       if constexpr (EPI == UD_EPI_QKV) {
-        if (swap) gemm_epilogue<TMC, 4, EPI, true, PRE>(p, acc, mbase, nbase, eln, p.bias, (char*)p.out, (char*)p.out2, nullptr, 0.f, 0.f, nullptr, lnst);
-        else gemm_epilogue<TMC, 4, EPI, false, PRE>(p, acc, mbase, nbase, eln, p.bias, (char*)p.out, (char*)p.out2, nullptr, 0.f, 0.f, nullptr, lnst);
+        if (swap) gemm_epilogue<TMC, 4, EPI, true, PRE>(p, acc, mbase, nbase, eln, biasp, (char*)p.out, (char*)p.out2, nullptr, 0.f, 0.f, nullptr, lnst);
+        else gemm_epilogue<TMC, 4, EPI, false, PRE>(p, acc, mbase, nbase, eln, biasp, (char*)p.out, (char*)p.out2, nullptr, 0.f, 0.f, nullptr, lnst);
       } else {
-        gemm_epilogue<TMC, 4, EPI, true, PRE>(p, acc, mbase, nbase, eln, p.bias, (char*)p.out, (char*)p.out2, nullptr, 0.f, 0.f, nullptr, lnst);
+        gemm_epilogue<TMC, 4, EPI, true, PRE>(p, acc, mbase, nbase, eln, biasp, (char*)p.out, (char*)p.out2, nullptr, 0.f, 0.f, nullptr, lnst);
+      }
+    }
+    if constexpr (EPI == UD_EPI_F32 && !BAL) {
+      if (p.row_stats_final) {
+        // ---- LayerNorm statistics of the rows of this row tile: the LAST of the tiles_n workgroups to get here reduces the partial sums
+        // of all column tiles (ascending slab order: one summation order per row) -- no separate reduction launch (~7.5 us each, 47
+        // per step).  Tickets count arrivals per row tile and are never reset: tiles_n arrivals per launch.
+        unsigned* flag = (unsigned*)(smem + 2 * C::STAGE);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid == 0) *flag = atomicAdd(p.row_stats_ticket + m0 / BMC, 1u);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned arrived = *flag;
+        if (arrived % (unsigned)tiles_n == (unsigned)tiles_n - 1u) {
+          const int slabs = p.N >> 6;
+          if (tid < BMC && m0 + tid < p.M) {
+            const float* src = p.row_stats_out + (size_t)(m0 + tid) * slabs * 2;
+            f32x4 q[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              q[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+              if (2 * k < slabs) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(q[k]) : "v"(src + 4 * k) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7])::"memory");
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              s1 += q[k][0]; s2 += q[k][1];
+              s1 += q[k][2]; s2 += q[k][3];
+            }
+            const float inv = 1.0f / (float)p.ln_D;
+            const float mean = s1 * inv;
+            const float var = fmaxf(__builtin_fmaf(-mean, mean, s2 * inv), 0.0f);
+            f32x2 o;
+            o[0] = rsqrtf(var + p.ln_eps);
+            o[1] = -mean * o[0];
+            *(f32x2*)(p.row_stats_final + 2 * (size_t)(m0 + tid)) = o;
+          }
+        }
       }
     }
     UD_STAMP(3);
@@ -1274,19 +1331,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   }
 }
 
-template <int MH, int EPI, int AMODE, bool LNC = false>
+template <int MH, int EPI, int AMODE, bool LNC = false, bool GRP = false>
 int launch256(const UdGemm& d, hipStream_t s) {
   constexpr int BM = BigCfg<MH>::BM;
   const int tiles = ((d.N + 255) >> 8) * ((d.M + BM - 1) / BM);
-  const int lds = 2 * BigCfg<MH>::STAGE + (LNC ? LNC_LDS : 0);
+  const int lds = 2 * BigCfg<MH>::STAGE + (LNC ? LNC_LDS : 0) + (EPI == UD_EPI_F32 ? 64 : 0);
   static bool attr_set[UD_MAX_DEVICES];
   if (!ud_attr_once(attr_set)) {
-    if (hipFuncSetAttribute((const void*)gemm256_kernel<MH, EPI, AMODE, false, LNC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)gemm256_kernel<MH, EPI, AMODE, false, LNC, GRP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       ud_set_error("ud_gemm_f16: cannot reserve the LDS ring of the large-tile kernel");
       return UD_ERR_LAUNCH;
     }
   }
-  hipLaunchKernelGGL((gemm256_kernel<MH, EPI, AMODE, false, LNC>), dim3(tiles < 256 ? tiles : 256), dim3(512), lds, s, d);
+  hipLaunchKernelGGL((gemm256_kernel<MH, EPI, AMODE, false, LNC, GRP>), dim3(tiles < 256 ? tiles : 256), dim3(512), lds, s, d);
   UD_CHECK_LAUNCH("ud_gemm_f16 (large tile) launch");
   return UD_OK;
 }
@@ -1382,8 +1439,9 @@ int launch_big(const UdGemm& d, hipStream_t s, int which) {
     }
   }
   if constexpr (AMODE == UD_A_DENSE && (EPI == UD_EPI_F16 || EPI == UD_EPI_F32 || EPI == UD_EPI_QKV)) {
-    if (which == 8) return launch256bal<EPI>(d, s);
+    if (which == 8 && !d.row_stats_final) return launch256bal<EPI>(d, s);
   }
+  if (which == 8) which = 3;               // in-kernel statistics reduction: tickets are per row tile of ONE height (tile list only)
   return which == 3 ? launch256<3, EPI, AMODE>(d, s) : launch256<4, EPI, AMODE>(d, s);
 }
 
@@ -1688,6 +1746,33 @@ int dispatch_bn(const UdGemm& d, hipStream_t s) {
   return launch<Cfg<32, 32, 32>, EPI, AMODE>(d, s);
 }
 
+// A grouped dense problem as ONE launch of the 256 x 256 kernel (gemm256_kernel GRP): groups stacked along M (A rows shared or stacked,
+// outputs stacked), rows per group a multiple of the tile height.  Returns true and the merged descriptor when that form applies and
+// the tile-shape model prefers the large kernel for the merged problem.
+inline bool grouped_as_big(const UdGemm& d, UdGemm& m) {
+  if (d.groups <= 1 || d.amode != UD_A_DENSE || (d.M & 255) || d.tile_hint == 1 || d.a_wrap || d.w_wrap || d.row_stats_in || d.row_stats_out ||
+      d.rows_in || d.add)
+    return false;
+  if (d.epi != UD_EPI_F16 && d.epi != UD_EPI_F32 && d.epi != UD_EPI_QKV) return false;
+  if (!(d.gA == 0 || d.gA == (long long)d.M * d.lda) || d.gOut != (long long)d.M * d.ldc) return false;
+  if (d.bias && d.gBias < 0) return false;
+  if (d.out2) {
+    if (d.epi == UD_EPI_QKV) {
+      if (d.tok_per_img <= 0 || d.M % d.tok_per_img || d.gOut2 != (long long)(d.M / d.tok_per_img) * d.heads_v * 64 * d.kv_ld) return false;
+    } else if (d.gOut2 != (long long)d.M * d.ldc2) {
+      return false;
+    }
+  }
+  m = d;
+  m.grp_rows = d.M;
+  m.M = d.M * d.groups;
+  m.groups = 1;
+  if (2.0 * (double)d.groups * d.N * d.ldw >= 2147483648.0 || 2.0 * (double)m.M * d.lda >= 2147483648.0) return false;
+  m.tile_hint = 0;
+  const int bt = pick_tiles(m);
+  return bt == 4 || bt == 3 || bt == 8;         // the merged problem is large enough for the large-tile kernel (it then runs 256-row tiles)
+}
+
 }  // namespace
 
 extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
@@ -1722,6 +1807,13 @@ extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
       ud_set_error("ud_gemm_f16: row_stats_out needs the fp32 epilogue, N % 64 == 0 and 64-column wave tiles (N > 64, no groups)");
       return UD_ERR_UNSUPPORTED;
     }
+    if (d.row_stats_final && (bt == 0 || !d.row_stats_ticket || d.ln_D <= 0 || d.N > 1024 || d.groups > 1)) {
+      ud_set_error("ud_gemm_f16: row_stats_final (in-kernel reduction of the row statistics) needs the large-tile kernel, a ticket buffer, ln_D and N <= 1024");
+      return UD_ERR_UNSUPPORTED;
+    }
+  } else if (d.row_stats_final) {
+    ud_set_error("ud_gemm_f16: row_stats_final without row_stats_out");
+    return UD_ERR_BAD_ARG;
   }
   if (d.amode == UD_A_CONV3_REFLECT_UP && d.epi != UD_EPI_HEAD) {
     ud_set_error("ud_gemm_f16: CONV3_REFLECT_UP is implemented for the HEAD epilogue only");
@@ -1735,6 +1827,10 @@ extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
     if (d.amode != UD_A_DENSE || !d.out2 || (d.vsplit % 128) || (d.tok_per_img & 3) || (d.kv_ld & 3) || d.N <= 64) {
       ud_set_error("ud_gemm_f16: bad QKV epilogue geometry");
       return UD_ERR_BAD_ARG;
+    }
+    {
+      UdGemm mg;
+      if (grouped_as_big(d, mg)) return launch256<4, UD_EPI_QKV, UD_A_DENSE, false, true>(mg, s);
     }
     if (const int bt = pick_tiles(d)) return launch_big<UD_EPI_QKV>(d, s, bt);
     return launch<Cfg<128, 64, 64>, UD_EPI_QKV, UD_A_DENSE>(d, s);
@@ -1769,6 +1865,10 @@ extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
       if (d.amode == UD_A_CONV3_REFLECT) return d.N == 64 ? launch_conv_tile<4, UD_EPI_F16, true>(d, s) : launch_conv_tile<2, UD_EPI_F16, true>(d, s);
       return d.N == 64 ? launch_conv_tile<4, UD_EPI_F16, false>(d, s) : launch_conv_tile<2, UD_EPI_F16, false>(d, s);
     }
+    {
+      UdGemm mg;
+      if (grouped_as_big(d, mg)) return launch256<4, UD_EPI_F16, UD_A_DENSE, false, true>(mg, s);
+    }
     if (const int bt = pick_tiles(d))
       return d.amode == UD_A_DENSE ? launch_big<UD_EPI_F16>(d, s, bt) : launch_big<UD_EPI_F16, UD_A_CONV3_ZERO>(d, s, bt);
     if (d.amode == UD_A_DENSE) return dispatch_bn<UD_EPI_F16, UD_A_DENSE>(d, s);
@@ -1776,6 +1876,10 @@ extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
     return dispatch_bn<UD_EPI_F16, UD_A_CONV3_REFLECT>(d, s);
   }
   if (d.epi == UD_EPI_F32) {
+    {
+      UdGemm mg;
+      if (grouped_as_big(d, mg)) return launch256<4, UD_EPI_F32, UD_A_DENSE, false, true>(mg, s);
+    }
     if (const int bt = pick_tiles(d))
       return d.amode == UD_A_DENSE ? launch_big<UD_EPI_F32>(d, s, bt) : launch_big<UD_EPI_F32, UD_A_CONV3_ZERO>(d, s, bt);
     if (d.amode == UD_A_DENSE) return dispatch_bn<UD_EPI_F32, UD_A_DENSE>(d, s);
@@ -1792,14 +1896,19 @@ extern "C" int ud_trace_set(void* buf) {
 #endif
 
 // Which kernel ud_gemm_f16 would launch for this descriptor (for profiling labels): 0/1/2 = 128-row kernels with BN 128/64/32,
-// 3 = 192x256 tiles, 4 = 256x256 tiles, 5 = halo-tile conv, 6 / 7 = 128x128 pipelined ring without / with the K split.
+// 3 = 192x256 tiles, 4 = 256x256 tiles, 5 = halo-tile conv, 6 / 7 = 128x128 pipelined ring without / with the K split, 8 = row-balanced;
+// + 16 when the folded-LayerNorm consumer instantiation runs (row_stats_in), + 32 for a grouped problem run as one large-tile launch.
 extern "C" int ud_gemm_pick(const UdGemm* desc) {
   const UdGemm& d = *desc;
+  {
+    UdGemm mg;
+    if ((d.epi == UD_EPI_F16 || d.epi == UD_EPI_F32 || d.epi == UD_EPI_QKV) && grouped_as_big(d, mg)) return 4 + 32;
+  }
   if (conv_tile_ok(d) && (d.epi == UD_EPI_HEAD || d.epi == UD_EPI_F16)) return 5;
   if (d.epi != UD_EPI_HEAD) {
     const int bt = pick_tiles(d);
     if (bt && d.row_stats_in && big_tiles_per_wg(d, bt) > LNC_TILES) return 0;      // the folded-LayerNorm consumer cannot take it
-    if (bt) return bt;
+    if (bt) return bt + (d.row_stats_in ? 16 : 0);
   }
   if (d.N > 64 && d.epi != UD_EPI_D2S) {
     const int v = ring_variant(d);

@@ -114,14 +114,16 @@ class Program:
             kw["splitk_ws"], kw["splitk_cnt"] = self._splitk
         d = mk(UdGemm, **kw)
         pick, epi, amode = lib.ud_gemm_pick(C.byref(d)), kw.get("epi", 0), kw.get("amode", 0)
+        lnc, grp = "true" if pick & 16 else "false", "true" if pick & 32 else "false"
+        pick &= 15
         if pick <= 2:       # names as rocprofv3 prints them (template arguments), so profiles and bench lines can be joined
             cls = "gemm_kernel<Cfg<%s>, %d, %d, 2, false>" % (("128, 64, 64", "64, 64, 32", "32, 32, 32")[pick], epi, amode)
         elif pick in (6, 7):     # 128x128 tiles, 4-stage pipelined ring (7: + two-way K split)
             cls = "gemm_kernel<Cfg<128, 64, 64>, %d, %d, 4, %s>" % (epi, amode, "true" if pick == 7 else "false")
         elif pick <= 4:
-            cls = "gemm256_kernel<%d, %d, %d, false>" % (pick, epi, amode)
+            cls = "gemm256_kernel<%d, %d, %d, false, %s, %s>" % (pick, epi, amode, lnc, grp)
         elif pick == 8:     # row-balanced schedule of the 256-column kernel
-            cls = "gemm256_kernel<4, %d, %d, true>" % (epi, amode)
+            cls = "gemm256_kernel<4, %d, %d, true, %s, false>" % (epi, amode, lnc)
         else:
             cls = "conv_tile_kernel<%d, %d, %s, %s>" % (n // 16, epi, "true" if amode >= 2 else "false", "true" if amode == 3 else "false")
         self.keep.extend(v for v in kw.values() if isinstance(v, torch.Tensor))

@@ -144,14 +144,15 @@ class _Plan:
         slabs = D // 64
         x16 = z(M, D)
         rpart = z(M, slabs, 2, dtype=f32)                           # per 64-column slab (sum, sum of squares) written by proj / fc2
-        rstats = z(M, 2, dtype=f32)                                 # (rstd, -mean) per row
+        rstats = z(M, 2, dtype=f32)                                 # (rstd, -mean * rstd) per row, reduced by the producer's last workgroup per row tile
+        rticket = torch.zeros(2, M // 128 + 2, dtype=torch.int32, device=dev)     # one set per producer (proj, fc2): a set counts arrivals of ONE tiling
 
         def _pick(**kw):
             import ctypes as _C
             return ops.lib.ud_gemm_pick(_C.byref(ops.mk(ops.UdGemm, **kw)))
         big = all(_pick(A=xn, W=w[f"enc.0.{nm}.w"], out=xn, M=M, N=n_, K=k_, lda=k_, ldw=k_, ldc=n_, epi=e_, vsplit=2 * D, tok_per_img=Np,
                         kv_ld=Nkp, heads_v=heads, out2=vt, accumulate=int(e_ == UD_EPI_F32),
-                        **(dict(row_stats_in=rstats, wsum=w[f"enc.0.{nm}.wsum"]) if nm in ("qkv", "fc1") else {})) in (3, 4, 8)
+                        **(dict(row_stats_in=rstats, wsum=w[f"enc.0.{nm}.wsum"]) if nm in ("qkv", "fc1") else {})) & 15 in (3, 4, 8)
                   for nm, n_, k_, e_ in (("qkv", 3 * D, D, UD_EPI_QKV), ("proj", D, D, UD_EPI_F32), ("fc1", 4 * D, D, UD_EPI_F16), ("fc2", D, 4 * D, UD_EPI_F32)))
         fold = big and os.environ.get("UNIDEPTH_LN_FOLD", "1") != "0"
         self.ln_fold = fold
@@ -176,11 +177,10 @@ class _Plan:
                 tap("blocks.0.attn.qkv", _qkv0)
             P.attention(Q=qk, K=qk.data_ptr() + D * 2, Vt=vt, O=ao, B=B, H=heads, Nq=N, Nk=N, ldq=2 * D, ldk=2 * D, ldo=D,
                         kv_ld=Nkp, q_rows_per_img=Np, k_rows_per_img=Np, scale=(D // heads) ** -0.5, q_prescaled=1, tag="enc.attn")
-            prod = dict(out2=x16, ldc2=D, row_stats_out=rpart) if fold else {}
+            prod = dict(out2=x16, ldc2=D, row_stats_out=rpart, row_stats_final=rstats, row_stats_ticket=rticket[0], ln_D=D, ln_eps=1e-6) if fold else {}
             P.gemm(A=ao, W=w[f"enc.{i}.proj.w"], bias=w[f"enc.{i}.proj.b"], out=x, M=M, N=D, K=D, lda=D, ldw=D, ldc=D,
                    epi=UD_EPI_F32, accumulate=1, tag="enc.proj", flops=2.0 * B * N * D * D, **prod)
             if fold:
-                P.row_stats_finalize(rpart, rstats, M, slabs, D, 1e-6, tag="enc.ln")
                 P.gemm(A=x16, W=w[f"enc.{i}.fc1.w"], bias=w[f"enc.{i}.fc1.b"], out=hid, M=M, N=4 * D, K=D, lda=D, ldw=D, ldc=4 * D,
                        epi=UD_EPI_F16, act=UD_ACT_GELU, tag="enc.fc1", flops=8.0 * B * N * D * D, wsum=w[f"enc.{i}.fc1.wsum"], **lnc)
             else:
@@ -188,11 +188,9 @@ class _Plan:
                 P.gemm(A=xn, W=w[f"enc.{i}.fc1.w"], bias=w[f"enc.{i}.fc1.b"], out=hid, M=M, N=4 * D, K=D, lda=D, ldw=D, ldc=4 * D,
                        epi=UD_EPI_F16, act=UD_ACT_GELU, tag="enc.fc1", flops=8.0 * B * N * D * D)
             last = i == a["depth"] - 1
-            prod2 = prod if not last else {}            # nothing consumes the last block's raw copy
+            prod2 = dict(prod, row_stats_ticket=rticket[1]) if (fold and not last) else {}            # nothing consumes the last block's raw copy
             P.gemm(A=hid, W=w[f"enc.{i}.fc2.w"], bias=w[f"enc.{i}.fc2.b"], out=x, M=M, N=D, K=4 * D, lda=4 * D, ldw=4 * D, ldc=D,
                    epi=UD_EPI_F32, accumulate=1, tag="enc.fc2", flops=8.0 * B * N * D * D, **prod2)
-            if fold and not last:
-                P.row_stats_finalize(rpart, rstats, M, slabs, D, 1e-6, tag="enc.ln")
             if i in (0, 5, 11, 17, 23) or i == a["depth"] - 1:
                 tap(f"block{i}", lambda: x.view(B, Np, D)[:, :N].clone())      # residual stream after block i
             if (i + 1) in a["output_idx"]:
@@ -210,7 +208,8 @@ class _Plan:
         feat_all = z(4, Md, C, dtype=f32)
         ct = z(B * 4, C, dtype=f32)
         P.gemm(A=featn_all, W=w["dec.adapterg.w"], bias=w["dec.adapterg.b"], out=feat_all, M=Md, N=C, K=D, lda=D, ldw=D, ldc=C,
-               epi=UD_EPI_F32, groups=4, gA=Md * D, gW=C * D, gBias=C, gOut=Md * C, tag="dec.adapters(x4)")
+               epi=UD_EPI_F32, groups=4, gA=Md * D, gW=C * D, gBias=C, gOut=Md * C, tag="dec.adapters(x4)",
+               **({"tile_hint": 1} if os.environ.get("UNIDEPTH_GRP_BIG", "1") == "0" else {}))
         self.dec_first = self.enc_last
         for j in range(4):
             tap(f"input_adapter.{j}", lambda j=j: feat_all[j].view(B, hwp, C)[:, :hw].clone())
@@ -288,7 +287,7 @@ class _Plan:
         fn = z(4, Md, C); qd = z(4, Md, HC); kd = z(4, Mk, HC); vtd = z(4, nb, Hd, 64, hwkp); aod = z(4, Md, HC); hidd = z(4, Md, 4 * C)
         c16_all = z(4, Md, C)
         c16 = [c16_all[j] for j in range(4)]
-        G4 = dict(groups=4)
+        G4 = dict(groups=4, **({"tile_hint": 1} if os.environ.get("UNIDEPTH_GRP_BIG", "1") == "0" else {}))      # A/B switch: 128-row blockIdx.z form
         ln(feat_all, fn, 4 * Md)
         P.gemm(A=fn, W=w["dhg.q.w"], bias=w["dhg.q.b"], out=qd, M=Md, N=HC, K=C, lda=C, ldw=C, ldc=HC, epi=UD_EPI_F16,
                gA=Md * C, gW=HC * C, gBias=HC, gOut=Md * HC, tag="dh.q(x4)", **G4)
