@@ -113,6 +113,11 @@ typedef struct UdGemm {
    *     folded into W / bias as before): rstd (x - mean) W^T = rstd (x W^T - mean 1 W^T).  fp16(x) carries the same 2^-11 relative
    *     rounding as fp16(LN(x)) when |mean| <~ std, which holds for residual streams (tap tests).  At most 4 tiles per workgroup.
    *   ln_D / ln_eps: read by the producer when row_stats_final is set; ln_slabs: unused by the kernels (kept for program recording). */
+  float* max_out;              /* UD_EPI_F32, optional: fp32 [*, ldc] laid out like `out`; max_init != 0: max_out = stored value, else max_out =
+                                * max(max_out, stored value) -- the running element-wise maximum over the block outputs of a ConvNeXt stage
+                                * (utils/misc.py:18-21 max_stack, unidepthv1/decoder.py:366-373) taken where the value is produced instead of by
+                                * a separate pass over the stream (ud_max_f32: 36 launches, 12 B per element) */
+  int max_init;
   int grp_rows;                /* internal (callers leave 0): set by ud_gemm_f16 when it runs a grouped problem -- `groups` GEMMs stacked along M --
                                 * as ONE tile list of the large-tile kernel: rows per group */
   float* row_stats_out;

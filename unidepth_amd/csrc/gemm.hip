@@ -326,6 +326,16 @@ __device__ __forceinline__ void gemm_epilogue_impl(const UdGemm& p, f32x4 (&acc)
             for (int r = 0; r < 4; ++r) v[r] = ud_clampexp(v[r]);
           }
           if (p.accumulate != 2) *(f32x4*)dst = v;     // accumulate == 2: the fp32 stream dies here, only the fp16 copy is consumed
+          if (p.max_out) {                             // running element-wise maximum over successive launches (utils/misc.py:18-21 max_stack)
+            float* mp = p.max_out + (size_t)orow * p.ldc + nb;
+            f32x4 mv = v;
+            if (!p.max_init) {
+              const f32x4 mo = *(const f32x4*)mp;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) mv[r] = fmaxf(mo[r], v[r]);
+            }
+            *(f32x4*)mp = mv;
+          }
           ud_row_stats_acc(v, rs1, rs2);
           if (out2) {
             half4 h;
@@ -1169,6 +1179,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(biasp + nbase + j * 16 + 4 * fq);
         float* o = (float*)p.out + (size_t)(mbase + frow) * p.ldc + nbase + 4 * fq;
+        float* omax = p.max_out ? p.max_out + (size_t)(mbase + frow) * p.ldc + nbase + 4 * fq : nullptr;
         half_t* o2 = p.out2 ? (half_t*)p.out2 + (size_t)(mbase + frow) * p.ldc2 + nbase + 16 * (fq & 1) + 8 * (fq >> 1) : nullptr;
         const bool wr32 = p.accumulate != 2;   // accumulate == 2: the fp32 stream dies here, only the fp16 copy is consumed
         const bool lre = p.act2 == UD_ACT_LRELU;
@@ -1180,6 +1191,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
           for (int j = 0; j < 4; ++j) {
             const f32x4 v = acc[i][j] + bv[j];
             if (wr32) *(f32x4*)(o + (size_t)(i * 16) * p.ldc + j * 16) = v;
+            if (omax) {
+              float* mp = omax + (size_t)(i * 16) * p.ldc + j * 16;
+              f32x4 mv = v;
+              if (!p.max_init) {
+                const f32x4 mo = *(const f32x4*)mp;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mv[r] = fmaxf(mo[r], v[r]);
+              }
+              *(f32x4*)mp = mv;
+            }
             ud_row_stats_acc(v, rs1, rs2);
             if (o2) {
               f32x4 a = v;
@@ -1750,10 +1771,14 @@ int dispatch_bn(const UdGemm& d, hipStream_t s) {
 // outputs stacked), rows per group a multiple of the tile height.  Returns true and the merged descriptor when that form applies and
 // the tile-shape model prefers the large kernel for the merged problem.
 inline bool grouped_as_big(const UdGemm& d, UdGemm& m) {
-  if (d.groups <= 1 || d.amode != UD_A_DENSE || (d.M & 255) || d.tile_hint == 1 || d.a_wrap || d.w_wrap || d.row_stats_in || d.row_stats_out ||
+  if (d.groups <= 1 || d.amode != UD_A_DENSE || (d.M & 255) || d.tile_hint == 1 || d.a_wrap || d.w_wrap || d.row_stats_in || d.row_stats_out || d.max_out ||
       d.rows_in || d.add)
     return false;
-  if (d.epi != UD_EPI_F16 && d.epi != UD_EPI_F32 && d.epi != UD_EPI_QKV) return false;
+  // fp16 epilogues only: the fp32 (accumulate) epilogues of the x4 launches are traffic-bound (fp32 read + write of the stream) and ran
+  // SLOWER as 344 large tiles with the residual preload exposed per tile (dh.out 68 -> 80 us, dh.fc2 147 -> 164 us, adapters 89 -> 86)
+  // than as blockIdx.z slices of the 128-row kernel; dh.fc1 198 -> 135 us, dh.kv 87 -> 66 us, dh.q 50 -> 44 us (same-run table,
+  // profiles/r03_ops_per_launch.tsv against the r3c5 run)
+  if (d.epi != UD_EPI_F16 && d.epi != UD_EPI_QKV) return false;
   if (!(d.gA == 0 || d.gA == (long long)d.M * d.lda) || d.gOut != (long long)d.M * d.ldc) return false;
   if (d.bias && d.gBias < 0) return false;
   if (d.out2) {
@@ -1800,6 +1825,10 @@ extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
                    "and a problem the large-tile kernel takes with at most 4 tiles per workgroup (ud_gemm_pick >= 3)");
       return UD_ERR_UNSUPPORTED;
     }
+  }
+  if (d.max_out && (d.epi != UD_EPI_F32 || d.rows_in || d.accumulate == 2)) {
+    ud_set_error("ud_gemm_f16: max_out needs the fp32 epilogue without a row remap");
+    return UD_ERR_UNSUPPORTED;
   }
   if (d.row_stats_out) {
     const int bt = d.amode == UD_A_DENSE || d.amode == UD_A_CONV3_ZERO ? pick_tiles(d) : 0;

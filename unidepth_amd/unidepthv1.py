@@ -294,9 +294,9 @@ class _EncPlan:
                 P.layernorm(x=y, y=xh, rows=rows, D=C, ldx=C, ldy=C, eps=1e-6, rows_per_img=rows, in_rows_per_img=rows, out_rows_per_img=rows)
                 P.gemm(A=xh, W=w[f"blk.{s}.{i}.fc1.w"], bias=w[f"blk.{s}.{i}.fc1.b"], out=hid, M=rows, N=4 * C, lda=C, ldc=4 * C,
                        epi=UD_EPI_F16, act=UD_ACT_GELU, tag=f"enc.fc1.s{s}", **_wk(w[f"blk.{s}.{i}.fc1.w"], C))
+                # the stage's running maximum over its block outputs (max_stack) is taken in this epilogue, where the value is produced
                 P.gemm(A=hid, W=w[f"blk.{s}.{i}.fc2.w"], bias=w[f"blk.{s}.{i}.fc2.b"], out=x, M=rows, N=C, lda=4 * C, ldc=C,
-                       epi=UD_EPI_F32, accumulate=1, tag=f"enc.fc2.s{s}", **_wk(w[f"blk.{s}.{i}.fc2.w"], 4 * C))
-                P.max_(smax, x, rows * C, i == 0)
+                       epi=UD_EPI_F32, accumulate=1, tag=f"enc.fc2.s{s}", max_out=smax, max_init=int(i == 0), **_wk(w[f"blk.{s}.{i}.fc2.w"], 4 * C))
                 if blk >= nblk - 4:                        # the decoder reads the class tokens of the LAST four blocks (decoder.py:375-377)
                     cbuf = z(B, C, dtype=f32)
                     P.spatial_mean(x, cbuf, B, H * W, C, C)
