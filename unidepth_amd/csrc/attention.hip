@@ -34,8 +34,11 @@ constexpr int STAGE = KS_BYTES + VS_BYTES;
 //   busy 34 %).  A growing maximum (deferred, threshold 2^8 as before) is handled on the rare path by shifting S''.
 //   MODE 2 additionally forms the row sums with v_dot2_f32_f16 on the packed P pairs (16 instead of 32 adds; the sum is then over the
 //   ROUNDED probabilities, i.e. exactly what P V multiplies).
-template <int ABL, int MODE>
-__global__ __launch_bounds__(256) void attention_kernel(const UdAttention p, const float defer_thr) {
+// NW = waves per workgroup (4 or 8), 32 query rows each: the NW * 32 rows of a workgroup share every K / V^T tile it stages, so 8 waves
+// halve the L2 -> LDS traffic and the DMA issue + barrier work per query row (the ablation of the 4-wave kernel put the K / V traffic at
+// ~20 % of its time); the register budget (<= 128 VGPRs at 512 threads) is the 4-wave kernel's own 124.
+template <int ABL, int MODE, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void attention_kernel(const UdAttention p, const float defer_thr) {
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const UdAttention p, con
   // (2 x 175 KB at N = 1370), so all of them go to ONE XCD, in consecutive dispatch slots -- with the natural 3-D grid they
   // were spread over all 8 private L2s and every XCD pulled nearly every K/V through the fabric (rocprofv3 FETCH_SIZE
   // 403 MB per launch against 67 MB of unique Q/K/V: the kernel ran at the fabric read rate, 4.1 TB/s, not at MFMA rate).
-  const int qt = (p.Nq + 127) >> 7;
+  const int qt = (p.Nq + NW * 32 - 1) / (NW * 32);
   const int pairs = p.B * p.H;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int pr = xcd + 8 * (slot / qt);
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const UdAttention p, con
   const int head = pr % p.H;
   const int img = pr / p.H;
   const int kimg = p.kv_broadcast ? (p.kv_group > 0 ? img / p.kv_group : 0) : img;
-  const int q0 = (slot % qt) * 128 + wv * 32;
+  const int q0 = (slot % qt) * (NW * 32) + wv * 32;
 
   const half_t* Q = (const half_t*)p.Q;
   const half_t* K = (const half_t*)p.K;
@@ -77,10 +80,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const UdAttention p, con
   const int lrow = lane >> 3, lch = lane & 7;
   const ud_rsrc_t rK = ud_make_rsrc(K + (size_t)kimg * p.k_rows_per_img * p.ldk + head * 64, (unsigned)((p.Nk - 1) * p.ldk + 64) * 2u);
   const ud_rsrc_t rV = ud_make_rsrc(Vt, 64u * (unsigned)p.kv_ld * 2u);
-  unsigned koff[2], voff[2];
+  constexpr int PW = 8 / NW;                              // 1-KiB pieces per wave and operand tile (8 pieces each)
+  unsigned koff[PW], voff[PW];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = (wv * 2 + i) * 8 + lrow;              // key (K tile) / d (V^T tile)
+  for (int i = 0; i < PW; ++i) {
+    const int row = (wv * PW + i) * 8 + lrow;             // key (K tile) / d (V^T tile)
     const int ch = lch ^ ((row >> 1) & 7);
     koff[i] = (unsigned)(row * p.ldk + ch * 8) * 2u;
     voff[i] = (unsigned)(row * p.kv_ld + ch * 8) * 2u;
@@ -89,8 +93,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const UdAttention p, con
   auto issue = [&](int kt, int stage) {
     char* sb = smem + stage * STAGE;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int piece = wv * 2 + i;
+    for (int i = 0; i < PW; ++i) {
+      const int piece = wv * PW + i;
       ud_bufl16(rK, koff[i] + (unsigned)kt * kstep, 0, sb + piece * 1024);
       ud_bufl16(rV, voff[i], kt * (KT * 2), sb + KS_BYTES + piece * 1024);
     }
@@ -275,7 +279,16 @@ extern "C" int ud_attention_f16(const UdAttention* desc, void* stream) {
     ud_set_error("ud_attention_f16: bad argument (ldq/ldk % 8, kv_ld % 64, kv_ld >= roundup(Nk, 64))");
     return UD_ERR_BAD_ARG;
   }
-  const int qt = (d.Nq + 127) / 128, pairs = d.B * d.H;
+#ifndef UD_ATTN_NW
+#define UD_ATTN_NW 4
+#endif
+  // -DUD_ATTN_NW=8: 8-wave workgroups (256 query rows share each staged K / V^T tile) for long query sequences.  Measured on the encoder
+  // shape (B = 8, H = 16, N = 1370), interleaved against the 4-wave build on one box: 90.6 / 90.7 us against 86.3 / 90.4 us -- halving the
+  // K / V staging traffic buys nothing (105 instead of 124 VGPRs, same 16 waves per CU), and 6 tiles of 256 rows waste 5 of 48 wave slots
+  // per (image, head) where 11 tiles of 128 rows waste 1 of 44.  The product builds the 4-wave form.
+  const bool wide = UD_ATTN_NW == 8 && d.Nq >= 512;
+  const int rows_wg = wide ? 256 : 128;
+  const int qt = (d.Nq + rows_wg - 1) / rows_wg, pairs = d.B * d.H;
   dim3 grid(8 * ((pairs + 7) / 8) * qt);
   const float thr = (ud_debug_flags_host() & 1) ? -1.0f : 8.0f;
   const int extra_lds = ((ud_debug_flags_host() >> 16) & 255) * 1024;   // tools only: occupancy experiments
@@ -289,7 +302,10 @@ extern "C" int ud_attention_f16(const UdAttention* desc, void* stream) {
 #ifndef UD_ATTN_PRE_MODE
 #define UD_ATTN_PRE_MODE 1
 #endif
-  if (d.q_prescaled) hipLaunchKernelGGL((attention_kernel<0, UD_ATTN_PRE_MODE>), grid, dim3(256), extra_lds, (hipStream_t)stream, d, thr);
+  if (wide) {
+    if (d.q_prescaled) hipLaunchKernelGGL((attention_kernel<0, UD_ATTN_PRE_MODE, 8>), grid, dim3(512), extra_lds, (hipStream_t)stream, d, thr);
+    else hipLaunchKernelGGL((attention_kernel<0, 0, 8>), grid, dim3(512), extra_lds, (hipStream_t)stream, d, thr);
+  } else if (d.q_prescaled) hipLaunchKernelGGL((attention_kernel<0, UD_ATTN_PRE_MODE>), grid, dim3(256), extra_lds, (hipStream_t)stream, d, thr);
   else hipLaunchKernelGGL((attention_kernel<0, 0>), grid, dim3(256), extra_lds, (hipStream_t)stream, d, thr);
 #endif
   UD_CHECK_LAUNCH("ud_attention_f16 launch");
