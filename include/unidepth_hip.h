@@ -329,10 +329,13 @@ int ud_spatial_mean_f32(const float* x, float* out, int B, int HW, int C, int ld
  *                i = B, Hn, Wn, pad_l, pad_t; f[0] = ratio
  *  POINTS        z map + K33 -> points [B,3,H,W] (out), depth [B,1,H,W] (out2) (unidepthv1.py:353-371; utils/geometric.py:45-73).  i = B, H, W, ldz, nK
  *  MEAN3         out = (a + b + c) / 3 on column 0 of strided maps (unidepthv1.py:66-77).  i = n & 0x7fffffff, ld, n >> 31
+ *  VIT_TAP       UniDepthV1 on a DINOv2 backbone: out = init ? v : max(out, v), v = patch tokens + class token of the block whose residual
+ *                stream is a [B*Np, D] (row 0 of an image = class token): unidepthv1.py:324-328 + decoder.py:366-373 max_stack; out2
+ *                (optional) = the raw class tokens [B, D].  i = B, Np, hw, D, init
  *  PREPROCESS    V1 network image (unidepthv1.py:305-321,50-56): [/255], ImageNet normalise, antialiased resize to (h, w), zero pad to (Hn, Wn).
  *                i = B, H, W, h, w, Hn, Wn, pad_l, pad_t, is_u8, div255, normalize */
 enum { UD_V1_RESIZE_AA = 1, UD_V1_SH_EMBED, UD_V1_SOFTMAX, UD_V1_ATTN_FEWQ, UD_V1_SEGMENT_MEAN, UD_V1_BMM, UD_V1_PINV_INIT, UD_V1_ADD,
-       UD_V1_COPY_ROWS, UD_V1_TRANSPOSE16, UD_V1_CAMERA, UD_V1_POINTS, UD_V1_MEAN3, UD_V1_PREPROCESS };
+       UD_V1_COPY_ROWS, UD_V1_TRANSPOSE16, UD_V1_CAMERA, UD_V1_POINTS, UD_V1_MEAN3, UD_V1_PREPROCESS, UD_V1_VIT_TAP };
 typedef struct UdV1Op {
   int kind;
   const void* a; const void* b; void* c; void* out; void* out2;

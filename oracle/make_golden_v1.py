@@ -48,6 +48,18 @@ def main():
             out = model.infer(rgb, K, skip_camera=skip)
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **v1_digest({k: v.detach() for k, v in out.items()}))
         print(name, float(out["depth"].mean()))
+    # UniDepthV1 on DINOv2 ViT-L/14 (configs/config_v1_vitl14.json)
+    from test_oracle_v1_pins import VITL_CASES, vitl_case_inputs
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = UniDepthV1(json.load(open(os.path.join(ref_loader.REF_ROOT, "configs", "config_v1_vitl14.json")))).eval()
+    cfg = synth_v1.load_config_v1("vitl14")
+    model.load_state_dict(synth_v1.make_synthetic_checkpoint_v1(cfg, 212), strict=True)
+    for name in VITL_CASES:
+        rgb, K, skip = vitl_case_inputs(name)
+        with torch.no_grad():
+            out = model.infer(rgb, K, skip_camera=skip)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **v1_digest({k: v.detach() for k, v in out.items()}))
+        print(name, float(out["depth"].mean()))
 
 
 if __name__ == "__main__":

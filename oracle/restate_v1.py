@@ -237,15 +237,66 @@ def v1_shapes(image_shape, network_shape):
     return (nh, nw), ratio, (pl, pr, pt, pb)
 
 
+VIT = {"dinov2_vitl14": (1024, 24, 16, [5, 12, 18, 24])}       # models/encoder.py:171-186
+
+
 class OracleV1(OracleConvNeXt):
     def __init__(self, config: dict, state_dict: dict):
-        super().__init__(config, state_dict)
+        name = config["model"]["pixel_encoder"]["name"]
+        self.vit = VIT.get(name)
+        if self.vit is None:
+            super().__init__(config, state_dict)
+        else:               # UniDepthV1 on DINOv2 ViT-L/14 (configs/config_v1_vitl14.json)
+            self.p = "pixel_encoder."
+            self.a = {"output_idx": list(config["model"]["pixel_encoder"].get("output_idx", self.vit[3]))}
+            self.taps, self.keep_taps = {}, False
         self.w = {k: v.detach().to(torch.float32).cpu() for k, v in state_dict.items()}
         self.cfg = config
         self.C = config["model"]["pixel_decoder"]["hidden_dim"]
         self.heads = config["model"]["num_heads"]
         self.dec_depths = list(config["model"]["pixel_decoder"]["depths"])
         self.image_shape = list(config["data"]["image_shape"])
+
+    # ---- DINOv2 encoder as UniDepthV1 builds it (unidepthv1.py:412-421: interpolate_offset = 0.1, use_norm False -> NO final LayerNorm,
+    # every block's output is returned; backbones/dinov2.py:267-347) followed by unidepthv1.py:324-328: patch tokens + class token
+    def _vit_pos_embed(self, h, w):
+        pe = self.w["pixel_encoder.pos_embed"]
+        N = pe.shape[1] - 1
+        M = int(math.sqrt(N))
+        if h * w == N and h == w:
+            return pe
+        D = pe.shape[-1]
+        grid = pe[:, 1:].reshape(1, M, M, D).permute(0, 3, 1, 2)
+        # interpolate_offset != 0: scale factors (h + 0.1) / M instead of an output size (dinov2.py:283-296, "historical kludge")
+        grid = F.interpolate(grid, scale_factor=(float(h + 0.1) / M, float(w + 0.1) / M), mode="bicubic", antialias=False)
+        assert tuple(grid.shape[-2:]) == (h, w)
+        return torch.cat([pe[:, :1], grid.permute(0, 2, 3, 1).reshape(1, -1, D)], dim=1)
+
+    def encode(self, image):
+        if self.vit is None:
+            return super().encode(image)
+        D, depth, heads, _ = self.vit
+        w, pe = self.w, "pixel_encoder."
+        B, _, Hn, Wn = image.shape
+        h, wd = Hn // 14, Wn // 14
+        x = F.conv2d(image, w[pe + "patch_embed.proj.weight"], w[pe + "patch_embed.proj.bias"], stride=14).flatten(2).transpose(1, 2)
+        x = torch.cat([w[pe + "cls_token"].expand(B, -1, -1), x], dim=1) + self._vit_pos_embed(h, wd)
+        outs, cls = [], []
+        for i in range(depth):
+            b = f"{pe}blocks.{i}"
+            y = F.layer_norm(x, (D,), w[b + ".norm1.weight"], w[b + ".norm1.bias"], 1e-6)
+            qkv = F.linear(y, w[b + ".attn.qkv.weight"], w[b + ".attn.qkv.bias"])
+            N = qkv.shape[1]
+            qkv = qkv.reshape(B, N, 3, heads, D // heads).permute(2, 0, 3, 1, 4)
+            o = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2]).transpose(1, 2).reshape(B, N, D)
+            x = x + F.linear(o, w[b + ".attn.proj.weight"], w[b + ".attn.proj.bias"]) * w[b + ".ls1.gamma"]
+            y = F.layer_norm(x, (D,), w[b + ".norm2.weight"], w[b + ".norm2.bias"], 1e-6)
+            y = F.linear(F.gelu(F.linear(y, w[b + ".mlp.fc1.weight"], w[b + ".mlp.fc1.bias"])), w[b + ".mlp.fc2.weight"], w[b + ".mlp.fc2.bias"])
+            x = x + y * w[b + ".ls2.gamma"]
+            c = x[:, :1]
+            cls.append(c.contiguous())
+            outs.append((x[:, 1:].reshape(B, h, wd, D) + c.unsqueeze(1)).contiguous())       # unidepthv1.py:324-328
+        return outs, cls
 
     # ---- small blocks
     def _ln(self, x, name, eps=1e-5):
@@ -307,6 +358,8 @@ class OracleV1(OracleConvNeXt):
         toks = [cls[-i - 1] for i in range(4)]
         res = [tuple(sorted([f.shape[1], f.shape[2]])) for f in feats]
         level_shapes = sorted(set(res))[::-1]
+        if len(level_shapes) == 1:                         # ViT: one resolution for all levels (decoder.py:391-392)
+            level_shapes = level_shapes * 4
         assert len(level_shapes) == 4
         common = level_shapes[-2]
         flat = [flat_interpolate(f.reshape(B, -1, f.shape[-1]), level_shapes[i], common) for i, f in enumerate(feats)]

@@ -21,15 +21,42 @@ def load_config_v1(name: str = "cnvnxtl") -> dict:
         return json.load(f)
 
 
+VIT = {"dinov2_vitl14": (1024, 24, 16, [5, 12, 18, 24])}       # encoder.py:171-186: embed dim, blocks, heads, default output_idx
+
+
 def v1_param_shapes(config: dict) -> "OrderedDict[str, tuple]":
-    from .restate_v1 import convnext_arch
-    a = convnext_arch(config)
-    depths, dims = a["depths"], a["dims"]
     C = config["model"]["pixel_decoder"]["hidden_dim"]
     E = config["model"]["expansion"]
     dec_depths = list(config["model"]["pixel_decoder"]["depths"])
     s: "OrderedDict[str, tuple]" = OrderedDict()
     pe = "pixel_encoder."
+    name = config["model"]["pixel_encoder"]["name"]
+    if name in VIT:
+        # UniDepthV1 on DINOv2 ViT-L/14 (configs/config_v1_vitl14.json; backbones/dinov2.py:115-264): same encoder keys as the V2 checkpoints
+        D, depth, _, ends = VIT[name]
+        ends = list(config["model"]["pixel_encoder"].get("output_idx", ends))
+        s[pe + "cls_token"] = (1, 1, D)
+        s[pe + "pos_embed"] = (1, 37 * 37 + 1, D)
+        s[pe + "register_tokens"] = (1, 1, D)
+        s[pe + "mask_token"] = (1, D)
+        s[pe + "patch_embed.proj.weight"] = (D, 3, 14, 14)
+        s[pe + "patch_embed.proj.bias"] = (D,)
+        for i in range(depth):
+            b = f"{pe}blocks.{i}."
+            s[b + "norm1.weight"] = (D,); s[b + "norm1.bias"] = (D,)
+            s[b + "attn.qkv.weight"] = (3 * D, D); s[b + "attn.qkv.bias"] = (3 * D,)
+            s[b + "attn.proj.weight"] = (D, D); s[b + "attn.proj.bias"] = (D,)
+            s[b + "ls1.gamma"] = (D,)
+            s[b + "norm2.weight"] = (D,); s[b + "norm2.bias"] = (D,)
+            s[b + "mlp.fc1.weight"] = (4 * D, D); s[b + "mlp.fc1.bias"] = (4 * D,)
+            s[b + "mlp.fc2.weight"] = (D, 4 * D); s[b + "mlp.fc2.bias"] = (D,)
+            s[b + "ls2.gamma"] = (D,)
+        s[pe + "norm.weight"] = (D,); s[pe + "norm.bias"] = (D,)
+        embed_dims = [D] * depth
+        return _v1_decoder_shapes(s, config, ends, embed_dims, C, E, dec_depths)
+    from .restate_v1 import convnext_arch
+    a = convnext_arch(config)
+    depths, dims = a["depths"], a["dims"]
     s[pe + "mask_token"] = (1, dims[0], 1, 1)
     s[pe + "stem.0.weight"] = (dims[0], 3, 4, 4); s[pe + "stem.0.bias"] = (dims[0],)
     s[pe + "stem.1.weight"] = (dims[0],); s[pe + "stem.1.bias"] = (dims[0],)
@@ -45,9 +72,13 @@ def v1_param_shapes(config: dict) -> "OrderedDict[str, tuple]":
             s[p + "mlp.fc1.weight"] = (4 * d, d); s[p + "mlp.fc1.bias"] = (4 * d,)
             s[p + "mlp.fc2.weight"] = (d, 4 * d); s[p + "mlp.fc2.bias"] = (d,)
 
-    pd = "pixel_decoder."
     ends = a["output_idx"]
     embed_dims = [d for dep, d in zip(depths, dims) for _ in range(dep)]
+    return _v1_decoder_shapes(s, config, ends, embed_dims, C, E, dec_depths)
+
+
+def _v1_decoder_shapes(s, config, ends, embed_dims, C, E, dec_depths):
+    pd = "pixel_decoder."
     in_dims = [embed_dims[e - 1] for e in ends]                       # decoder.py:480
     tok_dims = [embed_dims[-i - 1] for i in range(len(ends))]         # decoder.py:478 (the LAST four blocks, deepest first)
     s[pd + "level_embeds"] = (len(in_dims), C)
@@ -119,10 +150,12 @@ def make_synthetic_checkpoint_v1(config: dict, seed: int = 211, encoder_only: bo
             continue
         leaf = k.rsplit(".", 1)[-1]
         t = torch.randn(shp, generator=g, dtype=torch.float32)
-        is_norm = len(shp) == 1 and (".norm" in k or "stem.1." in k or "downsample.0." in k or ".input_adapters." in k and k.split(".")[-2] == "0"
+        is_norm = len(shp) == 1 and (".norm" in k or "encoder.norm." in k or "stem.1." in k or "downsample.0." in k or ".input_adapters." in k and k.split(".")[-2] == "0"
                                      or "cls_project.0." in k or "level_embed_layer.3." in k)
-        if k.endswith("latents_pos") or k.endswith("level_embeds"):
+        if k.endswith("latents_pos") or k.endswith("level_embeds") or k.endswith("pos_embed") or k.endswith("cls_token"):
             t = t * 0.5
+        elif k.endswith("register_tokens"):
+            t = t * 0.02                            # unused (num_register_tokens = 0)
         elif k.endswith("mask_token"):
             t = t * 0.02                            # unused by infer()
         elif leaf == "gamma":

@@ -157,8 +157,8 @@ def test_hubconf_at_repo_root():
 
 
 def test_hub_entry_point_surface():
-    """hubconf.UniDepth(version, backbone, pretrained) signature (reference hubconf.py:25-41): V2 configs resolve, v1/cnvnxtl builds the
-    engine's UniDepthV1 (encoder half; its infer() names what is missing), everything else fails loudly."""
+    """hubconf.UniDepth(version, backbone, pretrained) signature (reference hubconf.py:25-41): V2 configs resolve, v1 / cnvnxtl and
+    v1 / vitl14 build the engine's UniDepthV1, v2old fails loudly."""
     import pytest
     import unidepth_amd
     m = unidepth_amd.UniDepth(version="v2", backbone="vits14", pretrained=False)
@@ -167,8 +167,8 @@ def test_hub_entry_point_surface():
         unidepth_amd.UniDepth(version="v2", backbone="cnvnxtl", pretrained=False)
     m1 = unidepth_amd.UniDepth(version="v1", backbone="cnvnxtl", pretrained=False)
     assert type(m1).__name__ == "UniDepthV1" and m1.image_shape == [462, 616] and len(m1.embed_dims) == 36 and m1.depths == [3, 6, 33, 36]
-    with pytest.raises(NotImplementedError):
-        unidepth_amd.UniDepth(version="v1", backbone="vitl14", pretrained=False)
+    m2 = unidepth_amd.UniDepth(version="v1", backbone="vitl14", pretrained=False)
+    assert type(m2).__name__ == "UniDepthV1" and len(m2.embed_dims) == 24 and m2.depths == [5, 12, 18, 24] and m2.patch_size == 14 and m1.patch_size == 16
     with pytest.raises(NotImplementedError):
         unidepth_amd.UniDepth(version="v2old", backbone="vitl14", pretrained=False)
     with pytest.raises(RuntimeError):

@@ -20,7 +20,7 @@ def _image(B=1, H=128, W=160, seed=3):
     return torch.randn(B, 3, H, W, generator=g)
 
 
-def _reference_v1(sd):
+def _reference_v1(sd, backbone="cnvnxtl"):
     import contextlib
     import io
     import json
@@ -28,7 +28,7 @@ def _reference_v1(sd):
     with warnings.catch_warnings(), contextlib.redirect_stdout(io.StringIO()):
         warnings.simplefilter("ignore")
         from unidepth.models import UniDepthV1  # type: ignore
-        cfg = json.load(open(os.path.join(ref_loader.REF_ROOT, "configs", "config_v1_cnvnxtl.json")))
+        cfg = json.load(open(os.path.join(ref_loader.REF_ROOT, "configs", f"config_v1_{backbone}.json")))
         model = UniDepthV1(cfg).eval()
     return model
 
@@ -125,6 +125,57 @@ def test_v1_infer_matches_live_reference_with_nystrom_stub():
         o = orc.infer(rgb, None if K is None else K.clone(), skip_camera=skip)
         for k in r:
             assert (o[k] - r[k]).norm() / r[k].norm() < 2e-5, (name, k)
+
+
+VITL_CASES = {"v1vitl_infer_200x360_K": (1, 200, 360, 8, True, False), "v1vitl_infer_240x320": (1, 240, 320, 9, False, False)}
+
+
+def vitl_case_inputs(name):
+    B, H, W, seed, withK, skip = VITL_CASES[name]
+    rgb = torch.randint(0, 256, (B, 3, H, W), dtype=torch.uint8, generator=torch.Generator().manual_seed(seed))
+    return rgb, (torch.tensor(V1_K).repeat(B, 1, 1) if withK else None), skip
+
+
+@pytest.mark.skipif(not ref_loader.available(), reason="/root/reference not present (GPU box)")
+def test_v1_vitl14_matches_live_reference():
+    """UniDepthV1 on DINOv2 ViT-L/14 (reference hubconf.py:14-17, configs/config_v1_vitl14.json): strict key set of the synthetic checkpoint,
+    the encoder as V1 builds it (interpolate_offset 0.1, no final norm, every block returned, class token added: unidepthv1.py:322-328,
+    412-421) and the whole infer() against the real reference (Nystrom stub as for ConvNeXt)."""
+    warnings.simplefilter("ignore")
+    cfg = synth_v1.load_config_v1("vitl14")
+    sd = synth_v1.make_synthetic_checkpoint_v1(cfg, 212)
+    ref = _reference_v1(sd, "vitl14")
+    missing, unexpected = ref.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    orc = restate_v1.OracleV1(cfg, sd)
+    x = _image(1, 126, 168, seed=4)
+    with torch.no_grad():
+        r_outs, r_cls = ref.pixel_encoder(x)
+    outs, cls = orc.encode(x)
+    assert len(r_outs) == len(outs) == 24
+    for i in (0, 4, 11, 17, 23):
+        want = r_outs[i] + r_cls[i].unsqueeze(1)
+        assert (outs[i] - want).norm() / want.norm() < TOL, i
+        assert (cls[i] - r_cls[i]).norm() / r_cls[i].norm() < TOL, i
+    for name in VITL_CASES:
+        rgb, K, skip = vitl_case_inputs(name)
+        with torch.no_grad():
+            r = ref.infer(rgb, None if K is None else K.clone(), skip_camera=skip)
+        o = orc.infer(rgb, None if K is None else K.clone(), skip_camera=skip)
+        for k in r:
+            assert (o[k] - r[k]).norm() / r[k].norm() < 2e-5, (name, k)
+
+
+@pytest.mark.parametrize("name", list(VITL_CASES))
+def test_v1_vitl14_infer_golden(name, golden_dir):
+    cfg = synth_v1.load_config_v1("vitl14")
+    sd = synth_v1.make_synthetic_checkpoint_v1(cfg, 212)
+    rgb, K, skip = vitl_case_inputs(name)
+    got = v1_digest(restate_v1.OracleV1(cfg, sd).infer(rgb, K, skip_camera=skip))
+    want = np.load(os.path.join(golden_dir, name + ".npz"))
+    for k in want.files:
+        a, b = got[k].astype(np.float64), want[k].astype(np.float64)
+        assert a.shape == b.shape and np.linalg.norm(a - b) / np.linalg.norm(b) < 2e-5, (name, k)
 
 
 @pytest.mark.parametrize("name", list(V1_CASES))

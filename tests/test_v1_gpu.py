@@ -287,6 +287,48 @@ def test_v1_infer_config4_bs16_vs_oracle():
     print(f"v1 config4 bs=16 640x480: worst per-image depth ARel {worst:.2e}")
 
 
+def test_v1_vitl14_encoder_seam_vs_oracle():
+    """UniDepthV1 on DINOv2 ViT-L/14 (hubconf.py:14-17): the encoder as V1 runs it -- scale-factor position-embedding resample, no final
+    LayerNorm, per-level max over (patch tokens + class token), class tokens of the last four blocks -- against the pinned oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from unidepth_amd import UniDepthV1
+    cfg = synth_v1.load_config_v1("vitl14")
+    sd = synth_v1.make_synthetic_checkpoint_v1(cfg, 212)
+    x = torch.randn(2, 3, 126, 168, generator=torch.Generator().manual_seed(4))
+    orc = restate_v1.OracleV1(cfg, sd)
+    outs, cls = orc.encode(x)
+    feats_ref = orc.stage_features(outs)
+    model = UniDepthV1(cfg).load_state_dict(sd).to("cuda").eval()
+    feats, toks = model.stage_features(x.cuda())
+    torch.cuda.synchronize()
+    for j in range(4):
+        assert rel(feats[j], feats_ref[j]) < 2e-3, (j, rel(feats[j], feats_ref[j]))
+        assert rel(toks[j], cls[-j - 1]) < 2e-3, j
+    # the module seam in the reference's own form: raw patch tokens and class tokens per block
+    o2, c2 = model.pixel_encoder(x.cuda())
+    torch.cuda.synchronize()
+    assert len(o2) == 24
+    for i in (0, 11, 23):
+        assert rel(o2[i] + c2[i].unsqueeze(1), outs[i]) < 2e-3 and rel(c2[i], cls[i]) < 2e-3
+
+
+@pytest.mark.parametrize("B,H,W,withK", [(1, 240, 320, False), (2, 200, 360, True)])
+def test_v1_vitl14_infer_vs_oracle(B, H, W, withK):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from unidepth_amd import UniDepthV1
+    cfg = synth_v1.load_config_v1("vitl14")
+    sd = synth_v1.make_synthetic_checkpoint_v1(cfg, 212)
+    rgb = torch.randint(0, 256, (B, 3, H, W), dtype=torch.uint8, generator=torch.Generator().manual_seed(9))
+    K = torch.tensor([[250.0, 0.0, W / 2 - 2.0], [0.0, 251.0, H / 2 - 2.0], [0.0, 0.0, 1.0]]).repeat(B, 1, 1) if withK else None
+    ref = restate_v1.OracleV1(cfg, sd).infer(rgb, None if K is None else K.clone())
+    model = UniDepthV1(cfg).load_state_dict(sd).to("cuda").eval()
+    out = model.infer(rgb.cuda(), K)
+    torch.cuda.synchronize()
+    _v1_check(out, ref, f"v1vitl_{B}x{H}x{W}_K{int(withK)}")
+
+
 def test_v1_decoder_taps_vs_oracle():
     """Intermediate tensors of the V1 decoder (SURVEY.md 8c style): rel-L2 <= 3e-3 on every feature tap; the multi-scale outputs are
     exp(3x3 conv(features)) with |log| ~ 3 on the sensitised checkpoint, so a 1e-3 feature error is a 2..3e-3 relative output error."""

@@ -66,7 +66,7 @@ class UdExtractPatches(C.Structure):
 
 
 (UD_V1_RESIZE_AA, UD_V1_SH_EMBED, UD_V1_SOFTMAX, UD_V1_ATTN_FEWQ, UD_V1_SEGMENT_MEAN, UD_V1_BMM, UD_V1_PINV_INIT, UD_V1_ADD, UD_V1_COPY_ROWS,
- UD_V1_TRANSPOSE16, UD_V1_CAMERA, UD_V1_POINTS, UD_V1_MEAN3, UD_V1_PREPROCESS) = range(1, 15)
+ UD_V1_TRANSPOSE16, UD_V1_CAMERA, UD_V1_POINTS, UD_V1_MEAN3, UD_V1_PREPROCESS, UD_V1_VIT_TAP) = range(1, 16)
 UD_ACT_CLAMPEXP = 3
 
 

@@ -490,6 +490,29 @@ inline unsigned grid1(long long total, int cap = 256 * 32) {
 
 }  // namespace
 
+// UniDepthV1 on a DINOv2 backbone: what the decoder consumes of block i is max over the blocks of its level of (patch tokens + class token)
+// (unidepthv1.py:324-328 adds the class token to every block's patch tokens, decoder.py:366-373 max_stack) and the raw class tokens of the last
+// four blocks.  x fp32 [B*Np, D], row 0 of an image = class token, rows 1..hw = patches; smax fp32 [B*hw, D]; cls fp32 [B, D] or NULL.
+__global__ __launch_bounds__(256) void vit_tap_kernel(const float* __restrict__ x, float* __restrict__ smax, float* __restrict__ cls, int Np, int hw, int D4, int init) {
+  const int b = blockIdx.y;
+  const f32x4* xb = (const f32x4*)x + (size_t)b * Np * D4;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < (long long)hw * D4; idx += (long long)gridDim.x * 256) {
+    const int t = (int)(idx / D4), c = (int)(idx - (long long)t * D4);
+    const f32x4 v = xb[(size_t)(1 + t) * D4 + c] + xb[c];
+    f32x4* dst = (f32x4*)smax + ((size_t)b * hw + t) * D4 + c;
+    if (init) {
+      *dst = v;
+    } else {
+      const f32x4 o = *dst;
+      f32x4 m;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m[r] = fmaxf(o[r], v[r]);
+      *dst = m;
+    }
+    if (cls && t == 0) ((f32x4*)cls)[(size_t)b * D4 + c] = xb[c];
+  }
+}
+
 extern "C" int ud_v1_op(const UdV1Op* desc, void* stream) {
   const UdV1Op& d = *desc;
   hipStream_t s = (hipStream_t)stream;
@@ -556,6 +579,14 @@ extern "C" int ud_v1_op(const UdV1Op* desc, void* stream) {
       if (!d.a || !d.b || !d.out || n <= 0 || (n & 3)) break;
       hipLaunchKernelGGL(add_kernel, dim3(grid1(n / 4)), dim3(256), 0, s, (float*)d.out, (const float*)d.a, (const float*)d.b, n / 4);
       UD_CHECK_LAUNCH("ud_v1_op(add) launch");
+      return UD_OK;
+    }
+    case UD_V1_VIT_TAP: {        // a = x fp32 [B*Np, D]; out = smax fp32 [B*hw, D]; out2 = cls fp32 [B, D] or NULL; i = B, Np, hw, D, init
+      if (!d.a || !d.out || i[0] <= 0 || i[2] <= 0 || i[1] <= i[2] || (i[3] & 3)) break;
+      const long long n = (long long)i[2] * (i[3] / 4);
+      hipLaunchKernelGGL(vit_tap_kernel, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048), i[0]), dim3(256), 0, s, (const float*)d.a, (float*)d.out, (float*)d.out2,
+                         i[1], i[2], i[3] / 4, i[4]);
+      UD_CHECK_LAUNCH("ud_v1_op(vit_tap) launch");
       return UD_OK;
     }
     case UD_V1_COPY_ROWS: {      // a = src fp32 [n_img*T, D]; out rows (img*rows_per_img + row_off + t), stride ld; i = n_img, T, rows_per_img, row_off, D, ld, to_f16

@@ -1,8 +1,8 @@
 """`UniDepth(version, backbone, pretrained)` entry point with the reference's hubconf signature (hubconf.py:25-41): builds the
 engine class for the version from the shipped architecture config and, if `pretrained`, fetches `pytorch_model.bin` from the
 `lpiccinelli/unidepth-<version>-<backbone>` hub repository (needs network access or a warm huggingface cache).
-The V2 ViT backbones and `v1` / `cnvnxtl` (UniDepthV1 on ConvNeXt-L: encoder + decoder, unidepthv1.py) run end to end on the engine;
-`v2old` and the V1 ViT-L variant raise NotImplementedError.
+The V2 ViT backbones and both V1 variants (`v1` / `cnvnxtl`: ConvNeXt-L; `v1` / `vitl14`: DINOv2 ViT-L/14; unidepthv1.py) run end to end on the
+engine; `v2old` raises NotImplementedError.
 
 UniDepthV1 caveat (parity UNPINNED for its two Nystrom stages): the reference computes `layers_8` / `layers_4` with
 xformers' NystromAttention, a dependency that is neither vendored nor pinned, and hands it 4-D [b, n, h, d] tensors
@@ -26,8 +26,8 @@ from .unidepthv1 import UniDepthV1  # noqa: E402,F401  (ConvNeXt-L encoder + V1 
 def UniDepth(version: str = "v2", backbone: str = "vitl14", pretrained: bool = True):
     assert version in BACKBONES, f"version must be one of {list(BACKBONES)}"
     assert backbone in BACKBONES[version], f"backbone for current version ({version}) must be one of {BACKBONES[version]}"
-    if version == "v2old" or (version == "v1" and backbone != "cnvnxtl"):
-        raise NotImplementedError(f"UniDepth {version}/{backbone} is not implemented on the MI355X engine (SURVEY.md 8f next-1)")
+    if version == "v2old":
+        raise NotImplementedError(f"UniDepth {version}/{backbone} is not implemented on the MI355X engine (SURVEY.md 2: out of scope)")
     from .unidepthv2 import UniDepthV2
     with open(os.path.join(_CFG_DIR, f"config_{version}_{backbone}.json")) as f:
         config = json.load(f)

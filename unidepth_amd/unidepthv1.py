@@ -22,6 +22,7 @@ from . import ops
 from .ops import UD_ACT_GELU, UD_EPI_F16, UD_EPI_F32
 
 CONVNEXT = {"convnext_large": dict(depths=(3, 3, 27, 3), dims=(192, 384, 768, 1536))}     # models/encoder.py:127-136
+VIT = {"dinov2_vitl14": dict(D=1024, depth=24, heads=16, output_idx=[5, 12, 18, 24])}        # models/encoder.py:171-186 (hubconf.py:14-17 v1 / vitl14)
 
 
 def _rup(x, m):
@@ -102,6 +103,38 @@ def _ak(Wt: torch.Tensor, K: int) -> dict:
         return dict(K=2 * K, lda=2 * K, w_wrap=K)
     assert Wt.shape[1] == K, (tuple(Wt.shape), K)
     return dict(K=K, lda=K)
+
+
+def pack_vit(config: dict, sd: dict, device) -> dict:
+    """UniDepthV1 on DINOv2 ViT-L/14: the encoder's GEMM operands through the V2 packer's folds (weights.pack_vit_blocks), stored like every
+    other V1 weight (two fp16 terms when WSPLIT); the resampled position embedding / class token stay on the host side per grid."""
+    from .weights import pack_vit_blocks
+    a = VIT[config["model"]["pixel_encoder"]["name"]]
+    f = {k: v.detach().to(torch.float32).cpu() for k, v in sd.items() if k.startswith("pixel_encoder.")}
+    w = {}
+
+    def put16(name, t, wsum=False):
+        w[name] = _padk16(t).to(device)
+
+    def put32(name, t):
+        w[name] = t.to(torch.float32).contiguous().to(device)
+    pack_vit_blocks(f, a["D"], a["depth"], a["heads"], put16, put32)
+    w["host.pos_embed"] = f["pixel_encoder.pos_embed"]
+    w["host.cls_token"] = f["pixel_encoder.cls_token"].reshape(-1)
+    return w
+
+
+def vit_pos_embed_v1(pe: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """[1, 1 + M*M, D] -> [1 + h*w, D]: bicubic resample with the SCALE-FACTOR form V1 builds its DINOv2 with (interpolate_offset = 0.1:
+    unidepthv1.py:412-421, backbones/dinov2.py:283-296) -- not the output-size form of the V2 models."""
+    n = pe.shape[1] - 1
+    m = int(math.sqrt(n))
+    if h * w == n and h == w:
+        return pe[0].contiguous()
+    grid = pe[:, 1:].reshape(1, m, m, -1).permute(0, 3, 1, 2)
+    grid = torch.nn.functional.interpolate(grid, scale_factor=(float(h + 0.1) / m, float(w + 0.1) / m), mode="bicubic", antialias=False)
+    assert tuple(grid.shape[-2:]) == (h, w)
+    return torch.cat([pe[0, :1], grid.permute(0, 2, 3, 1).reshape(h * w, -1)], 0).contiguous()
 
 
 def _fold_ln(w, b, g, beta):
@@ -307,20 +340,94 @@ class _EncPlan:
             self.stage_max.append(smax)
 
 
+class _EncPlanViT:
+    """DINOv2 ViT-L/14 as UniDepthV1 runs it (backbones/dinov2.py:306-347 with use_norm False: no final LayerNorm, every block is an output;
+    unidepthv1.py:322-328 adds each block's class token to its patch tokens): the V2 engine's block program (LayerNorm statistics kernel,
+    fused qkv / attention / proj / fc1 + GELU / fc2 GEMMs) + after every block the running max of its level and, for the last four blocks,
+    the class token (UD_V1_VIT_TAP).  Same attributes as _EncPlan: shapes, stage_max, cls."""
+
+    def __init__(self, model: "UniDepthV1", B: int, Hn: int, Wn: int, P: Optional[ops.Program] = None, img: Optional[torch.Tensor] = None):
+        from . import _lib as L
+        from .ops import UD_EPI_QKV
+        w, dev, a = model._w, model.device, model._arch
+        D, depth, heads = a["D"], a["depth"], a["heads"]
+        f16, f32 = torch.float16, torch.float32
+        assert Hn % 14 == 0 and Wn % 14 == 0, "UniDepthV1 / ViT: the network image must be a multiple of the patch size"
+
+        def z(*shape, dtype=f16):
+            return torch.zeros(*shape, dtype=dtype, device=dev)
+
+        P = ops.Program() if P is None else P
+        self.prog, self.B = P, B
+        self.tap_points = []
+        self.img = z(B, 3, Hn, Wn, dtype=f32) if img is None else img
+        h, wg = Hn // 14, Wn // 14
+        hw = h * wg
+        N = hw + 1
+        Np, Nkp = _rup(N, 16), _rup(N, 64)
+        M = B * Np
+        patches = z(B * hw, 640)
+        P.preprocess(rgb=self.img, patches=patches, B=B, H=Hn, W=Wn, pad_l=0, pad_t=0, Hp=Hn, Wp=Wn, Hn=Hn, Wn=Wn, ldp=640, is_u8=0, normalize=0,
+                     mean=(0.0, 0.0, 0.0), inv_std=(1.0, 1.0, 1.0))
+        pos = vit_pos_embed_v1(w["host.pos_embed"], h, wg).to(dev)
+        cls_row = (w["host.cls_token"] + pos[0].cpu()).to(dev)
+        x = z(M, D, dtype=f32)
+        P.gemm(A=patches, W=w["patch.w"], bias=w["patch.b"], out=x, add=pos, M=B * hw, N=D, lda=640, ldc=D, ldadd=D, epi=UD_EPI_F32, rows_in=hw,
+               rows_out=Np, row_off=1, add_row_off=1, tag="vit.patch", **_wk(w["patch.w"], 640))
+        P.fill_rows(x, cls_row, B, Np, 0, D, D)
+        xn, qk, vt, ao, hid = z(M, D), z(M, 2 * D), z(B, heads, 64, Nkp), z(M, D), z(M, 4 * D)
+        ends = a["output_idx"]
+        self.stage_max = [z(B * hw, D, dtype=f32) for _ in range(4)]
+        self.cls = []
+        lvl = 0
+        for i in range(depth):
+            P.layernorm(x=x, y=xn, rows=M, D=D, ldx=D, ldy=D, eps=1e-6, rows_per_img=M, in_rows_per_img=M, out_rows_per_img=M)
+            P.gemm(A=xn, W=w[f"enc.{i}.qkv.w"], bias=w[f"enc.{i}.qkv.b"], out=qk, out2=vt, M=M, N=3 * D, lda=D, ldc=2 * D, epi=UD_EPI_QKV, vsplit=2 * D,
+                   tok_per_img=Np, kv_ld=Nkp, heads_v=heads, tag="vit.qkv", **_wk(w[f"enc.{i}.qkv.w"], D))
+            P.attention(Q=qk, K=qk.data_ptr() + D * 2, Vt=vt, O=ao, B=B, H=heads, Nq=N, Nk=N, ldq=2 * D, ldk=2 * D, ldo=D, kv_ld=Nkp, q_rows_per_img=Np,
+                        k_rows_per_img=Np, scale=(D // heads) ** -0.5, q_prescaled=1, tag="vit.attn")
+            P.gemm(A=ao, W=w[f"enc.{i}.proj.w"], bias=w[f"enc.{i}.proj.b"], out=x, M=M, N=D, lda=D, ldc=D, epi=UD_EPI_F32, accumulate=1, tag="vit.proj",
+                   **_wk(w[f"enc.{i}.proj.w"], D))
+            P.layernorm(x=x, y=xn, rows=M, D=D, ldx=D, ldy=D, eps=1e-6, rows_per_img=M, in_rows_per_img=M, out_rows_per_img=M)
+            P.gemm(A=xn, W=w[f"enc.{i}.fc1.w"], bias=w[f"enc.{i}.fc1.b"], out=hid, M=M, N=4 * D, lda=D, ldc=4 * D, epi=UD_EPI_F16, act=UD_ACT_GELU,
+                   tag="vit.fc1", **_wk(w[f"enc.{i}.fc1.w"], D))
+            P.gemm(A=hid, W=w[f"enc.{i}.fc2.w"], bias=w[f"enc.{i}.fc2.b"], out=x, M=M, N=D, lda=4 * D, ldc=D, epi=UD_EPI_F32, accumulate=1, tag="vit.fc2",
+                   **_wk(w[f"enc.{i}.fc2.w"], 4 * D))
+            first = i == (0 if lvl == 0 else ends[lvl - 1])
+            cbuf = None
+            if i >= depth - 4:                              # class tokens of the LAST four blocks (decoder.py:375-377), block order
+                cbuf = z(B, D, dtype=f32)
+                self.cls.append(cbuf)
+            P.v1(L.UD_V1_VIT_TAP, a=x, out=self.stage_max[lvl], out2=cbuf, i=(B, Np, hw, D, int(first)), tag="vit_tap")
+            self.tap_points.append((f"block{i}", len(P), (lambda x=x: x.view(B, Np, D)[:, :N].clone())))
+            if i + 1 == ends[lvl]:
+                lvl += 1
+        self.shapes = [(h, wg, D)] * 4
+        self.keep = [x, xn, qk, vt, ao, hid, patches, pos, cls_row]
+
+
 class UniDepthV1:
     """Engine counterpart of the reference's UniDepthV1 (unidepthv1.py:101).  See the module docstring for what runs today."""
 
     def __init__(self, config: dict, eps: float = 1e-6, **kwargs):
         self.config = config
         name = config["model"]["pixel_encoder"]["name"]
-        if name not in CONVNEXT:
-            raise NotImplementedError(f"UniDepthV1 pixel_encoder {name!r}: only the ConvNeXt-L backbone (config_v1_cnvnxtl) is implemented on this engine")
-        self._arch = dict(CONVNEXT[name])
-        self._arch["output_idx"] = list(config["model"]["pixel_encoder"].get("output_idx", [3, 6, 33, 36]))
-        ends = [sum(self._arch["depths"][:i + 1]) for i in range(4)]
-        if self._arch["output_idx"] != ends:
-            # the encoder program takes the element-wise max over WHOLE stages and the class tokens of the last four blocks
-            raise NotImplementedError(f"UniDepthV1 pixel_encoder.output_idx {self._arch['output_idx']}: only the stage ends {ends} are implemented")
+        if name in VIT:                              # DINOv2 ViT-L/14 (config_v1_vitl14): levels = block ranges ending at output_idx
+            self._arch = dict(VIT[name], kind="vit")
+            self._arch["output_idx"] = list(config["model"]["pixel_encoder"].get("output_idx", VIT[name]["output_idx"]))
+            oi = self._arch["output_idx"]
+            if len(oi) != 4 or oi != sorted(oi) or oi[-1] != self._arch["depth"] or oi[0] < 1:
+                raise NotImplementedError(f"UniDepthV1 / ViT output_idx {oi}: four increasing block counts ending at {self._arch['depth']} expected")
+        elif name in CONVNEXT:
+            self._arch = dict(CONVNEXT[name], kind="convnext")
+            self._arch["output_idx"] = list(config["model"]["pixel_encoder"].get("output_idx", [3, 6, 33, 36]))
+            ends = [sum(self._arch["depths"][:i + 1]) for i in range(4)]
+            if self._arch["output_idx"] != ends:
+                # the encoder program takes the element-wise max over WHOLE stages and the class tokens of the last four blocks
+                raise NotImplementedError(f"UniDepthV1 pixel_encoder.output_idx {self._arch['output_idx']}: only the stage ends {ends} are implemented")
+        else:
+            raise NotImplementedError(f"UniDepthV1 pixel_encoder {name!r}: the ConvNeXt-L (config_v1_cnvnxtl) and DINOv2 ViT-L/14 (config_v1_vitl14) "
+                                      "backbones are implemented on this engine")
         # PARITY UNPINNED for the Nystrom stages (see hub.py / oracle/restate_v1.py): warn once per model when it first runs infer()
         self.nystrom_caveat_acknowledged = os.environ.get("UNIDEPTH_V1_ACK_NYSTROM", "0") == "1"
         self.image_shape = list(config["data"]["image_shape"])                         # unidepthv1.py:444
@@ -393,7 +500,7 @@ class UniDepthV1:
             raise RuntimeError("no weights loaded (use from_pretrained or load_state_dict)")
         if self._w is None:
             with torch.cuda.device(self._device):
-                self._w = pack_convnext(self.config, self._sd, self._device)
+                self._w = (pack_vit if self._arch["kind"] == "vit" else pack_convnext)(self.config, self._sd, self._device)
                 if any(k.startswith("pixel_decoder.") for k in self._sd):
                     self._w.update(pack_v1_decoder(self.config, self._sd, self._device))
 
@@ -402,16 +509,23 @@ class UniDepthV1:
         if key not in self._plans:
             self._evict()
             with torch.cuda.device(self._device):
-                self._plans[key] = _EncPlan(self, B, Hn, Wn)
+                self._plans[key] = (_EncPlanViT if self._arch["kind"] == "vit" else _EncPlan)(self, B, Hn, Wn)
         self._plans.move_to_end(key)
         return self._plans[key]
 
     # ---- encoder seam (backbones/convnext.py:447-458) ----
-    embed_dim = 192
-    patch_size = 16                                                                   # unidepthv1.py:427-429 (non-DINO encoders)
+    @property
+    def embed_dim(self):
+        return self._arch["D"] if self._arch["kind"] == "vit" else 192
+
+    @property
+    def patch_size(self):                                                             # unidepthv1.py:427-429: 14 for DINO encoders, else 16
+        return 14 if self._arch["kind"] == "vit" else 16
 
     @property
     def embed_dims(self):
+        if self._arch["kind"] == "vit":
+            return [self._arch["D"]] * self._arch["depth"]
         return [d for dep, d in zip(self._arch["depths"], self._arch["dims"]) for _ in range(dep)]
 
     @property
@@ -428,8 +542,22 @@ class UniDepthV1:
         with torch.cuda.device(self._device):
             plan = self._enc_plan(B, Hn, Wn)
             plan.img.copy_(image.to(self._device, torch.float32), non_blocking=True)
-            n = sum(self._arch["depths"])
+            vit = self._arch["kind"] == "vit"
+            n = self._arch["depth"] if vit else sum(self._arch["depths"])
             outs: List[Optional[torch.Tensor]] = [None] * n
+            if vit:                                        # DINOv2 wrapper (backbones/dinov2.py:324-347): patch tokens [B,h,w,D] and class tokens [B,1,D] per block
+                h, w_, D = plan.shapes[0]
+                cls_v: List[Optional[torch.Tensor]] = [None] * n
+                pos = 0
+                for name, at, fn in plan.tap_points:
+                    plan.prog.run(pos, at)
+                    pos = at
+                    if keep_all or int(name[5:]) >= n - 4:
+                        xb = fn()
+                        outs[int(name[5:])] = xb[:, 1:].reshape(B, h, w_, D).contiguous() if keep_all else None
+                        cls_v[int(name[5:])] = xb[:, :1].contiguous()
+                plan.prog.run(pos, len(plan.prog))
+                return outs, cls_v
             if keep_all:
                 pos = 0
                 for name, at, fn in plan.tap_points:
@@ -634,13 +762,15 @@ class _FullPlan:
         self.rgb = torch.zeros(B, 3, H, W, dtype=torch.uint8 if is_u8 else f32, device=dev)
         img = z(B, 3, Hn, Wn, dtype=f32)
         P.v1(L.UD_V1_PREPROCESS, a=self.rgb, out=img, i=(B, H, W, h_in, w_in, Hn, Wn, pl, pt, int(is_u8), int(div255), int(normalize)), tag="preprocess")
-        enc = _EncPlan(model, B, Hn, Wn, P=P, img=img)
+        enc = (_EncPlanViT if model._arch["kind"] == "vit" else _EncPlan)(model, B, Hn, Wn, P=P, img=img)
         self.enc = enc
         self.dec_first = len(P)
         # level shapes as the reference derives them (decoder.py:380-392): sorted (short, long) sides, common = second smallest level
         lv = [tuple(sorted((hh, ww))) for hh, ww, _ in enc.shapes]
         level_shapes = sorted(set(lv))[::-1]
-        assert len(level_shapes) == 4, "UniDepthV1 decoder: the four encoder stages must have distinct resolutions"
+        if len(level_shapes) == 1:                  # ViT: one resolution for all four levels (decoder.py:391-392)
+            level_shapes = level_shapes * 4
+        assert len(level_shapes) == 4, "UniDepthV1 decoder: the encoder levels must have four distinct resolutions, or one"
         h, wd = level_shapes[-2]
         hw = h * wd
 

@@ -79,6 +79,29 @@ def _conv3_rows(w):                          # [Cout, Cin, 3, 3] -> [Cout, 9*Cin
     return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)
 
 
+def pack_vit_blocks(f: dict, D: int, depth: int, heads: int, put16, put32) -> None:
+    """The DINOv2 encoder's GEMM operands (patch embedding + `depth` blocks) from the reference's `pixel_encoder.*` tensors: norm1 / norm2
+    affines folded into qkv / fc1, LayerScale into proj / fc2, softmax scale and log2(e) into the q rows.  Shared by UniDepthV2 and by
+    UniDepthV1 on the ViT-L backbone; `put16(name, w, wsum=False)` stores a GEMM operand (its row sums too when asked)."""
+    pe = "pixel_encoder."
+    put16("patch.w", f[pe + "patch_embed.proj.weight"].reshape(D, -1))
+    put32("patch.b", f[pe + "patch_embed.proj.bias"])
+    for i in range(depth):
+        b = f"{pe}blocks.{i}."
+        w, bb = _fold_ln(f[b + "attn.qkv.weight"], f[b + "attn.qkv.bias"], f[b + "norm1.weight"], f[b + "norm1.bias"])
+        # softmax scale and the log2(e) of the kernel's exp2 live in the q projection (exact algebra; UdAttention.q_prescaled)
+        qc = (D // heads) ** -0.5 * LOG2E
+        w, bb = w.clone(), bb.clone()
+        w[:D] *= qc; bb[:D] *= qc
+        put16(f"enc.{i}.qkv.w", w, wsum=True); put32(f"enc.{i}.qkv.b", bb)
+        g1 = f[b + "ls1.gamma"]
+        put16(f"enc.{i}.proj.w", f[b + "attn.proj.weight"] * g1[:, None]); put32(f"enc.{i}.proj.b", f[b + "attn.proj.bias"] * g1)
+        w, bb = _fold_ln(f[b + "mlp.fc1.weight"], f[b + "mlp.fc1.bias"], f[b + "norm2.weight"], f[b + "norm2.bias"])
+        put16(f"enc.{i}.fc1.w", w, wsum=True); put32(f"enc.{i}.fc1.b", bb)
+        g2 = f[b + "ls2.gamma"]
+        put16(f"enc.{i}.fc2.w", f[b + "mlp.fc2.weight"] * g2[:, None]); put32(f"enc.{i}.fc2.b", f[b + "mlp.fc2.bias"] * g2)
+
+
 def pack(config: dict, sd: dict, device) -> dict:
     a = arch_of(config)
     D, C, H = a["D"], a["C"], a["dec_heads"]
@@ -98,22 +121,7 @@ def pack(config: dict, sd: dict, device) -> dict:
         out[name] = v.to(torch.float32).contiguous().to(device)
 
     pe = "pixel_encoder."
-    put16("patch.w", f[pe + "patch_embed.proj.weight"].reshape(D, -1))
-    put32("patch.b", f[pe + "patch_embed.proj.bias"])
-    for i in range(a["depth"]):
-        b = f"{pe}blocks.{i}."
-        w, bb = _fold_ln(f[b + "attn.qkv.weight"], f[b + "attn.qkv.bias"], f[b + "norm1.weight"], f[b + "norm1.bias"])
-        # softmax scale and the log2(e) of the kernel's exp2 live in the q projection (exact algebra; UdAttention.q_prescaled)
-        qc = (D // a["heads"]) ** -0.5 * LOG2E
-        w, bb = w.clone(), bb.clone()
-        w[:D] *= qc; bb[:D] *= qc
-        put16(f"enc.{i}.qkv.w", w, wsum=True); put32(f"enc.{i}.qkv.b", bb)
-        g1 = f[b + "ls1.gamma"]
-        put16(f"enc.{i}.proj.w", f[b + "attn.proj.weight"] * g1[:, None]); put32(f"enc.{i}.proj.b", f[b + "attn.proj.bias"] * g1)
-        w, bb = _fold_ln(f[b + "mlp.fc1.weight"], f[b + "mlp.fc1.bias"], f[b + "norm2.weight"], f[b + "norm2.bias"])
-        put16(f"enc.{i}.fc1.w", w, wsum=True); put32(f"enc.{i}.fc1.b", bb)
-        g2 = f[b + "ls2.gamma"]
-        put16(f"enc.{i}.fc2.w", f[b + "mlp.fc2.weight"] * g2[:, None]); put32(f"enc.{i}.fc2.b", f[b + "mlp.fc2.bias"] * g2)
+    pack_vit_blocks(f, D, a["depth"], a["heads"], put16, put32)
     gn, bn = f[pe + "norm.weight"], f[pe + "norm.bias"]
     put32("enc.norm.g", gn); put32("enc.norm.b", bn)     # only the module seams need the affine itself (it is folded into the adapters)
 
