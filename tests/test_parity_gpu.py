@@ -80,6 +80,37 @@ FEATURE_TAPS = ["tokens0", "blocks.0.attn.qkv", "block0", "block5", "block11", "
                 "to_latents", "ups.0", "ups.1"]
 
 
+def test_config5_mixed_list_bs32_vs_oracle(engine_cls):
+    """BASELINE.json configs[4] at its stated size on one GPU: 16 x 644x966 + 16 x 518x518 through dist.infer_mixed (ViT-L/14).  Every
+    output is checked for shape / finiteness, one image per shape against the fp32 oracle at the north-star bar, and the reversed list
+    must return every image's bits unchanged (bucketing and batch position do not leak into an image's result)."""
+    from unidepth_amd.dist import infer_mixed
+    case = cases.CASES["vitl_518x518_b1"]
+    cfg = synth.load_config(case["arch"])
+    sd = synth.make_synthetic_checkpoint(cfg, case["ckpt_seed"])
+    model = engine_cls(cfg).load_state_dict(sd).to("cuda").eval()
+    g = torch.Generator().manual_seed(21)
+    imgs = [torch.randint(0, 256, (3, 644, 966), dtype=torch.uint8, generator=g) for _ in range(16)] + \
+           [torch.randint(0, 256, (3, 518, 518), dtype=torch.uint8, generator=g) for _ in range(16)]
+    outs = infer_mixed(model, [im.cuda() for im in imgs], keys=("depth", "intrinsics", "confidence"), inflight=2)
+    torch.cuda.synchronize()
+    assert len(outs) == 32
+    for im, o in zip(imgs, outs):
+        assert o["depth"].shape == (1, im.shape[1], im.shape[2]) and torch.isfinite(o["depth"]).all() and (o["depth"] > 0).all()
+        assert o["intrinsics"].shape == (3, 3) and torch.isfinite(o["confidence"]).all()
+    orc = restate.OracleV2(cfg, sd)
+    for i in (3, 20):
+        ref = orc.infer(imgs[i][None])
+        d = ((outs[i]["depth"].cpu() - ref["depth"][0]).abs() / ref["depth"][0]).mean().item()
+        k = ((outs[i]["intrinsics"].cpu() - ref["intrinsics"][0]).abs() / ref["intrinsics"][0].abs().clamp_min(1.0)).max().item()
+        print(f"config5 image {i} {tuple(imgs[i].shape[1:])}: depth ARel {d:.2e}, K {k:.2e}")
+        assert d <= 1e-3 and k <= 2e-3, (i, d, k)
+    outs_r = infer_mixed(model, [im.cuda() for im in imgs[::-1]], keys=("depth",), inflight=2)[::-1]
+    torch.cuda.synchronize()
+    for a, b in zip(outs, outs_r):
+        assert torch.equal(a["depth"], b["depth"])
+
+
 @pytest.mark.parametrize("arch,H,W,B,seed", [("vits14", 462, 616, 1, 123), ("vitl14", 518, 518, 2, 125)])
 def test_taps_vs_oracle(engine_cls, arch, H, W, B, seed):
     """intermediate tensors of the engine against the oracle's, rel-L2 <= 3e-3 for encoder / decoder feature taps,

@@ -26,6 +26,8 @@ fc1 = dict(W=W1, bias=b1, out=hid, M=M, N=4 * D, K=D, lda=D, ldw=D, ldc=4 * D, e
 proj = dict(A=ao, W=Wp, bias=bp, out=x, M=M, N=D, K=D, lda=D, ldw=D, ldc=D, epi=ops.UD_EPI_F32, accumulate=1)
 fc2 = dict(A=hin, W=W2, bias=b2, out=x, M=M, N=D, K=4 * D, lda=4 * D, ldw=4 * D, ldc=D, epi=ops.UD_EPI_F32, accumulate=1)
 prod = dict(out2=x16, ldc2=D, row_stats_out=part)
+tk = torch.zeros(2, M // 128 + 2, dtype=torch.int32, device="cuda")
+fin = lambda k: dict(prod, row_stats_final=stats, row_stats_ticket=tk[k], ln_D=D, ln_eps=1e-6)      # + in-kernel reduction (last workgroup per row tile)
 cases = {
     "layernorm": lambda: ops.layernorm(x=x, y=xn, rows=M, D=D, ldx=D, ldy=D, eps=1e-6, rows_per_img=M, in_rows_per_img=M, out_rows_per_img=M),
     "finalize": lambda: ops.row_stats_finalize(part, stats, M, D // 64, D, 1e-6),
@@ -34,6 +36,7 @@ cases = {
     "fc1 classic list": lambda: ops.gemm(A=xn, tile_hint=2, **fc1), "fc1 folded list": lambda: ops.gemm(A=x16, wsum=ws1, tile_hint=2, **fc1, **lnc),
     "proj classic": lambda: ops.gemm(**proj), "proj producer": lambda: ops.gemm(**proj, **prod),
     "fc2 classic": lambda: ops.gemm(**fc2), "fc2 producer": lambda: ops.gemm(**fc2, **prod),
+    "proj producer+final": lambda: ops.gemm(**proj, **fin(0)), "fc2 producer+final": lambda: ops.gemm(**fc2, **fin(1)),
 }
 tot = {k: 0.0 for k in cases}
 R = 5

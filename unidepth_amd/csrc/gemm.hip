@@ -1074,6 +1074,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
     }
     const bool full = (m0 + BMC <= p.M) && (n0 + 256 <= p.N) && p.rows_in == 0 && p.add == nullptr && p.bias != nullptr;
     bool fast = false;
+    bool ticket_taken = false;                   // row_stats_final: the straight-line fp32 epilogue takes the row tile's ticket early
+    unsigned ticket_val = 0;
     int eln = lane;
     asm volatile("" : "+v"(eln));              // epilogue addresses are derived here, per tile: nothing of them lives across the K loop
     const int frow = eln & 15, fq = eln >> 4;
@@ -1183,6 +1185,25 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
         half_t* o2 = p.out2 ? (half_t*)p.out2 + (size_t)(mbase + frow) * p.ldc2 + nbase + 16 * (fq & 1) + 8 * (fq >> 1) : nullptr;
         const bool wr32 = p.accumulate != 2;   // accumulate == 2: the fp32 stream dies here, only the fp16 copy is consumed
         const bool lre = p.act2 == UD_ACT_LRELU;
+        if constexpr (!BAL) {
+          if (p.row_stats_final) {
+            // in-kernel reduction of the row statistics: the partial sums go out FIRST, then the ticket is taken, and only then the big
+            // stores of the row values are issued -- the drain before the ticket covers 16 bytes per row instead of the whole tile, and
+            // the ticket's round trip and the other column tiles' arrival hide under the stores (the finalizer below saw ~5 us per
+            // launch with the ticket after the stores).  Same values, same order as the store loop below: v = acc + bias.
+#pragma unroll
+            for (int i = 0; i < TMC; ++i) {
+              float rs1 = 0.f, rs2 = 0.f;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) ud_row_stats_acc(acc[i][j] + bv[j], rs1, rs2);
+              ud_row_stats_store(p, rs1, rs2, mbase + i * 16 + frow, nbase, eln, true);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (tid == 0) ticket_val = atomicAdd(p.row_stats_ticket + m0 / BMC, 1u);
+            ticket_taken = true;
+          }
+        }
 #pragma unroll
         for (int i = 0; i < TMC; ++i) {
           unsigned w[4][2];
@@ -1222,7 +1243,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
               *(u32x4*)(o2 + (size_t)(i * 16) * p.ldc2 + jp * 32) = s;
             }
           }
-          if (p.row_stats_out) ud_row_stats_store(p, rs1, rs2, mbase + i * 16 + frow, nbase, eln, true);
+          if (p.row_stats_out && !ticket_taken) ud_row_stats_store(p, rs1, rs2, mbase + i * 16 + frow, nbase, eln, true);
         }
       }
     }
@@ -1297,9 +1318,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
         // of all column tiles (ascending slab order: one summation order per row) -- no separate reduction launch (~7.5 us each, 47
         // per step).  Tickets count arrivals per row tile and are never reset: tiles_n arrivals per launch.
         unsigned* flag = (unsigned*)(smem + 2 * C::STAGE);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (tid == 0) *flag = atomicAdd(p.row_stats_ticket + m0 / BMC, 1u);
+        if (ticket_taken) {                       // straight-line epilogue: partial sums and ticket went out ahead of the row stores
+          if (tid == 0) *flag = ticket_val;
+        } else {                                  // edge tiles: after the stores
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          if (tid == 0) *flag = atomicAdd(p.row_stats_ticket + m0 / BMC, 1u);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const unsigned arrived = *flag;
