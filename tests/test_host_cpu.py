@@ -274,3 +274,51 @@ def test_v1_host_shape_policy_and_position_embedding_match_the_oracle():
     for (h, w, npf) in ((30, 40, 256), (29, 39, 256), (15, 20, 64)):
         a, b = v1.pos_embed_sine(h, w, npf), restate_v1.pos_embed_sine(h, w, npf)
         assert a.shape == b.shape and torch.allclose(a.reshape(-1), b.reshape(-1), atol=1e-6, rtol=0)
+
+
+def test_v1_split_weight_packing_is_exact_to_22_bits():
+    """UniDepthV1 weights as two fp16 terms (unidepthv1._padk16 / _conv3_rows / _wk / _ak): W_hi + W_lo reproduces the fp32 weight to ~2^-22,
+    the K concatenation has the layout the kernels' wrap-around loaders expect (dense: [hi(Kp) | lo(Kp)], 3x3: per tap [hi(Cin) | lo(Cin)]),
+    and the descriptor helpers derive K / a_wrap / Cin from the packed width."""
+    from unidepth_amd import unidepthv1 as U
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(96, 200, generator=g) * 200 ** -0.5
+    p = U._padk16(w, split=True)
+    assert p.shape == (96, 512) and p.dtype == torch.float16
+    hi, lo = p[:, :200].float(), p[:, 256:456].float()
+    assert (p[:, 200:256] == 0).all() and (p[:, 456:] == 0).all()
+    assert torch.equal(hi, w.half().float())
+    err = ((hi + lo) - w).abs().max() / w.abs().max()
+    assert err < 2 ** -20, float(err)
+    assert ((w.half().float() - w).abs().max() / w.abs().max()) > 100 * err          # the single term carries the 2^-11 rounding
+    assert U._wk(p, 256) == dict(K=512, ldw=512, a_wrap=256) and U._wk(U._padk16(w, split=False), 256) == dict(K=256, ldw=256)
+    assert U._ak(p, 256) == dict(K=512, lda=512, w_wrap=256)
+    wc = torch.randn(32, 64, 3, 3, generator=g) * 576 ** -0.5
+    rows = U._conv3_rows(wc, split=True)                                     # fp32 [Cout, 9 * 2 * Cin], exactly representable halves
+    assert rows.shape == (32, 9 * 128)
+    r = rows.view(32, 9, 2, 64)
+    want = wc.permute(0, 2, 3, 1).reshape(32, 9, 64)
+    assert torch.equal(r[:, :, 0], want.half().float()) and ((r[:, :, 0] + r[:, :, 1]) - want).abs().max() < 2 ** -20 * want.abs().max()
+    assert torch.equal(rows.half().float(), rows)                                # the later fp16 cast is exact
+    pk = U._padk16(rows, split=False)
+    assert U._wk(pk, 0, 64) == dict(K=pk.shape[1], ldw=pk.shape[1], Cin=128, a_wrap=64)
+    assert U._wk(U._padk16(U._conv3_rows(wc, split=False), split=False), 0, 64)["Cin"] == 64
+
+
+def test_v1_vit_position_embedding_scale_factor_form():
+    """UniDepthV1 builds its DINOv2 with interpolate_offset = 0.1: the position embedding is resampled with scale factors (h + 0.1) / 37, not
+    with an output size (backbones/dinov2.py:283-296) -- the engine's host-side resample against the pinned oracle's, and against the V2 form
+    (they must differ: a silent swap would cost ~1e-2 in the tokens)."""
+    from oracle import restate_v1, synth_v1
+    from unidepth_amd.unidepthv1 import vit_pos_embed_v1
+    cfg = synth_v1.load_config_v1("vitl14")
+    pe = torch.randn(1, 37 * 37 + 1, 64, generator=torch.Generator().manual_seed(1))
+    orc = restate_v1.OracleV1.__new__(restate_v1.OracleV1)
+    orc.w = {"pixel_encoder.pos_embed": pe}
+    want = orc._vit_pos_embed(33, 44)[0]
+    got = vit_pos_embed_v1(pe, 33, 44)
+    assert got.shape == (33 * 44 + 1, 64) and torch.allclose(got, want, atol=1e-6)
+    grid = pe[:, 1:].reshape(1, 37, 37, 64).permute(0, 3, 1, 2)
+    v2 = torch.nn.functional.interpolate(grid, size=(33, 44), mode="bicubic", antialias=False).permute(0, 2, 3, 1).reshape(33 * 44, 64)
+    assert (got[1:] - v2).abs().max() > 1e-3
+    assert torch.equal(vit_pos_embed_v1(pe, 37, 37), pe[0])
