@@ -111,7 +111,7 @@ typedef struct UdGemm {
    *   consumer (UD_EPI_F16 / UD_EPI_QKV): A = the raw fp16 copy, row_stats_in = the finalized [M][2]; the epilogue stores
    *     act(rstd * acc - mean * rstd * wsum[n] + bias[n]), wsum[n] = sum_k W[n, k] over the fp16-ROUNDED weights (the LayerNorm's affine
    *     folded into W / bias as before): rstd (x - mean) W^T = rstd (x W^T - mean 1 W^T).  fp16(x) carries the same 2^-11 relative
-   *     rounding as fp16(LN(x)) when |mean| <~ std, which holds for residual streams (tap tests).  At most 4 tiles per workgroup.
+   *     rounding as fp16(LN(x)) when |mean| <~ std, which holds for residual streams (tap tests).
    *   ln_D / ln_eps: read by the producer when row_stats_final is set; ln_slabs: unused by the kernels (kept for program recording). */
   float* max_out;              /* UD_EPI_F32, optional: fp32 [*, ldc] laid out like `out`; max_init != 0: max_out = stored value, else max_out =
                                 * max(max_out, stored value) -- the running element-wise maximum over the block outputs of a ConvNeXt stage

@@ -432,12 +432,13 @@ def _ln_fold_pair(ops, x0, A1, W1, b1, W2, b2, hint1, hint2, epi2, D, eps=1e-6, 
     return x, x16, stats, qk, vt
 
 
-@pytest.mark.parametrize("D,hint1,hint2", [(1024, 3, 8), (1024, 2, 3), (768, 3, 2), (384, 2, 3)])
-def test_gemm_layernorm_fold_fc1(ops, D, hint1, hint2):
+@pytest.mark.parametrize("D,hint1,hint2,nimg", [(1024, 3, 8, 4), (1024, 2, 3, 4), (768, 3, 2, 4), (384, 2, 3, 4), (1024, 3, 3, 16), (1024, 3, 8, 16)])
+def test_gemm_layernorm_fold_fc1(ops, D, hint1, hint2, nimg):
     """LayerNorm folded into a producer / consumer pair (UdGemm.row_stats_out / row_stats_in): proj-like accumulate writes the raw fp16
     copy and 64-column partial sums, the fc1-like consumer normalises in its epilogue.  Against fp32 torch: x, the partial sums, and
-    GELU(LN(x) W^T + b); edge tiles in M (M is not a multiple of 192 / 256), ViT-S/B/L widths (6 / 12 / 16 slabs)."""
-    M = 4 * 1376 + 32
+    GELU(LN(x) W^T + b); edge tiles in M (M is not a multiple of 192 / 256), ViT-S/B/L widths (6 / 12 / 16 slabs); nimg = 16: five to six
+    tiles per workgroup (the statistics tables alternate per tile, filled from the previous tile's last K-tile)."""
+    M = nimg * 1376 + 32
     x0 = rnd(M, D, seed=1) * (1.0 + 3.0 * (torch.arange(D, device="cuda") % 97 == 0))          # a few large channels, like a real residual stream
     x0 = x0 + 0.3                                                                                # non-zero row mean
     A1 = rnd(M, D, seed=2).half(); W1 = rnd(D, D, scale=D ** -0.5, seed=3).half(); b1 = rnd(D, seed=4)

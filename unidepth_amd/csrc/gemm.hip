@@ -29,8 +29,8 @@ __device__ unsigned long long* ud_trace_ptr = nullptr;
 
 namespace {
 
-constexpr int UD_LNC_TILES = 4;                  // tiles per workgroup the folded-LayerNorm consumer holds statistics for
-constexpr int UD_LNC_PLANE = UD_LNC_TILES * 256; // floats per plane of its LDS table: [tiles][256] rstd, then [tiles][256] -mean * rstd
+constexpr int UD_LNC_TILES = 2;                  // statistics tables of the folded-LayerNorm consumer: the current tile's and the next one's
+constexpr int UD_LNC_PLANE = UD_LNC_TILES * 256; // floats per plane of its LDS table: [2][256] rstd, then [2][256] -mean * rstd
 
 template <int BN_, int WM_, int WN_>
 struct Cfg {
@@ -740,10 +740,10 @@ __device__ __forceinline__ void ud_interleave_reads() {
 // rounds, the third one 69 % full), every column of 256 outputs gets floor(256 / tiles_n) workgroups and each of them a contiguous
 // span of ceil(M / 64) / that many 64-row units (+-1), cut into tiles of 64 * {2, 3, 4} rows of near-equal height (fc1: 704 rows =
 // 256 + 256 + 192 per CU): all CUs finish together.  A tile of 64 * MHC rows runs the MHC-instantiation of the tile body.
-// LNC (consumer of a folded LayerNorm, UdGemm.row_stats_in): A holds the RAW fp16 rows; the per-row (rstd, -mean) of ALL tiles of the
-// workgroup's list (at most LNC_TILES: the host checks) are copied to LDS tables at kernel start, before any accumulator is live; per
-// tile the accumulators start at -mean * wsum[n] and the epilogue multiplies by rstd -- no register lives across the K loop or the
-// epilogues for it.  (A first version reduced the producer's 16 partial pairs per row here, per tile: 32 live registers across the
+// LNC (consumer of a folded LayerNorm, UdGemm.row_stats_in): A holds the RAW fp16 rows; the per-row (rstd, -mean rstd) of a tile are
+// copied to a small LDS table by LDS-DMA together with the tile's first operand K-tile (at kernel start for the first tile, from the last
+// K-tile of the previous tile otherwise: the same vmcnt(0) + barrier covers both), two tables alternating per tile; the epilogue applies
+// them -- no register lives across the K loop or the epilogues for it, any number of tiles per workgroup.  (A first version reduced the producer's 16 partial pairs per row here, per tile: 32 live registers across the
 // epilogue, 55-340 spilled registers in the Q|K / V^T instantiations, +14..16 us per launch -- slower than the LayerNorm kernel it
 // replaced; the reduction is now ud_row_stats_finalize, one thread per row.)
 // GRP: a grouped problem (UdGemm.groups: G independent GEMMs of equal shape whose A rows / output rows are stacked along M and whose
@@ -922,26 +922,19 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   tile_at(t, m0, n0, mhc);
   setup(m0, n0, mhc);
   issue(0, 0, mhc);
-  if constexpr (LNC) {
-    // fill the statistics tables by LDS-DMA (4 bytes per lane, lane-linear destination = 64 consecutive rows of one plane): no VGPR holds
-    // them and nothing waits here -- they land under the first tile's K loop (its vmcnt(0) + barrier per K-tile cover them) and are
-    // first read by the first epilogue.  (Loading them through registers before the first barrier cost 10-15 us per launch.)
-    const ud_rsrc_t rS = ud_make_rsrc(p.row_stats_in, (unsigned)p.M * 8u);
-#pragma unroll
-    for (int k = 0; k < LNC_TILES; ++k) {
-      const int tt = t + k * (BAL ? 1 : (int)gridDim.x);
-      if (tt < (BAL ? bal_k : nblk) && wv < 4) {
-        int tm0, tn0, tmh;
-        tile_at(tt, tm0, tn0, tmh);
-        if (wv < tmh) {
-          int m = tm0 + wv * 64 + lane;
-          m = m < p.M ? m : p.M - 1;
-          ud_bufl4(rS, (unsigned)m * 8u, 0, lds_rstd + k * 256 + wv * 64);
-          ud_bufl4(rS, (unsigned)m * 8u + 4u, 0, lds_nm + k * 256 + wv * 64);
-        }
-      }
+  // fill a statistics table by LDS-DMA (4 bytes per lane, lane-linear destination = 64 consecutive rows of one plane): no VGPR holds the
+  // values and nothing waits here -- they land with the tile's first operand K-tile.  (Loading them through registers before the
+  // first barrier cost 10-15 us per launch.)
+  const ud_rsrc_t rS = ud_make_rsrc(LNC ? p.row_stats_in : nullptr, (unsigned)p.M * 8u);
+  auto stats_dma = [&](int tm0, int tmh, int buf) {
+    if (wv < 4 && wv < tmh) {
+      int m = tm0 + wv * 64 + lane;
+      m = m < p.M ? m : p.M - 1;
+      ud_bufl4(rS, (unsigned)m * 8u, 0, lds_rstd + buf * 256 + wv * 64);
+      ud_bufl4(rS, (unsigned)m * 8u + 4u, 0, lds_nm + buf * 256 + wv * 64);
     }
-  }
+  };
+  if constexpr (LNC) stats_dma(m0, mhc, 0);
 
   int trace_tile = 0;
   bool first = true;
@@ -1008,6 +1001,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
         if (has_next) {
           setup(m0n, n0n, mhn);
           issue(0, stg ^ 1, mhn);
+          if constexpr (LNC) stats_dma(m0n, mhn, (tl + 1) & 1);      // the table epilogue tl - 1 read: every wave is past it
         }
       } else {
         issue(kt + 1, stg ^ 1, MHC);
@@ -1060,7 +1054,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
       kloop(BoolTag<true>{});
     }
     UD_STAMP(2);
-    const float* const lnst = LNC ? lds_rstd + tl * 256 + wm * (BMC / 2) : nullptr;   // rstd of the wave's rows
+    const float* const lnst = LNC ? lds_rstd + (tl & 1) * 256 + wm * (BMC / 2) : nullptr;   // rstd of the wave's rows
 
     // =================================== epilogue ===================================
     // Accumulator layout (SWAP): lane owns row mbase + 16 i + (lane & 15), columns nbase + 16 j + 4 q .. + 3, q = lane >> 4.
@@ -1844,10 +1838,9 @@ extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
   }
   if (d.row_stats_in) {
     const int bt = d.amode == UD_A_DENSE ? pick_tiles(d) : 0;
-    if (d.amode != UD_A_DENSE || (d.epi != UD_EPI_F16 && d.epi != UD_EPI_QKV) || !d.wsum || d.add || d.rows_in || (d.N & 15) || bt == 0 ||
-        big_tiles_per_wg(d, bt) > LNC_TILES) {
+    if (d.amode != UD_A_DENSE || (d.epi != UD_EPI_F16 && d.epi != UD_EPI_QKV) || !d.wsum || d.add || d.rows_in || (d.N & 15) || bt == 0) {
       ud_set_error("ud_gemm_f16: LayerNorm-folded consumer (row_stats_in) needs dense A, an fp16 epilogue without add / row remap, wsum, N % 16 == 0 "
-                   "and a problem the large-tile kernel takes with at most 4 tiles per workgroup (ud_gemm_pick >= 3)");
+                   "and a problem the large-tile kernel takes (ud_gemm_pick >= 3)");
       return UD_ERR_UNSUPPORTED;
     }
   }
@@ -1961,7 +1954,6 @@ extern "C" int ud_gemm_pick(const UdGemm* desc) {
   if (conv_tile_ok(d) && (d.epi == UD_EPI_HEAD || d.epi == UD_EPI_F16)) return 5;
   if (d.epi != UD_EPI_HEAD) {
     const int bt = pick_tiles(d);
-    if (bt && d.row_stats_in && big_tiles_per_wg(d, bt) > LNC_TILES) return 0;      // the folded-LayerNorm consumer cannot take it
     if (bt) return bt + (d.row_stats_in ? 16 : 0);
   }
   if (d.N > 64 && d.epi != UD_EPI_D2S) {

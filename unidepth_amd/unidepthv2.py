@@ -140,7 +140,7 @@ class _Plan:
         # LayerNorm folded into the neighbouring GEMMs (UdGemm.row_stats_out / row_stats_in): proj / fc2 write the raw fp16 copy of the
         # residual stream and per-row partial sums with their fp32 accumulate, qkv / fc1 normalise in their epilogues -- no LayerNorm
         # launch, no second pass over x.  Only where all four GEMMs run on the large-tile kernel (its epilogues hold the statistics
-        # code): bs >= 4 or so for ViT-L; smaller problems keep the LayerNorm kernel.  UNIDEPTH_LN_FOLD=0 turns it off (A/B).
+        # code): bs >= 4 or so for ViT-L; smaller problems keep the LayerNorm kernel ...
         slabs = D // 64
         x16 = z(M, D)
         rpart = z(M, slabs, 2, dtype=f32)                           # per 64-column slab (sum, sum of squares) written by proj / fc2
@@ -154,7 +154,13 @@ class _Plan:
                         kv_ld=Nkp, heads_v=heads, out2=vt, accumulate=int(e_ == UD_EPI_F32),
                         **(dict(row_stats_in=rstats, wsum=w[f"enc.0.{nm}.wsum"]) if nm in ("qkv", "fc1") else {})) & 15 in (3, 4, 8)
                   for nm, n_, k_, e_ in (("qkv", 3 * D, D, UD_EPI_QKV), ("proj", D, D, UD_EPI_F32), ("fc1", 4 * D, D, UD_EPI_F16), ("fc2", D, 4 * D, UD_EPI_F32)))
-        fold = big and os.environ.get("UNIDEPTH_LN_FOLD", "1") != "0"
+        # ... and where the producers (proj / fc2, N = D) run about one tile per workgroup: measured on one box (gpurun_out r3c12), bs = 8:
+        # +2.5 %, 644x966 bs = 4 (264 tiles): +0.3 %, bs = 16 (460 tiles): +-0, bs = 32 (916 tiles): -1.2 % -- with several tiles per
+        # workgroup the per-tile drain + ticket of the in-kernel reduction sits inside the tile stream, and the LayerNorm kernels it
+        # replaces are efficient HBM streams at that size.  UNIDEPTH_LN_FOLD=1 forces it on, =0 off.
+        prod_tiles = -(-M // 192) * -(-D // 256)
+        env = os.environ.get("UNIDEPTH_LN_FOLD", "")
+        fold = big and env != "0" and (prod_tiles <= 320 or env == "1")
         self.ln_fold = fold
         lnc = dict(row_stats_in=rstats, ln_slabs=slabs, ln_D=D, ln_eps=1e-6)
         for i in range(a["depth"]):
