@@ -452,7 +452,7 @@ def extra_configs(torch, model_v2, dev, cpu=True):
         fl_total = sum(v[1] for v in tot.values())
         rec = {"metric": "images/sec, UniDepthV1 ConvNeXt-L 640x480 bs=16 (BASELINE configs[3])", "value": round(B1 / dt, 2), "unit": "images/s",
                "ms_per_step": round(dt * 1e3, 3), "steps": 10, "launches": len(plan.prog),
-               "dtype": "f16 MFMA operands, fp32 accumulate" + ("; every weight as TWO fp16 terms (W_hi + W_lo, ~22-bit weights: UdGemm.a_wrap)" if v1mod.WSPLIT else "")
+               "dtype": "f16 MFMA operands, fp32 accumulate" + ("; weights as TWO fp16 terms (W_hi + W_lo, ~22-bit weights: UdGemm.a_wrap)" + ("" if v1mod.WSPLIT_CONVNEXT_FC1 else " except the ConvNeXt blocks' fc1") if v1mod.WSPLIT else "")
                         + "; depth-wise convolutions, LayerNorm / softmax statistics, the camera transformer, the Nystrom pseudo-inverse and all residual streams in fp32",
                "parity": "depth ARel <= 1e-3 per image vs the fp32 oracle at this batch (tests/test_v1_gpu.py::test_v1_infer_config4_bs16_vs_oracle); "
                          "Nystrom stages: parity unpinned (oracle header)",

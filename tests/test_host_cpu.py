@@ -305,6 +305,21 @@ def test_v1_split_weight_packing_is_exact_to_22_bits():
     assert U._wk(U._padk16(U._conv3_rows(wc, split=False), split=False), 0, 64)["Cin"] == 64
 
 
+def test_v1_convnext_fc1_is_the_one_unsplit_weight():
+    """Default placement of the two-term weights (tools/v1_precision_study.py placement): every GEMM weight of the ConvNeXt encoder is
+    [W_hi | W_lo] except the blocks' fc1 (A = LayerNorm output), whose fp16 rounding the depth error does not see."""
+    from unidepth_amd import unidepthv1 as U
+    from oracle import synth_v1
+    cfg = synth_v1.load_config_v1()
+    assert U.WSPLIT and not U.WSPLIT_CONVNEXT_FC1                                 # the environment of the test run: defaults
+    w = U.pack_convnext(cfg, synth_v1.make_synthetic_checkpoint_v1(cfg, 211), torch.device("cpu"))
+    dims = U.CONVNEXT[cfg["model"]["pixel_encoder"]["name"]]["dims"]
+    for s, C in enumerate(dims):
+        assert w[f"blk.{s}.0.fc1.w"].shape == (4 * C, C) and U._wk(w[f"blk.{s}.0.fc1.w"], C) == dict(K=C, ldw=C)
+        assert w[f"blk.{s}.0.fc2.w"].shape == (C, 8 * C) and U._wk(w[f"blk.{s}.0.fc2.w"], 4 * C)["a_wrap"] == 4 * C
+    assert w["ds.1.w"].shape[1] == 2 * 4 * dims[0] and w["stem.w"].shape[1] == 128
+
+
 def test_v1_vit_position_embedding_scale_factor_form():
     """UniDepthV1 builds its DINOv2 with interpolate_offset = 0.1: the position embedding is resampled with scale factors (h + 0.1) / 37, not
     with an output size (backbones/dinov2.py:283-296) -- the engine's host-side resample against the pinned oracle's, and against the V2 form

@@ -121,7 +121,11 @@ def main():
         ins[c] = torch.randint(0, 256, (c[0], 3, c[1], c[2]), dtype=torch.uint8, generator=torch.Generator().manual_seed(5))
         refs[c] = restate_v1.OracleV1(cfg, sd).infer(ins[c])
 
+    STATE_NAMES = list(sd.keys())
+
     def run(tag, rules):
+        if os.environ.get("ONLY") and os.environ["ONLY"] not in tag:          # ONLY=substring: run the matching rule sets only
+            return
         STATE["rules"] = rules
         res = []
         for c in cases:
@@ -137,6 +141,24 @@ def main():
         r.update({k.replace("__", "."): v for k, v in kw.items()})
         return r
 
+    if len(sys.argv) > 1 and sys.argv[1] == "placement":
+        # round 3: WHERE the weights have to be exact.  'w' = split-fp16 weights (A fp16, W ~fp32), 'h' = single fp16 weights.
+        W_ALL = {**ENGINE_R2, "": "w", "camera_layer.in_features": "w", "camera_layer.aggregate.kv": "w"}
+        run("split weights everywhere (the engine since 9.1)", W_ALL)
+        run("encoder single fp16, decoder split", {**W_ALL, "pixel_encoder": "h"})
+        run("encoder stage 2 single fp16, rest split", {**W_ALL, "pixel_encoder.stages.2": "h"})
+        run("encoder stage 2 fc1 single fp16, rest split", {**W_ALL, **{f"pixel_encoder.stages.2.blocks.{i}.mlp.fc1": "h" for i in range(27)}})
+        run("encoder stage 2 fc2 single fp16, rest split", {**W_ALL, **{f"pixel_encoder.stages.2.blocks.{i}.mlp.fc2": "h" for i in range(27)}})
+        run("encoder stage 2 blocks 0-13 single fp16, rest split", {**W_ALL, **{f"pixel_encoder.stages.2.blocks.{i}.": "h" for i in range(14)}})
+        run("encoder stages 2+3 single fp16, rest split", {**W_ALL, "pixel_encoder.stages.2": "h", "pixel_encoder.stages.3": "h"})
+        run("encoder split, decoder single fp16", {**ENGINE_R2, "pixel_encoder": "w"})
+        # GEMMs whose A operand is a LayerNorm output (zero-mean rows): ConvNeXt fc1 / pwconv1, the transformer blocks' q / kv / mlp.proj1
+        FC1 = {f"pixel_encoder.stages.{s}.blocks.{i}.mlp.fc1": "h" for s, d in enumerate((3, 3, 27, 3)) for i in range(d)}
+        run("every encoder fc1 single fp16, rest split", {**W_ALL, **FC1})
+        LNFED = {k: "h" for k in STATE_NAMES if k.startswith("pixel_decoder.depth_layer") and
+                 (k.endswith(".mlp.proj1.weight") or k.endswith(".q.weight") or k.endswith(".kv.weight") or k.endswith(".pwconv1.weight"))}
+        run("encoder fc1 + the depth decoder's LayerNorm-fed GEMMs single fp16", {**W_ALL, **FC1, **LNFED})
+        return
     E = ENGINE_R2
     run("engine r2 (all MFMA GEMMs fp16 x fp16)", E)
     run("encoder exact", with_(E, pixel_encoder="x"))

@@ -35,7 +35,14 @@ def _rup(x, m):
 # UniDepthV1 in fp32 (no autocast, unidepthv1.py:287-373), so every weight goes to the matrix pipes as TWO fp16 terms,
 # W = W_hi + W_lo, concatenated along K: [W_hi | W_lo] against A read twice (UdGemm.a_wrap) -- A W_hi^T + A W_lo^T in one fp32
 # accumulator, the weights exact to ~22 bits.  UNIDEPTH_V1_WSPLIT=0 keeps single fp16 weights (A/B of the cost).
-WSPLIT = os.environ.get("UNIDEPTH_V1_WSPLIT", "1") != "0"
+# Not every GEMM needs it (`tools/v1_precision_study.py placement`, depth ARel on three inputs): all weights split 7.1 / 7.7 / 7.4e-4;
+# the ConvNeXt blocks' fc1 (A = the block's LayerNorm output) single fp16, everything else split 7.4 / 8.0 / 7.5e-4 -- within the study's
+# noise, a quarter of the encoder's MFMA work saved; the same blocks' fc2 (A = GELU output, every channel's mean positive: a rounding
+# error of W shifts an output channel by the same amount at every pixel) 7.8 / 8.5 / 8.1e-4; the depth decoder's LayerNorm-fed GEMMs
+# 1.1-1.2e-3: not those.  Default: split everything except the ConvNeXt fc1; UNIDEPTH_V1_WSPLIT=all splits those too.
+_WSPLIT_ENV = os.environ.get("UNIDEPTH_V1_WSPLIT", "1")
+WSPLIT = _WSPLIT_ENV != "0"
+WSPLIT_CONVNEXT_FC1 = _WSPLIT_ENV == "all"
 
 
 def _padk16(w: torch.Tensor, split: Optional[bool] = None) -> torch.Tensor:
@@ -72,8 +79,8 @@ def pack_convnext(config: dict, sd: dict, device) -> dict:
     pe = "pixel_encoder."
     w = {}
 
-    def p16(name, t):
-        w[name] = _padk16(t).to(device)
+    def p16(name, t, split=None):
+        w[name] = _padk16(t, split).to(device)
 
     def p32(name, t):
         w[name] = t.to(torch.float32).contiguous().to(device)
@@ -91,7 +98,7 @@ def pack_convnext(config: dict, sd: dict, device) -> dict:
             p32(f"blk.{s}.{i}.dw.w", f[r + "conv_dw.weight"].reshape(d, 49).t()); p32(f"blk.{s}.{i}.dw.b", f[r + "conv_dw.bias"])
             g, b = f[r + "norm.weight"], f[r + "norm.bias"]
             w1, b1 = f[r + "mlp.fc1.weight"], f[r + "mlp.fc1.bias"]
-            p16(f"blk.{s}.{i}.fc1.w", w1 * g[None, :]); p32(f"blk.{s}.{i}.fc1.b", b1 + w1 @ b)
+            p16(f"blk.{s}.{i}.fc1.w", w1 * g[None, :], split=WSPLIT_CONVNEXT_FC1); p32(f"blk.{s}.{i}.fc1.b", b1 + w1 @ b)
             ls = f[r + "gamma"]
             p16(f"blk.{s}.{i}.fc2.w", f[r + "mlp.fc2.weight"] * ls[:, None]); p32(f"blk.{s}.{i}.fc2.b", f[r + "mlp.fc2.bias"] * ls)
     return w
