@@ -385,7 +385,12 @@ def kernel_timing(torch, model, fl, B, dump=""):
                      "attainable_source": "profiles/r02_mfma_attainable.txt (MFMA-only stream, random fp16 operands, power-limited clocks)",
                      "flop_per_launch": round(d["flops"] / d["launches"], 1),
                      "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 3),
-                     "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"], 1)},
+                     "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"], 1),
+                     "note": ("a kernel CLASS (template instantiation), not one shape: in the ViT-L step this one holds the encoder's proj (K = 1024, 23 GFLOP) "
+                              "and fc2 (K = 4096, 92 GFLOP) launches with the fp32 residual accumulate epilogue; where the LayerNorm fold is on "
+                              "(DESIGN 9.2) the same launches also write the fp16 copy of their rows and the rows' LayerNorm statistics, i.e. "
+                              "they carry the work of the 47 LayerNorm launches that are gone from the step -- the block-scope fraction below "
+                              "is the one to compare across rounds") if dom.startswith("gemm256_kernel<3, 1, 0") else None},
         "roofline_enc_attention_mlp": {"achieved": round(enc_fl / (enc_ms * 1e-3) / 1e12, 2), "peak": MFMA_PEAK_TFLOPS,
                                        "unit": "TFLOP/s", "frac": round(enc_fl / (enc_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
                                        "frac_of_attainable": round(enc_fl / (enc_ms * 1e-3) / 1e12 / MFMA_ATTAINABLE_TFLOPS, 4),

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """UniDepthV1 (ConvNeXt-L) on one MI355X at BASELINE.json configs[3]: 640x480 inputs, batch 16.  Prints ONE JSON line in the layout of
 bench.py (metric / value / roofline of the dominant kernel class / cpu_baseline = the fp32 oracle on the host cores, bounded sample) and
-the per-kernel-class breakdown (HIP events around every launch of the program).  GPU box only.   python tools/bench_v1.py [batch] [--no-cpu]"""
+the per-kernel-class breakdown (HIP events around every launch of the program).  GPU box only.   python tools/bench_v1.py [batch] [--no-cpu] [--by-tag]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,6 +19,7 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
 plan = next(reversed(m._plans.values())); P = plan.prog; n = len(P)
 tot = {}
+bytag = {}
 for rep in range(2):
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
     evs[0].record()
@@ -30,6 +31,7 @@ for rep in range(2):
             cls, tag, fl, nb = P.meta[i]
             key = cls if cls.startswith("gemm") or cls.startswith("conv") else tag if cls.startswith("v1.") else cls
             d = tot.setdefault(key, [0.0, 0.0, 0]); d[0] += evs[i].elapsed_time(evs[i + 1]); d[1] += fl; d[2] += 1
+            d = bytag.setdefault(("enc " if i < plan.dec_first else "dec ") + tag, [0.0, 0.0, 0]); d[0] += evs[i].elapsed_time(evs[i + 1]); d[1] += fl; d[2] += 1
 enc_ms = sum(evs[i].elapsed_time(evs[i + 1]) for i in range(plan.dec_first))
 dom, dv = max(((k, v) for k, v in tot.items() if v[1] > 0), key=lambda kv: kv[1][0])
 line = {"metric": "images/sec, UniDepthV1 ConvNeXt-L 640x480 (BASELINE configs[3])", "value": round(B / dt, 2), "unit": "images/s", "n_gpus": 1,
@@ -53,3 +55,6 @@ if "--no-cpu" not in sys.argv:
 print(json.dumps(line))
 for k, v in sorted(tot.items(), key=lambda kv: -kv[1][0])[:24]:
     print(f"  {k:58s} {v[0]:8.3f} ms  x{v[2]:4d}  {v[1] / (v[0] * 1e-3) / 1e12 if v[1] else 0:7.1f} TF")
+if "--by-tag" in sys.argv:                      # the same launches by program tag (which layer), largest first
+    for k, v in sorted(bytag.items(), key=lambda kv: -kv[1][0])[:70]:
+        print(f"  {k:58s} {v[0]:8.3f} ms  x{v[2]:4d}  {v[1] / (v[0] * 1e-3) / 1e12 if v[1] else 0:7.1f} TF")

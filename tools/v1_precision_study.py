@@ -44,15 +44,29 @@ def _rounders(mode):
     return ra, rw
 
 
+def _pixel_mean(x, chan_dim):
+    """mean over everything but the batch (dim 0) and the channel dim, kept for broadcasting"""
+    dims = [d for d in range(x.dim()) if d not in (0, chan_dim % x.dim())]
+    return x.mean(dim=dims, keepdim=True) if dims and x.dim() > 2 else x.mean(dim=0, keepdim=True)
+
+
 def linear(x, w, b=None):
-    ra, rw = _rounders(mode_of(STATE["names"].get(id(w), "?")))
+    m = mode_of(STATE["names"].get(id(w), "?"))
+    if m == "m":        # single fp16 weights + MEAN-FIELD correction: the per-image mean activation against the weights' rounding error
+        y = _orig["linear"](r16(x), r16(w), b)
+        return y + _orig["linear"](_pixel_mean(x, -1), w - r16(w))
+    ra, rw = _rounders(m)
     return _orig["linear"](ra(x), rw(w), b)
 
 
 def conv2d(x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
     if groups != 1:                                   # depth-wise 7x7: fp32 VALU in the engine
         return _orig["conv2d"](x, w, b, stride, padding, dilation, groups)
-    ra, rw = _rounders(mode_of(STATE["names"].get(id(w), "?")))
+    m = mode_of(STATE["names"].get(id(w), "?"))
+    if m == "m":
+        y = _orig["conv2d"](r16(x), r16(w), b, stride, padding, dilation, groups)
+        return y + _orig["conv2d"](_pixel_mean(x, 1).expand_as(x), w - r16(w), None, stride, padding, dilation, groups)
+    ra, rw = _rounders(m)
     return _orig["conv2d"](ra(x), rw(w), b, stride, padding, dilation, groups)
 
 
@@ -152,6 +166,12 @@ def main():
         run("encoder stage 2 blocks 0-13 single fp16, rest split", {**W_ALL, **{f"pixel_encoder.stages.2.blocks.{i}.": "h" for i in range(14)}})
         run("encoder stages 2+3 single fp16, rest split", {**W_ALL, "pixel_encoder.stages.2": "h", "pixel_encoder.stages.3": "h"})
         run("encoder split, decoder single fp16", {**ENGINE_R2, "pixel_encoder": "w"})
+        # mean-field correction instead of the second term: y = A fp16(W)^T + mean_pixels(A) (W - fp16(W))^T  (a GEMV per image)
+        M_ALL = {k: ("m" if v == "w" else v) for k, v in W_ALL.items()}
+        run("mean-field correction everywhere instead of the split", M_ALL)
+        run("mean-field: ConvNeXt fc2 only, fc1 single, rest split", {**W_ALL, **{f"pixel_encoder.stages.{s}.blocks.{i}.mlp.fc1": "h" for s, d in enumerate((3, 3, 27, 3)) for i in range(d)},
+                                                                       **{f"pixel_encoder.stages.{s}.blocks.{i}.mlp.fc2": "m" for s, d in enumerate((3, 3, 27, 3)) for i in range(d)}})
+        run("mean-field: encoder (fc1 single), decoder split", {**W_ALL, "pixel_encoder": "m", **{f"pixel_encoder.stages.{s}.blocks.{i}.mlp.fc1": "h" for s, d in enumerate((3, 3, 27, 3)) for i in range(d)}})
         # GEMMs whose A operand is a LayerNorm output (zero-mean rows): ConvNeXt fc1 / pwconv1, the transformer blocks' q / kv / mlp.proj1
         FC1 = {f"pixel_encoder.stages.{s}.blocks.{i}.mlp.fc1": "h" for s, d in enumerate((3, 3, 27, 3)) for i in range(d)}
         run("every encoder fc1 single fp16, rest split", {**W_ALL, **FC1})
