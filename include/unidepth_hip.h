@@ -194,8 +194,18 @@ typedef struct UdAttention {
   int kv_group;           /* with kv_broadcast: image i uses the K/V of image i / kv_group (0 -> all share image 0) */
   int q_prescaled;        /* != 0: Q already holds q * scale * log2(e) (folded into the q projection by the caller): `scale` is ignored and the
                            * kernel skips the per-score multiply (softmax(q k^T scale) is unchanged) */
+  int k_chunk;            /* > 0 (multiple of 64, with `part`, q_prescaled == 0): SPLIT-KEY mode for few queries against many keys (the Nystrom
+                           * kernel_3 product softmax(q_landmarks K^T) V, layers/nystrom_attention.py:59-62 -> xformers NystromAttention): the
+                           * keys are cut into NC = ceil(ceil(Nk / 64) * 64 / k_chunk) chunks, one workgroup per (image, head, 128 queries, chunk);
+                           * O is not written (may be NULL); ud_attention_merge_f32 combines the chunks */
+  float* part;            /* split-key mode: fp32 [B][NC][H * Nq][UD_ATTN_PART_LD]: 64 un-normalised outputs sum_k exp(s_k - m) v_k, then
+                           * m (running maximum of scale * q.k, natural-log units) and sum_k exp(s_k - m); written completely */
 } UdAttention;
+#define UD_ATTN_PART_LD 68
 int ud_attention_f16(const UdAttention* desc, void* stream);
+/* split-key mode, second step: out fp32 [H][B][Nq][64] (head-major: the (head, image) order of the Nystrom pseudo-inverse batch) =
+ * sum_c part_c exp(m_c - M) / sum_c l_c exp(m_c - M) (+ bias[h * 64 + d] if bias != NULL), M = max_c m_c. */
+int ud_attention_merge_f32(const float* part, const float* bias, float* out, int B, int NC, int H, int Nq, void* stream);
 
 /* ---- pre-processing + im2col for the 14x14 patch embedding ---------------------------------------------
  * Replaces unidepthv2.py:288-297 (/255, ImageNet mean/std, zero pad, bilinear align_corners=False resize) and
@@ -324,7 +334,10 @@ int ud_spatial_mean_f32(const float* x, float* out, int B, int HW, int C, int ld
  *  PINV_INIT     Z0 = K^T / max column sum (iterative_pinv initialisation).  i = G, n
  *  ADD           out = a + b (fp32; latents + ray embedding, decoder.py:263,283,303).  i = n & 0x7fffffff, n >> 31
  *  COPY_ROWS     out[(img*rows_per_img + row_off + t)*ld + d] = a[(img*T + t)*D + d] (torch.cat of token groups).  i = n_img, T, rows_per_img, row_off, D, ld, to_f16
- *  TRANSPOSE16   fp32 [G, M, N] -> fp16 [G, N, ldo] transposed, zero padded.  i = G, M, N, ldo
+ *  TRANSPOSE16   fp32 [G, M, N] -> fp16 [G, N, ldo] transposed, zero padded.  i = G, M, N, ldo, nh, vt.  nh > 0: input groups (head, image)-major
+ *                (g = head * G / nh + image), output groups (image, head)-major; vt != 0 (ldo % 16 == 0): output columns in the V^T block
+ *                order of ud_attention_f16 -- together: T = pinv(kernel_2) kernel_3 v as the V^T operand of the Nystrom output attention
+ *  ATTN_MERGE    ud_attention_merge_f32 as a program op: a = part, b = bias or NULL, out; i = B, NC, H, Nq
  *  CAMERA        raw [B*4] -> K33 (out), its inverse (out2), post-processed K (c) (decoder.py:85-99,347-353; unidepthv1.py:88-92).
  *                i = B, Hn, Wn, pad_l, pad_t; f[0] = ratio
  *  POINTS        z map + K33 -> points [B,3,H,W] (out), depth [B,1,H,W] (out2) (unidepthv1.py:353-371; utils/geometric.py:45-73).  i = B, H, W, ldz, nK
@@ -335,7 +348,7 @@ int ud_spatial_mean_f32(const float* x, float* out, int B, int HW, int C, int ld
  *  PREPROCESS    V1 network image (unidepthv1.py:305-321,50-56): [/255], ImageNet normalise, antialiased resize to (h, w), zero pad to (Hn, Wn).
  *                i = B, H, W, h, w, Hn, Wn, pad_l, pad_t, is_u8, div255, normalize */
 enum { UD_V1_RESIZE_AA = 1, UD_V1_SH_EMBED, UD_V1_SOFTMAX, UD_V1_ATTN_FEWQ, UD_V1_SEGMENT_MEAN, UD_V1_BMM, UD_V1_PINV_INIT, UD_V1_ADD,
-       UD_V1_COPY_ROWS, UD_V1_TRANSPOSE16, UD_V1_CAMERA, UD_V1_POINTS, UD_V1_MEAN3, UD_V1_PREPROCESS, UD_V1_VIT_TAP };
+       UD_V1_COPY_ROWS, UD_V1_TRANSPOSE16, UD_V1_CAMERA, UD_V1_POINTS, UD_V1_MEAN3, UD_V1_PREPROCESS, UD_V1_VIT_TAP, UD_V1_ATTN_MERGE };
 typedef struct UdV1Op {
   int kind;
   const void* a; const void* b; void* c; void* out; void* out2;

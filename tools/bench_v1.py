@@ -55,6 +55,10 @@ if "--no-cpu" not in sys.argv:
 print(json.dumps(line))
 for k, v in sorted(tot.items(), key=lambda kv: -kv[1][0])[:24]:
     print(f"  {k:58s} {v[0]:8.3f} ms  x{v[2]:4d}  {v[1] / (v[0] * 1e-3) / 1e12 if v[1] else 0:7.1f} TF")
+if "--dump" in sys.argv:                        # every launch of the decoder in program order: index, class, tag, us
+    for i in range(plan.dec_first, n):
+        cls, tag, fl, nb = P.meta[i]
+        print(f"  #{i:4d} {cls[:44]:44s} {tag:28s} {evs[i].elapsed_time(evs[i + 1]) * 1e3:8.1f} us")
 if "--by-tag" in sys.argv:                      # the same launches by program tag (which layer), largest first
     for k, v in sorted(bytag.items(), key=lambda kv: -kv[1][0])[:70]:
         print(f"  {k:58s} {v[0]:8.3f} ms  x{v[2]:4d}  {v[1] / (v[0] * 1e-3) / 1e12 if v[1] else 0:7.1f} TF")

@@ -10,7 +10,7 @@ void ud_set_error(const char* msg) {
 }
 
 extern "C" const char* ud_last_error(void) { return g_err; }
-extern "C" int ud_version(void) { return 110; }
+extern "C" int ud_version(void) { return 111; }
 
 // struct sizes, so the Python binding can verify its ctypes mirror of include/unidepth_hip.h
 extern "C" int ud_struct_size(int which) {

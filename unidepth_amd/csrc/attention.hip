@@ -37,7 +37,10 @@ constexpr int STAGE = KS_BYTES + VS_BYTES;
 // NW = waves per workgroup (4 or 8), 32 query rows each: the NW * 32 rows of a workgroup share every K / V^T tile it stages, so 8 waves
 // halve the L2 -> LDS traffic and the DMA issue + barrier work per query row (the ablation of the 4-wave kernel put the K / V traffic at
 // ~20 % of its time); the register budget (<= 128 VGPRs at 512 threads) is the 4-wave kernel's own 124.
-template <int ABL, int MODE, int NW = 4>
+// SPLIT: split-key mode (UdAttention.k_chunk / part): the workgroup covers ONE chunk of the keys and leaves its un-normalised accumulators,
+// running maximum and row sum in `part`; attention_merge_kernel combines the chunks.  For few queries against many keys (the Nystrom
+// kernel_3 product: 128 landmark queries x up to 19200 keys per (image, head) -- one workgroup per pair would walk 300 key tiles alone).
+template <int ABL, int MODE, int NW = 4, bool SPLIT = false>
 __global__ __launch_bounds__(NW * 64) void attention_kernel(const UdAttention p, const float defer_thr) {
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   const int tid = threadIdx.x;
@@ -51,13 +54,20 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const UdAttention p,
   // 403 MB per launch against 67 MB of unique Q/K/V: the kernel ran at the fabric read rate, 4.1 TB/s, not at MFMA rate).
   const int qt = (p.Nq + NW * 32 - 1) / (NW * 32);
   const int pairs = p.B * p.H;
+  const int nt = (p.Nk + KT - 1) / KT;
+  const int tpc = SPLIT ? p.k_chunk / KT : nt;            // key tiles per chunk
+  const int nc = SPLIT ? (nt + tpc - 1) / tpc : 1;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int pr = xcd + 8 * (slot / qt);
+  const int pr = xcd + 8 * (slot / (qt * nc));            // all q-tiles and chunks of a pair on one XCD, consecutive slots
   if (pr >= pairs) return;
   const int head = pr % p.H;
   const int img = pr / p.H;
   const int kimg = p.kv_broadcast ? (p.kv_group > 0 ? img / p.kv_group : 0) : img;
-  const int q0 = (slot % qt) * (NW * 32) + wv * 32;
+  const int rem = slot % (qt * nc);
+  const int chunk = rem / qt;
+  const int q0 = (rem % qt) * (NW * 32) + wv * 32;
+  const int kt0 = chunk * tpc;
+  const int kt1 = SPLIT ? (kt0 + tpc < nt ? kt0 + tpc : nt) : nt;
 
   const half_t* Q = (const half_t*)p.Q;
   const half_t* K = (const half_t*)p.K;
@@ -76,7 +86,6 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const UdAttention p,
   // ---- tile loader: 512 16-byte chunks per operand tile = 8 wave-instructions of 8 rows x 128 B; wave w issues pieces 2w, 2w+1.
   // Buffer-descriptor DMA: V^T advances by an SGPR offset (no VALU); K by one v_add per piece, and its descriptor ends after
   // key Nk-1, so the rows of the last tile beyond the sequence read as zeros instead of the next image's keys.
-  const int nt = (p.Nk + KT - 1) / KT;
   const int lrow = lane >> 3, lch = lane & 7;
   const ud_rsrc_t rK = ud_make_rsrc(K + (size_t)kimg * p.k_rows_per_img * p.ldk + head * 64, (unsigned)((p.Nk - 1) * p.ldk + 64) * 2u);
   const ud_rsrc_t rV = ud_make_rsrc(Vt, 64u * (unsigned)p.kv_ld * 2u);
@@ -109,16 +118,16 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const UdAttention p,
   float l_i = 0.0f;
   const float c = p.scale * 1.4426950408889634f;
 
-  issue(0, 0);
+  issue(kt0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const int kswz = (ql >> 1) & 7;   // (key >> 1) & 7 for key = kb*32 + ql
-  for (int kt = 0; kt < nt; ++kt) {
+  for (int kt = kt0; kt < kt1; ++kt) {
     if constexpr (!(ABL & 8)) {
-      if (kt + 1 < nt) issue(kt + 1, (kt + 1) & 1);       // every wave passed the barrier that ended tile kt-1: that stage is free
+      if (kt + 1 < kt1) issue(kt + 1, (kt + 1 - kt0) & 1);   // every wave passed the barrier that ended tile kt-1: that stage is free
     }
-    const char* sb = smem + ((ABL & 8) ? 0 : (kt & 1)) * STAGE;
+    const char* sb = smem + ((ABL & 8) ? 0 : ((kt - kt0) & 1)) * STAGE;
 
     // ---- S^T = K Q^T  (two 32-key blocks)
     f32x16 s[2];
@@ -192,10 +201,10 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const UdAttention p,
           }
     } else {
       // scores are already S - m (in log2 units); mt = how far this tile's row maximum exceeds the running one
-      if (kt == 0 || __any(mt > defer_thr)) {
-        const float d = kt == 0 ? mt : fmaxf(mt, 0.0f);
+      if (kt == kt0 || __any(mt > defer_thr)) {
+        const float d = kt == kt0 ? mt : fmaxf(mt, 0.0f);
         m_i += d;
-        if (kt != 0) {                                   // first tile: O and l are still zero (and exp2(-d) may overflow)
+        if (kt != kt0) {                                   // first tile: O and l are still zero (and exp2(-d) may overflow)
           const float alpha = __builtin_amdgcn_exp2f(-d);
           l_i *= alpha;
 #pragma unroll
@@ -252,10 +261,31 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const UdAttention p,
     if constexpr (!(ABL & 16)) __syncthreads();
   }
 
-  // ---- normalise and store O[q][head*64 + d]
   const float l_tot = l_i + __shfl_xor(l_i, 32, 64);
-  const float inv = 1.0f / l_tot;
   const int qr = q0 + ql;
+  if constexpr (SPLIT) {
+    // ---- split-key mode: un-normalised O^T, the running maximum in natural-log units (MODE 0: m_i is a raw score, P = exp(scale (s - m)))
+    //      and the row sum go to part[img][chunk][head * Nq + q][0..65]
+    if (qr < p.Nq) {
+      float* pp = p.part + ((((size_t)img * nc + chunk) * p.H + head) * p.Nq + qr) * UD_ATTN_PART_LD;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = o[db][g * 4 + e];
+          *(f32x4*)(pp + db * 32 + g * 8 + 4 * hh) = v;
+        }
+      if (hh == 0) {
+        pp[64] = MODE ? m_i * 0.6931471805599453f : m_i * p.scale;
+        pp[65] = l_tot;
+      }
+    }
+    return;
+  }
+  // ---- normalise and store O[q][head*64 + d]
+  const float inv = 1.0f / l_tot;
   if (qr < p.Nq) {
     half_t* op = (half_t*)p.O + ((size_t)img * p.q_rows_per_img + qr) * p.ldo + head * 64 + 4 * hh;
 #pragma unroll
@@ -270,11 +300,45 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const UdAttention p,
   }
 }
 
+// split-key mode, second step: one 64-lane block per (image, head, query) row
+__global__ __launch_bounds__(64) void attention_merge_kernel(const float* part, const float* bias, float* out, int B, int NC, int H, int Nq) {
+  const int row = blockIdx.x;                       // (img * H + head) * Nq + q
+  const int q = row % Nq, ih = row / Nq;
+  const int head = ih % H, img = ih / H;
+  const int d = threadIdx.x;
+  const size_t cs = (size_t)H * Nq * UD_ATTN_PART_LD;
+  const float* pb = part + (size_t)img * NC * cs + ((size_t)head * Nq + q) * UD_ATTN_PART_LD;
+  float M = -__builtin_inff();
+  for (int c = 0; c < NC; ++c) M = fmaxf(M, pb[c * cs + 64]);
+  float L = 0.f, acc = 0.f;
+  for (int c = 0; c < NC; ++c) {
+    const float e = __expf(pb[c * cs + 64] - M);
+    L = fmaf(pb[c * cs + 65], e, L);
+    acc = fmaf(pb[c * cs + d], e, acc);
+  }
+  out[(((size_t)head * B + img) * Nq + q) * 64 + d] = acc / L + (bias ? bias[head * 64 + d] : 0.f);
+}
+
 }  // namespace
+
+extern "C" int ud_attention_merge_f32(const float* part, const float* bias, float* out, int B, int NC, int H, int Nq, void* stream) {
+  if (!part || !out || B <= 0 || NC <= 0 || H <= 0 || Nq <= 0) {
+    ud_set_error("ud_attention_merge_f32: bad argument");
+    return UD_ERR_BAD_ARG;
+  }
+  hipLaunchKernelGGL(attention_merge_kernel, dim3((unsigned)B * H * Nq), dim3(64), 0, (hipStream_t)stream, part, bias, out, B, NC, H, Nq);
+  UD_CHECK_LAUNCH("ud_attention_merge_f32 launch");
+  return UD_OK;
+}
 
 extern "C" int ud_attention_f16(const UdAttention* desc, void* stream) {
   const UdAttention& d = *desc;
-  if (!d.Q || !d.K || !d.Vt || !d.O || d.B <= 0 || d.H <= 0 || d.Nq <= 0 || d.Nk <= 0 || (d.ldq & 7) || (d.ldk & 7) ||
+  const bool split = d.k_chunk > 0;
+  if (split && (!d.part || (d.k_chunk & 63) || d.q_prescaled || d.kv_broadcast)) {
+    ud_set_error("ud_attention_f16: split-key mode needs part, k_chunk % 64 == 0, q_prescaled == 0, kv_broadcast == 0");
+    return UD_ERR_BAD_ARG;
+  }
+  if (!d.Q || !d.K || !d.Vt || (!d.O && !split) || d.B <= 0 || d.H <= 0 || d.Nq <= 0 || d.Nk <= 0 || (d.ldq & 7) || (d.ldk & 7) ||
       (d.ldo & 3) || (d.kv_ld & 63) || d.kv_ld < ((d.Nk + 63) & ~63)) {
     ud_set_error("ud_attention_f16: bad argument (ldq/ldk % 8, kv_ld % 64, kv_ld >= roundup(Nk, 64))");
     return UD_ERR_BAD_ARG;
@@ -286,12 +350,19 @@ extern "C" int ud_attention_f16(const UdAttention* desc, void* stream) {
   // shape (B = 8, H = 16, N = 1370), interleaved against the 4-wave build on one box: 90.6 / 90.7 us against 86.3 / 90.4 us -- halving the
   // K / V staging traffic buys nothing (105 instead of 124 VGPRs, same 16 waves per CU), and 6 tiles of 256 rows waste 5 of 48 wave slots
   // per (image, head) where 11 tiles of 128 rows waste 1 of 44.  The product builds the 4-wave form.
-  const bool wide = UD_ATTN_NW == 8 && d.Nq >= 512;
+  const bool wide = UD_ATTN_NW == 8 && d.Nq >= 512 && !split;
   const int rows_wg = wide ? 256 : 128;
   const int qt = (d.Nq + rows_wg - 1) / rows_wg, pairs = d.B * d.H;
-  dim3 grid(8 * ((pairs + 7) / 8) * qt);
+  const int ntile = (d.Nk + 63) / 64;
+  const int nc = split ? (ntile + d.k_chunk / 64 - 1) / (d.k_chunk / 64) : 1;
+  dim3 grid(8 * ((pairs + 7) / 8) * qt * nc);
   const float thr = (ud_debug_flags_host() & 1) ? -1.0f : 8.0f;
   const int extra_lds = ((ud_debug_flags_host() >> 16) & 255) * 1024;   // tools only: occupancy experiments
+  if (split) {
+    hipLaunchKernelGGL((attention_kernel<0, 0, 4, true>), grid, dim3(256), 0, (hipStream_t)stream, d, thr);
+    UD_CHECK_LAUNCH("ud_attention_f16 (split-key) launch");
+    return UD_OK;
+  }
 #ifdef UD_ABLATE
   switch ((ud_debug_flags_host() >> 8) & 31) {
 #define UD_ABL_CASE(X) case X: hipLaunchKernelGGL((attention_kernel<X, 0>), grid, dim3(256), extra_lds, (hipStream_t)stream, d, thr); break;

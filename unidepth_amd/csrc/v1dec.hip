@@ -393,12 +393,18 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(void* dst, const float* 
   }
 }
 // out fp16 [G, N, ldo] = transpose of in fp32 [G, M, N] (M <= ldo; pad columns zero): pinv @ kernel_3 as the W operand of the last Nystrom GEMM
-__global__ __launch_bounds__(256) void transpose_f32_f16_kernel(const float* in, half_t* out, int G, int M, int N, int ldo) {
+// nh > 0: the input groups are (head, image)-major (g = head * B + image, the order of the pseudo-inverse batch), the output groups
+// (image, head)-major -- with vt != 0 the output is then the V^T operand [image][head][N = 64][ldo] of ud_attention_f16, whose columns
+// hold the 4-row blocks of every aligned group of 16 input rows in the order [0, 2, 1, 3] (bits 2 and 3 of the index swapped).
+__global__ __launch_bounds__(256) void transpose_f32_f16_kernel(const float* in, half_t* out, int G, int M, int N, int ldo, int nh, int vt) {
   const long long total = (long long)G * N * ldo;
+  const int B = nh > 0 ? G / nh : 0;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    const int m = (int)(idx % ldo);
+    const int col = (int)(idx % ldo);
     const long long r = idx / ldo;
-    const int n = (int)(r % N), g = (int)(r / N);
+    const int n = (int)(r % N), go = (int)(r / N);
+    const int m = vt ? ((col & ~12) | ((col & 4) << 1) | ((col & 8) >> 1)) : col;       // the swap is its own inverse
+    const int g = nh > 0 ? (go % nh) * B + go / nh : go;
     out[idx] = m < M ? (half_t)in[((size_t)g * M + m) * N + n] : (half_t)0.f;
   }
 }
@@ -595,12 +601,15 @@ extern "C" int ud_v1_op(const UdV1Op* desc, void* stream) {
       UD_CHECK_LAUNCH("ud_v1_op(copy_rows) launch");
       return UD_OK;
     }
-    case UD_V1_TRANSPOSE16: {    // a = fp32 [G, M, N] -> out fp16 [G, N, ldo] (transposed, zero padded); i = G, M, N, ldo
-      if (!d.a || !d.out || i[0] <= 0 || i[3] < i[1]) break;
-      hipLaunchKernelGGL(transpose_f32_f16_kernel, dim3(grid1((long long)i[0] * i[2] * i[3])), dim3(256), 0, s, (const float*)d.a, (half_t*)d.out, i[0], i[1], i[2], i[3]);
+    case UD_V1_TRANSPOSE16: {    // a = fp32 [G, M, N] -> out fp16 [G, N, ldo] (transposed, zero padded); i = G, M, N, ldo, nh, vt
+      if (!d.a || !d.out || i[0] <= 0 || i[3] < i[1] || i[4] < 0 || (i[4] > 0 && i[0] % i[4]) || (i[5] && (i[3] & 15))) break;
+      hipLaunchKernelGGL(transpose_f32_f16_kernel, dim3(grid1((long long)i[0] * i[2] * i[3])), dim3(256), 0, s, (const float*)d.a, (half_t*)d.out, i[0], i[1], i[2], i[3],
+                         i[4], i[5]);
       UD_CHECK_LAUNCH("ud_v1_op(transpose16) launch");
       return UD_OK;
     }
+    case UD_V1_ATTN_MERGE:       // a = part (ud_attention_f16 split-key mode), b = bias fp32 [H * 64] or NULL, out fp32 [H][B][Nq][64]; i = B, NC, H, Nq
+      return ud_attention_merge_f32((const float*)d.a, (const float*)d.b, (float*)d.out, i[0], i[1], i[2], i[3], stream);
     case UD_V1_CAMERA: {         // a = raw fp32 [B*4]; out = K33, out2 = Kinv33, c = Kpost33 (written); i = B, Hn, Wn, pad_l, pad_t; f[0] = ratio
       if (!d.a || !d.out || !d.out2 || !d.c || i[0] <= 0 || !(d.f[0] > 0.f)) break;
       hipLaunchKernelGGL(camera_v1_kernel, dim3((i[0] + 63) / 64), dim3(64), 0, s, (const float*)d.a, (float*)d.out, (float*)d.out2, (float*)d.c, i[0], i[1], i[2], d.f[0], i[3], i[4]);

@@ -40,6 +40,10 @@ def _rup(x, m):
 # noise, a quarter of the encoder's MFMA work saved; the same blocks' fc2 (A = GELU output, every channel's mean positive: a rounding
 # error of W shifts an output channel by the same amount at every pixel) 7.8 / 8.5 / 8.1e-4; the depth decoder's LayerNorm-fed GEMMs
 # 1.1-1.2e-3: not those.  Default: split everything except the ConvNeXt fc1; UNIDEPTH_V1_WSPLIT=all splits those too.
+# Nystrom stages: kernel_1 / kernel_3 are never materialised -- softmax(q_l k^T) v runs as split-key flash attention (ud_attention_f16 with
+# k_chunk + ud_attention_merge_f32) and softmax(q k_l^T) (pinv(kernel_2) kernel_3 v) as plain flash attention over the 128 landmarks.
+# UNIDEPTH_V1_NYS_FLASH=0: the first form (GEMM -> row softmax -> GEMM through fp32 score matrices in HBM), kept for A/B runs.
+NYS_FLASH = os.environ.get("UNIDEPTH_V1_NYS_FLASH", "1") != "0"
 _WSPLIT_ENV = os.environ.get("UNIDEPTH_V1_WSPLIT", "1")
 WSPLIT = _WSPLIT_ENV != "0"
 WSPLIT_CONVNEXT_FC1 = _WSPLIT_ENV == "all"
@@ -259,8 +263,11 @@ def pack_v1_decoder(config: dict, sd: dict, device) -> dict:
             src, dst = f"{dl}{nm}.{i}.", f"{nm}.{i}."
             lin_ln16(dst + "q", src + "q", None, src + "norm_attnx")
             wkv, bkv = _fold_ln(f[src + "kv.weight"], f[src + "kv.bias"], f[src + "norm_attnctx.weight"], f[src + "norm_attnctx.bias"])
-            p16(dst + "k.w", wkv[:d]); p32(dst + "k.b", bkv[:d])
-            p16(dst + "v.w", wkv[d:]); p32(dst + "v.b", bkv[d:])
+            if NYS_FLASH:                      # one [K | V] GEMM with the V^T scatter epilogue, like layers_16
+                p16(dst + "kv.w", wkv); p32(dst + "kv.b", bkv)
+            else:
+                p16(dst + "k.w", wkv[:d]); p32(dst + "k.b", bkv[:d])
+                p16(dst + "v.w", wkv[d:]); p32(dst + "v.b", bkv[d:])
             p16(dst + "out.w", f[src + "out.weight"] * f[src + "ls1.gamma"][:, None]); p32(dst + "out.b", f[src + "out.bias"] * f[src + "ls1.gamma"])
             mlp16(dst, src + "mlp.", f[src + "ls2.gamma"])
     for nm, d in (("up8", C), ("up4", C // 2), ("up2", C // 4)):
@@ -992,6 +999,67 @@ class _FullPlan:
 
         # ---------------- Nystrom attention block (layers/nystrom_attention.py:22-84; xformers NystromAttention, 128 landmarks -- PARITY UNPINNED)
         def nystrom_block(pre, x, e_tok, n, Cl, nh):
+            (nystrom_block_flash if NYS_FLASH else nystrom_block_scores)(pre, x, e_tok, n, Cl, nh)
+
+        def nystrom_pinv(K2, G, Lm):
+            """Z ~ pinv(kernel_2) for all (head, image) pairs at once: Z0 = K^T / (||K||_1 ||K||_inf), six Newton-Schulz steps
+            Z <- 1/4 Z (13 I - KZ (15 I - KZ (7 I - KZ)))  (xformers iterative_pinv)."""
+            Z = z(G * Lm, Lm, dtype=f32); Zn = z(G * Lm, Lm, dtype=f32); KZ = z(G * Lm, Lm, dtype=f32); T1 = z(G * Lm, Lm, dtype=f32); T2 = z(G * Lm, Lm, dtype=f32)
+            P.v1(L.UD_V1_PINV_INIT, a=K2, out=Z, i=(G, Lm), tag="pinv")
+            za, zb = Z, Zn
+            for _ in range(6):
+                P.v1(L.UD_V1_BMM, a=K2, b=za, out=KZ, i=(G, Lm, Lm, Lm), f=(1.0, 0.0), tag="pinv")        # KZ
+                P.v1(L.UD_V1_BMM, a=K2, b=za, out=T1, i=(G, Lm, Lm, Lm), f=(-1.0, 7.0), tag="pinv")       # 7 I - KZ
+                P.v1(L.UD_V1_BMM, a=KZ, b=T1, out=T2, i=(G, Lm, Lm, Lm), f=(-1.0, 15.0), tag="pinv")      # 15 I - KZ (7 I - KZ)
+                P.v1(L.UD_V1_BMM, a=KZ, b=T2, out=T1, i=(G, Lm, Lm, Lm), f=(-1.0, 13.0), tag="pinv")      # 13 I - KZ (...)
+                P.v1(L.UD_V1_BMM, a=za, b=T1, out=zb, i=(G, Lm, Lm, Lm), f=(0.25, 0.0), tag="pinv")       # Z <- 1/4 Z (...)
+                za, zb = zb, za
+            return za
+
+        def nystrom_block_flash(pre, x, e_tok, n, Cl, nh):
+            """out = kernel_1 pinv(kernel_2) (kernel_3 v) with kernel_1 = softmax(q k_l^T), kernel_2 = softmax(q_l k_l^T), kernel_3 = softmax(q_l k^T),
+            q_l / k_l = 128 segment means (layers/nystrom_attention.py:22-84 -> xformers NystromAttention).  Only kernel_2 (128 x 128) exists
+            in memory: kernel_3 v is a flash attention of the 128 landmark queries over all n keys, split along the keys (one pair alone
+            would walk up to 300 key tiles) and merged; kernel_1 (...) is a flash attention of the n queries over the 128 landmark keys
+            whose "values" are T = pinv(kernel_2) kernel_3 v."""
+            M = B * n
+            npad = _rup(n, 64)
+            Lm = 128
+            xn = z(M, Cl); q = z(M, Cl); k = z(M, Cl); vt = z(B, nh, 64, npad); ao = z(M, Cl)
+            ln(x, xn, M, Cl)
+            gemm(xn, pre + "q", q, M, Cl, Cl, epi=UD_EPI_F16, add=e_tok, ldadd=Cl)
+            P.gemm(A=xn, W=w[pre + "kv.w"], bias=w[pre + "kv.b"], out=k, out2=vt, M=M, N=2 * Cl, lda=Cl, ldc=Cl, epi=UD_EPI_QKV, vsplit=Cl, **_wk(w[pre + "kv.w"], Cl),
+                   tok_per_img=n, kv_ld=npad, heads_v=nh, tag="v1.nys.kv")
+            ql = z(B * Lm, Cl); kl = z(B * Lm, Cl)
+            P.v1(L.UD_V1_SEGMENT_MEAN, a=q, out=ql, i=(B, n, Cl, Lm, Cl, Cl), tag="landmarks")
+            P.v1(L.UD_V1_SEGMENT_MEAN, a=k, out=kl, i=(B, n, Cl, Lm, Cl, Cl), tag="landmarks")
+            sc = 64 ** -0.5
+            G = nh * B                                                         # (head, image) groups of the small fp32 matrices
+            S2 = z(B * Lm, Lm, dtype=f32); K2 = z(G * Lm, Lm, dtype=f32)
+            for hd in range(nh):
+                o2 = hd * 64 * 2                                                 # byte offset of the head's 64 columns in an fp16 row
+                P.gemm(A=ql.data_ptr() + o2, W=kl.data_ptr() + o2, out=S2, M=Lm, N=Lm, K=64, lda=Cl, ldw=Cl, ldc=Lm, epi=UD_EPI_F32, groups=B, gA=Lm * Cl,
+                       gW=Lm * Cl, gOut=Lm * Lm, tag="v1.nys.k2")
+                P.v1(L.UD_V1_SOFTMAX, a=S2, out=K2[hd * B * Lm:(hd + 1) * B * Lm], i=(B * Lm, Lm, Lm, Lm, 1, 0), f=(sc,), tag="softmax")
+            # kernel_3 v: ~1024 workgroups (chunks of whole 64-key tiles), then the merge into the (head, image)-major fp32 batch
+            nt = npad // 64
+            tpc = max(1, -(-nt // max(1, 1024 // G)))
+            nc = -(-nt // tpc)
+            part = z(B * nc * nh * Lm, L.UD_ATTN_PART_LD, dtype=f32); k3 = z(G * Lm, 64, dtype=f32)
+            P.attention(Q=ql, K=k, Vt=vt, O=None, B=B, H=nh, Nq=Lm, Nk=n, ldq=Cl, ldk=Cl, ldo=Cl, kv_ld=npad, q_rows_per_img=Lm, k_rows_per_img=n, scale=sc,
+                        k_chunk=tpc * 64, part=part, tag="v1.nys.k3v")
+            P.v1(L.UD_V1_ATTN_MERGE, a=part, out=k3, i=(B, nc, nh, Lm), tag="nys.merge")
+            za = nystrom_pinv(K2, G, Lm)
+            T = z(G * Lm, 64, dtype=f32); Tt = z(B, nh, 64, Lm)
+            P.v1(L.UD_V1_BMM, a=za, b=k3, out=T, i=(G, Lm, 64, Lm), f=(1.0, 0.0), tag="nys.pinv_k3")
+            P.v1(L.UD_V1_TRANSPOSE16, a=T, out=Tt, i=(G, Lm, 64, Lm, nh, 1), tag="nys.T")
+            P.attention(Q=q, K=kl, Vt=Tt, O=ao, B=B, H=nh, Nq=n, Nk=Lm, ldq=Cl, ldk=Cl, ldo=Cl, kv_ld=Lm, q_rows_per_img=n, k_rows_per_img=Lm, scale=sc,
+                        tag="v1.nys.out")
+            gemm(ao, pre + "out", x, M, Cl, Cl, epi=UD_EPI_F32, accumulate=1)
+            mlp(x, pre, M, Cl, 4)
+            self._keep = getattr(self, "_keep", []) + [ql, kl]                  # raw-pointer operands of the per-head launches
+
+        def nystrom_block_scores(pre, x, e_tok, n, Cl, nh):
             M = B * n
             npad = _rup(n, 64)
             Lm = 128
@@ -1008,7 +1076,6 @@ class _FullPlan:
             G = nh * B                                                         # (head, image) groups of the small fp32 matrices
             S1 = z(M, Lm, dtype=f32); P1 = z(nh, M, Lm); S2 = z(B * Lm, Lm, dtype=f32); K2 = z(G * Lm, Lm, dtype=f32)
             S3 = z(B * Lm, n, dtype=f32); P3 = z(B * Lm, npad); k3 = z(G * Lm, 64, dtype=f32)
-            Z = z(G * Lm, Lm, dtype=f32); Zn = z(G * Lm, Lm, dtype=f32); KZ = z(G * Lm, Lm, dtype=f32); T1 = z(G * Lm, Lm, dtype=f32); T2 = z(G * Lm, Lm, dtype=f32)
             T = z(G * Lm, 64, dtype=f32); Tt = z(G * 64, Lm)
             for hd in range(nh):
                 o2 = hd * 64 * 2                                                 # byte offset of the head's 64 columns in an fp16 row
@@ -1023,17 +1090,7 @@ class _FullPlan:
                 P.v1(L.UD_V1_SOFTMAX, a=S3, out=P3, i=(B * Lm, n, n, npad, 0, 0), f=(sc,), tag="softmax")
                 P.gemm(A=P3, W=vt.data_ptr() + hd * 64 * npad * 2, bias=w[pre + "v.b"].data_ptr() + hd * 64 * 4, out=k3[hd * B * Lm:(hd + 1) * B * Lm], M=Lm, N=64,
                        K=npad, lda=npad, ldw=npad, ldc=64, epi=UD_EPI_F32, groups=B, gA=Lm * npad, gW=Cl * npad, gBias=0, gOut=Lm * 64, tag="v1.nys.k3v")
-            # pseudo-inverse of kernel_2 for all (head, image) pairs at once: Z0 = K^T / ||K||_1, six Newton-Schulz steps
-            # Z <- 1/4 Z (13 I - KZ (15 I - KZ (7 I - KZ)))
-            P.v1(L.UD_V1_PINV_INIT, a=K2, out=Z, i=(G, Lm), tag="pinv")
-            za, zb = Z, Zn
-            for _ in range(6):
-                P.v1(L.UD_V1_BMM, a=K2, b=za, out=KZ, i=(G, Lm, Lm, Lm), f=(1.0, 0.0), tag="pinv")        # KZ
-                P.v1(L.UD_V1_BMM, a=K2, b=za, out=T1, i=(G, Lm, Lm, Lm), f=(-1.0, 7.0), tag="pinv")       # 7 I - KZ
-                P.v1(L.UD_V1_BMM, a=KZ, b=T1, out=T2, i=(G, Lm, Lm, Lm), f=(-1.0, 15.0), tag="pinv")      # 15 I - KZ (7 I - KZ)
-                P.v1(L.UD_V1_BMM, a=KZ, b=T2, out=T1, i=(G, Lm, Lm, Lm), f=(-1.0, 13.0), tag="pinv")      # 13 I - KZ (...)
-                P.v1(L.UD_V1_BMM, a=za, b=T1, out=zb, i=(G, Lm, Lm, Lm), f=(0.25, 0.0), tag="pinv")       # Z <- 1/4 Z (...)
-                za, zb = zb, za
+            za = nystrom_pinv(K2, G, Lm)
             P.v1(L.UD_V1_BMM, a=za, b=k3, out=T, i=(G, Lm, 64, Lm), f=(1.0, 0.0), tag="nys.pinv_k3")
             P.v1(L.UD_V1_TRANSPOSE16, a=T, out=Tt, i=(G, Lm, 64, Lm), tag="nys.T")
             for hd in range(nh):
