@@ -330,7 +330,8 @@ int ud_spatial_mean_f32(const float* x, float* out, int B, int HW, int C, int ld
  *                c (optional) = fp32 scratch of B * ceil(Nk / 64) * T * (D + 2) floats: the keys are then processed in chunks of 64 by
  *                separate workgroups and merged in a second launch (deterministic order)
  *  SEGMENT_MEAN  Nystrom landmark pooling (xformers AvgPool): fp16 [G, N, ldi] -> n segment means, fp16 out and optional fp32 out2.  i = G, N, C, n, ldi, ldo
- *  BMM           out[g] = f[1] * I + f[0] * a[g] b[g], small fp32 matrices (Newton-Schulz pseudo-inverse of xformers iterative_pinv).  i = G, M, N, K
+ *  BMM           out[g] = f[1] * I + f[0] * a[g] b[g], small fp32 matrices (Newton-Schulz pseudo-inverse of xformers iterative_pinv).  i = G, M, N, K;
+ *                out2 != NULL: also out2[g] = f[3] * I + f[2] * a[g] b[g] (KZ and 7 I - KZ from one product)
  *  PINV_INIT     Z0 = K^T / max column sum (iterative_pinv initialisation).  i = G, n
  *  ADD           out = a + b (fp32; latents + ray embedding, decoder.py:263,283,303).  i = n & 0x7fffffff, n >> 31
  *  COPY_ROWS     out[(img*rows_per_img + row_off + t)*ld + d] = a[(img*T + t)*D + d] (torch.cat of token groups).  i = n_img, T, rows_per_img, row_off, D, ld, to_f16

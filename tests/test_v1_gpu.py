@@ -160,6 +160,13 @@ def test_v1_softmax_fewq_segment_bmm_pinv(ops):
     ops.v1_op(L.UD_V1_SOFTMAX, a=s, out=p, i=(300, 1064, 1064, 1088, 0, 0), f=(0.5,))
     torch.cuda.synchronize()
     assert rel(p[:, :1064].float(), torch.softmax(s * 0.5, dim=-1)) < 1e-3 and (p[:, 1064:] == 0).all()
+    # the register-resident forms (N <= 1280 above, N <= 5120 here with padding beyond the registers' span), the generic form (N % 4 != 0, N > 5120, fp32 out)
+    for (R, N, ldo, f32o) in ((50, 4800, 4800, 0), (33, 4100, 5376, 0), (20, 1131, 1152, 0), (9, 6000, 6016, 0), (64, 128, 128, 1), (40, 300, 320, 0)):
+        s = torch.randn(R, N, generator=g).cuda() * 4
+        p = torch.full((R, ldo), 7.0, dtype=torch.float32 if f32o else torch.half, device="cuda")
+        ops.v1_op(L.UD_V1_SOFTMAX, a=s, out=p, i=(R, N, N, ldo, f32o, 0), f=(0.3,))
+        torch.cuda.synchronize()
+        assert rel(p[:, :N].float(), torch.softmax(s * 0.3, dim=-1)) < (1e-6 if f32o else 1e-3) and (p[:, N:] == 0).all(), (R, N, ldo)
     # few-query attention
     B, T, Nk, D = 2, 4, 1000, 512
     q = torch.randn(B * T, D, generator=g).cuda()
@@ -194,12 +201,9 @@ def test_v1_softmax_fewq_segment_bmm_pinv(ops):
     km = torch.softmax(torch.randn(5, 128, 128, generator=g), dim=-1).cuda()
     z = torch.zeros_like(km); kz = torch.zeros_like(km); t1 = torch.zeros_like(km); t2 = torch.zeros_like(km); zn = torch.zeros_like(km)
     ops.v1_op(L.UD_V1_PINV_INIT, a=km, out=z, i=(5, 128))
-    for _ in range(6):
-        ops.v1_op(L.UD_V1_BMM, a=km, b=z, out=kz, i=(5, 128, 128, 128), f=(1.0, 0.0))
-        ops.v1_op(L.UD_V1_BMM, a=kz, b=kz, out=t1, i=(5, 128, 128, 128), f=(-1.0, 0.0))        # placeholder overwritten below (keeps shapes exercised)
-        eye = torch.eye(128, device="cuda")
-        # t1 = 7I - kz ; t2 = 15I - kz t1 ; t1 = 13I - kz t2 ; z = 0.25 z t1
-        t1.copy_(7 * eye - kz)
+    for _ in range(6):                                 # the engine's chain: KZ and 7 I - KZ from ONE product (out / out2)
+        ops.v1_op(L.UD_V1_BMM, a=km, b=z, out=kz, out2=t1, i=(5, 128, 128, 128), f=(1.0, 0.0, -1.0, 7.0))
+        assert torch.equal(t1, 7 * torch.eye(128, device="cuda") - kz)
         ops.v1_op(L.UD_V1_BMM, a=kz, b=t1, out=t2, i=(5, 128, 128, 128), f=(-1.0, 15.0))
         ops.v1_op(L.UD_V1_BMM, a=kz, b=t2, out=t1, i=(5, 128, 128, 128), f=(-1.0, 13.0))
         ops.v1_op(L.UD_V1_BMM, a=z, b=t1, out=zn, i=(5, 128, 128, 128), f=(0.25, 0.0))

@@ -2,6 +2,7 @@
 // unidepth/models/unidepthv1/decoder.py, unidepthv1.py:28-98,288-373, utils/geometric.py, utils/sht.py:833, layers/nystrom_attention.py).
 // One C-ABI entry, ud_v1_op(), dispatches on UdV1Op.kind (include/unidepth_hip.h documents every kind and cites what it replaces).
 #include "ud_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -57,75 +58,196 @@ __global__ __launch_bounds__(256) void resize_aa_kernel(const float* in, float* 
 }
 
 // ------------------------------------------------------------------------------------------------ spherical-harmonics ray embedding
-// One wave per output token: antialiased down-sampling of the planar ray map [nb,3,Hn,Wn] to (h, w) (flat_interpolate, decoder.py:205-219),
+// Antialiased down-sampling of the planar ray map [nb,3,Hn,Wn] to (h, w) (flat_interpolate, decoder.py:205-219),
 // F.normalize, the 81 real spherical harmonics of degree <= 8 (utils/sht.py:833 rsh_cart_8 is a generated closed-form table; here the
 // standard recurrences: Q_m^m = (2m-1)!!, Q_{m+1}^m = (2m+1) z Q_m^m, (l-m) Q_l^m = (2l-1) z Q_{l-1}^m - (l+m-1) Q_{l-2}^m,
 // (x+iy)^m = A_m + i B_m, Y_l^{+-m} = (-1)^m sqrt2 K_l^m Q_l^m {A_m, B_m}), then LayerNorm statistics over the 81 values (the MLP's
-// norm, affine folded into proj1) -> fp16 row of 128 (columns 81.. stay zero).  Lane i evaluates harmonic i and i + 64.
-__device__ __forceinline__ float sh_one(int idx, float x, float y, float z) {
-  int l = 0;
-  while ((l + 1) * (l + 1) <= idx) ++l;
-  const int m = idx - l * (l + 1);
-  const int am = m < 0 ? -m : m;
-  float A = 1.f, Bv = 0.f;
-  for (int k = 0; k < am; ++k) {
-    const float a2 = A * x - Bv * y;
-    Bv = A * y + Bv * x;
-    A = a2;
+// norm, affine folded into proj1) -> fp16 row of 128 (columns 81.. stay zero).
+template <int I, int N, typename F>
+__device__ __forceinline__ void sh_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    sh_static_for<I + 1, N>(f);
   }
-  float qmm = 1.f;
-  for (int k = 1; k <= am; ++k) qmm *= (float)(2 * k - 1);
-  float q = qmm, q1 = qmm, q2 = 0.f;
-  for (int ll = am + 1; ll <= l; ++ll) {
-    q = ll == am + 1 ? (float)(2 * am + 1) * z * q1 : ((float)(2 * ll - 1) * z * q1 - (float)(ll + am - 1) * q2) / (float)(ll - am);
-    q2 = q1;
-    q1 = q;
-  }
-  float ratio = 1.f;                                   // (l-m)! / (l+m)!
-  for (int k = l - am + 1; k <= l + am; ++k) ratio /= (float)k;
-  float K = sqrtf((float)(2 * l + 1) * 0.07957747154594767f * ratio);          // 1 / (4 pi)
-  if (am == 0) return K * q;
-  K *= 1.4142135623730951f * ((am & 1) ? -1.f : 1.f);
-  return K * q * (m > 0 ? A : Bv);
 }
 
-__global__ __launch_bounds__(256) void sh_embed_kernel(const float* rays, half_t* out, int nb, int Hn, int Wn, int h, int w, int ldo, int rows_per_img, float eps) {
+// Normalisation K_l^m of Y_l^{+-m} (times sqrt2 (-1)^m for m > 0), row l at offset l (l + 1) / 2: evaluated in double, rounded once.
+__constant__ float SH_K[45] = {
+    2.820947918e-01f, 4.886025119e-01f, -4.886025119e-01f, 6.307831305e-01f, -3.641828102e-01f, 1.820914051e-01f,
+    7.463526652e-01f, -3.046971996e-01f, 9.635371475e-02f, -3.933623933e-02f, 8.462843753e-01f, -2.676186174e-01f,
+    6.307831305e-02f, -1.685838828e-02f, 5.960340338e-03f, 9.356025796e-01f, -2.415715473e-01f, 4.565273129e-02f,
+    -9.318824751e-03f, 2.196468058e-03f, -6.945841871e-04f, 1.017107236e+00f, -2.219509952e-01f, 3.509353370e-02f,
+    -5.848922283e-03f, 1.067862224e-03f, -2.276689911e-04f, 6.572237664e-05f, 1.092548431e+00f, -2.064722459e-01f,
+    2.809731381e-02f, -3.973560225e-03f, 5.990367431e-04f, -9.983945719e-05f, 1.958012848e-05f, -5.233009454e-06f,
+    1.163106623e+00f, -1.938511038e-01f, 2.316963852e-02f, -2.851985351e-03f, 3.681897256e-04f, -5.105872827e-05f,
+    7.878532816e-06f, -1.438416714e-06f, 3.596041786e-07f};
+
+// Two phases per wave of 64 tokens.  (1) the antialiased average of the ray map over a token's footprint is a 64-lane reduction (up to
+// 32 x 32 taps at 1/16 resolution): the wave walks its 64 tokens one after the other and lane j keeps token j's direction.  (2) every lane
+// evaluates all 81 harmonics of ITS token with the recurrences fully unrolled (~400 flops, no divergence) and LayerNorms them in
+// registers.  The first version ran one token per wave with lane i evaluating harmonic i through loops whose trip counts depend on the
+// lane: 534 us for the 307200 tokens of the 1/4 level at bs 16, all of it divergent scalar-style work.
+__global__ __launch_bounds__(256) void sh_embed_kernel(const float* rays, half_t* out, int nb, int Hn, int Wn, int h, int w, int ldo, int rows_per_img, float eps, int tpw) {
   const int lane = threadIdx.x & 63;
-  const long long tok = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int ntw = tpw < 0 ? 64 : tpw;                 // tokens per wave (<= 64); tpw < 0: 64, every lane averaging its own footprint
+  const long long tok0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * ntw;
   const int hw = h * w;
-  if (tok >= (long long)nb * hw) return;
-  const int img = (int)(tok / hw), t = (int)(tok - (long long)img * hw);
-  const int ty = t / w, tx = t - ty * w;
-  int ylo, yn, xlo, xn;
-  float yc, yi, xc, xi;
-  aa_taps(ty, (float)Hn / (float)h, Hn, ylo, yn, yc, yi);
-  aa_taps(tx, (float)Wn / (float)w, Wn, xlo, xn, xc, xi);
+  const long long ntok = (long long)nb * hw;
+  if (tok0 >= ntok) return;
   const size_t HW = (size_t)Hn * Wn;
-  const float* r = rays + (size_t)img * 3 * HW;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, ws = 0.f;
-  for (int i = lane; i < yn * xn; i += 64) {
-    const int iy = i / xn, ix = i - iy * xn;
-    const float wgt = aa_w(iy, ylo, yc, yi) * aa_w(ix, xlo, xc, xi);
-    const size_t off = (size_t)(ylo + iy) * Wn + xlo + ix;
-    a0 += wgt * r[off]; a1 += wgt * r[off + HW]; a2 += wgt * r[off + 2 * HW];
-    ws += wgt;
+  float x = 0.f, y = 0.f, z = 1.f;
+  const int cnt = ntok - tok0 < ntw ? (int)(ntok - tok0) : ntw;
+  if (tpw < 0) {
+    // small footprints (<= ~8 x 8 taps, the 1/4 level): lane = token from the start -- 64 tokens x (one 64-lane pass + four wave sums) cost
+    // five times the 192 loads + FMAs a lane spends on its own footprint, and neighbouring lanes' footprints overlap in L1
+    const long long tok = tok0 + lane;
+    if (tok < ntok) {
+      const int img = (int)(tok / hw), t = (int)(tok - (long long)img * hw);
+      const int ty = t / w, tx = t - ty * w;
+      int ylo, yn, xlo, xn;
+      float yc, yi, xc, xi;
+      aa_taps(ty, (float)Hn / (float)h, Hn, ylo, yn, yc, yi);
+      aa_taps(tx, (float)Wn / (float)w, Wn, xlo, xn, xc, xi);
+      const float* r = rays + (size_t)img * 3 * HW;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, ws = 0.f;
+      for (int iy = 0; iy < yn; ++iy) {
+        const float wy = aa_w(iy, ylo, yc, yi);
+        const float* rr = r + (size_t)(ylo + iy) * Wn + xlo;
+        for (int ix = 0; ix < xn; ++ix) {
+          const float wgt = wy * aa_w(ix, xlo, xc, xi);
+          a0 += wgt * rr[ix]; a1 += wgt * rr[ix + HW]; a2 += wgt * rr[ix + 2 * HW];
+          ws += wgt;
+        }
+      }
+      x = a0 / ws; y = a1 / ws; z = a2 / ws;
+    }
+  } else
+  for (int j = 0; j < cnt; ++j) {
+    const long long tok = tok0 + j;
+    const int img = (int)(tok / hw), t = (int)(tok - (long long)img * hw);
+    const int ty = t / w, tx = t - ty * w;
+    int ylo, yn, xlo, xn;
+    float yc, yi, xc, xi;
+    aa_taps(ty, (float)Hn / (float)h, Hn, ylo, yn, yc, yi);
+    aa_taps(tx, (float)Wn / (float)w, Wn, xlo, xn, xc, xi);
+    const float* r = rays + (size_t)img * 3 * HW;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, ws = 0.f;
+    for (int i = lane; i < yn * xn; i += 64) {
+      const int iy = i / xn, ix = i - iy * xn;
+      const float wgt = aa_w(iy, ylo, yc, yi) * aa_w(ix, xlo, xc, xi);
+      const size_t off = (size_t)(ylo + iy) * Wn + xlo + ix;
+      a0 += wgt * r[off]; a1 += wgt * r[off + HW]; a2 += wgt * r[off + 2 * HW];
+      ws += wgt;
+    }
+    a0 = ud_wave_sum(a0); a1 = ud_wave_sum(a1); a2 = ud_wave_sum(a2); ws = ud_wave_sum(ws);
+    if (lane == j) { x = a0 / ws; y = a1 / ws; z = a2 / ws; }
   }
-  a0 = ud_wave_sum(a0); a1 = ud_wave_sum(a1); a2 = ud_wave_sum(a2); ws = ud_wave_sum(ws);
-  float x = a0 / ws, y = a1 / ws, z = a2 / ws;
+  if (lane >= cnt) return;
   const float inv = 1.0f / fmaxf(sqrtf(x * x + y * y + z * z), 1e-12f);
   x *= inv; y *= inv; z *= inv;
-  const float v0 = sh_one(lane, x, y, z);
-  const float v1 = lane + 64 < 81 ? sh_one(lane + 64, x, y, z) : 0.f;
-  const float mean = ud_wave_sum(v0 + v1) / 81.0f;
-  const float d0 = v0 - mean, d1 = lane + 64 < 81 ? v1 - mean : 0.f;
-  const float rstd = rsqrtf(ud_wave_sum(d0 * d0 + d1 * d1) / 81.0f + eps);
+  float A[9], Bv[9];                                  // (x + i y)^m = A_m + i B_m
+  A[0] = 1.f; Bv[0] = 0.f;
+#pragma unroll
+  for (int m = 1; m <= 8; ++m) {
+    A[m] = A[m - 1] * x - Bv[m - 1] * y;
+    Bv[m] = A[m - 1] * y + Bv[m - 1] * x;
+  }
+  float v[81];
+  float qmm = 1.f;
+  sh_static_for<0, 9>([&](auto Mc) {                  // compile-time (l, m): every v[] index is a constant, the table stays in registers
+    constexpr int m = decltype(Mc)::value;
+    if (m > 0) qmm *= (float)(2 * m - 1);
+    float q2 = 0.f, q1 = qmm;                         // Q_{l-2}^m, Q_{l-1}^m
+    sh_static_for<m, 9>([&](auto Lc) {
+      constexpr int l = decltype(Lc)::value;
+      float q;
+      if constexpr (l == m) q = qmm;
+      else if constexpr (l == m + 1) q = (float)(2 * m + 1) * z * q1;
+      else q = ((float)(2 * l - 1) * z * q1 - (float)(l + m - 1) * q2) / (float)(l - m);
+      if constexpr (l > m) { q2 = q1; q1 = q; }
+      const float kq = SH_K[l * (l + 1) / 2 + m] * q;
+      if constexpr (m == 0) v[l * (l + 1)] = kq;
+      else {
+        v[l * (l + 1) + m] = kq * A[m];
+        v[l * (l + 1) - m] = kq * Bv[m];
+      }
+    });
+  });
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 81; ++i) sum += v[i];
+  const float mean = sum / 81.0f;
+  float var = 0.f;
+#pragma unroll
+  for (int i = 0; i < 81; ++i) { v[i] -= mean; var = fmaf(v[i], v[i], var); }
+  const float rstd = rsqrtf(var / 81.0f + eps);
+  const long long tok = tok0 + lane;
+  const int img = (int)(tok / hw), t = (int)(tok - (long long)img * hw);
   half_t* row = out + ((size_t)img * rows_per_img + t) * ldo;
-  row[lane] = (half_t)(d0 * rstd);
-  if (lane + 64 < 81) row[lane + 64] = (half_t)(d1 * rstd);
+  if ((ldo & 7) == 0) {                               // 16-byte stores: ten chunks of 8 + the 81st value
+#pragma unroll
+    for (int c = 0; c < 10; ++c) {
+      half8 hv;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) hv[e] = (half_t)(v[c * 8 + e] * rstd);
+      *(half8*)(row + c * 8) = hv;
+    }
+    row[80] = (half_t)(v[80] * rstd);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 81; ++i) row[i] = (half_t)(v[i] * rstd);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ row softmax (fp32 scores -> fp16 probabilities)
 // out[r, :N] = softmax(scale * in[r, :N]); columns N..ldo-1 are written as zeros (K padding of the following P V GEMM).  One wave per row.
+// Rows that fit the wave's registers (N <= 256 NV, N and the strides multiples of 4): one 16-byte load per 4 scores, ONE exp per score, 8-byte
+// fp16 stores -- the generic kernel below reads every row three times with 4-byte loads and exponentiates twice (226 us for the 16 x 1200
+// x 4800 scores of aggregate_16 at bs 16: 368 MB in, 184 MB out at 2.4 TB/s).
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* in, half_t* out, long long rows, int N, int ldi, int ldo, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* src = in + (size_t)r * ldi;
+  f32x4 v[NV];
+  float m = -3.0e38f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = (k * 64 + lane) * 4;
+    if (c < N) {
+      v[k] = *(const f32x4*)(src + c);
+      m = fmaxf(fmaxf(m, fmaxf(v[k][0], v[k][1])), fmaxf(v[k][2], v[k][3]));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  const float sc = scale * 1.4426950408889634f;
+  const float msc = m * sc;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = (k * 64 + lane) * 4;
+    if (c < N) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[k][e] = __builtin_amdgcn_exp2f(fmaf(v[k][e], sc, -msc)); s += v[k][e]; }
+    }
+  }
+  s = 1.0f / ud_wave_sum(s);
+  half_t* dst = out + (size_t)r * ldo;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c = (k * 64 + lane) * 4;
+    if (c < ldo) {
+      half4 hv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) hv[e] = c < N ? (half_t)(v[k][e] * s) : (half_t)0.f;
+      *(half4*)(dst + c) = hv;
+    }
+  }
+  for (int c = (NV * 64 + lane) * 4; c < ldo; c += 256) *(half4*)(dst + c) = (half4){(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};    // K padding beyond the registers' span
+}
+
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* in, void* out, long long rows, int N, int ldi, int ldo, float scale, int out_f32) {
   const int lane = threadIdx.x & 63;
   const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -288,6 +410,37 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(const half_t* in, hal
   const int seg = N / n, nround = n - N % n;
   const int start = s < nround ? s * seg : nround * seg + (s - nround) * (seg + 1);
   const int len = (N % n == 0 || s < nround) ? seg : seg + 1;
+  const int pairs = C >> 1;
+  if ((C & 1) == 0 && (ldi & 1) == 0 && pairs <= 256) {
+    // channel PAIRS across the lanes, the segment's tokens across 256 / pairs slices of the block (a thread per channel walking the whole
+    // segment was one dependent chain of up to 150 two-byte loads: 64 us for the 1/4-level q or k at bs 16, 79 MB at 1.2 TB/s)
+    __shared__ float red[2][256];
+    const int nsl = 256 / pairs, sl = threadIdx.x / pairs, cp = threadIdx.x - sl * pairs;
+    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+    if (sl < nsl) {
+      const half_t* p = in + ((size_t)g * N + start) * ldi + 2 * cp;
+      int t = sl;
+      for (; t + nsl < len; t += 2 * nsl) {           // two independent accumulator pairs
+        const half2v u = *(const half2v*)(p + (size_t)t * ldi), v = *(const half2v*)(p + (size_t)(t + nsl) * ldi);
+        a0 += (float)u[0]; a1 += (float)u[1]; b0 += (float)v[0]; b1 += (float)v[1];
+      }
+      if (t < len) {
+        const half2v u = *(const half2v*)(p + (size_t)t * ldi);
+        a0 += (float)u[0]; a1 += (float)u[1];
+      }
+    }
+    red[0][threadIdx.x] = a0 + b0; red[1][threadIdx.x] = a1 + b1;
+    __syncthreads();
+    if (sl == 0) {
+      float s0 = 0.f, s1 = 0.f;
+      for (int k = 0; k < nsl; ++k) { s0 += red[0][k * pairs + cp]; s1 += red[1][k * pairs + cp]; }      // fixed order: deterministic
+      s0 /= (float)len; s1 /= (float)len;
+      const size_t o = ((size_t)g * n + s) * ldo + 2 * cp;
+      out16[o] = (half_t)s0; out16[o + 1] = (half_t)s1;
+      if (out32) { out32[o] = s0; out32[o + 1] = s1; }
+    }
+    return;
+  }
   for (int c = threadIdx.x; c < C; c += 256) {
     float acc = 0.f;
     const half_t* p = in + ((size_t)g * N + start) * ldi + c;
@@ -304,7 +457,8 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(const half_t* in, hal
 // this kernel ran on the VALU (15 TFLOP/s, 17.9 us per launch of 64 matrices of 128^3) -- same bits, a tenth of the issue slots.
 // 64 x 64 output tile per block, one 32 x 32 quadrant per wave, K in steps of 16 through LDS ([k][m] / [k][n]: lane = row or column).
 typedef __attribute__((ext_vector_type(16))) float f32x16v;
-__global__ __launch_bounds__(256) void bmm_small_kernel(const float* A, const float* Bm, float* Cm, int M, int N, int K, float alpha, float diag) {
+__global__ __launch_bounds__(256) void bmm_small_kernel(const float* A, const float* Bm, float* Cm, int M, int N, int K, float alpha, float diag,
+                                                        float* Cm2, float alpha2, float diag2) {
   // K in rounds of 64 (one round for the 128-landmark matrices' halves): the operands of round r + 1 are fetched into registers
   // while round r multiplies, so a 128-deep product pays two memory latencies, not eight (K steps of 16 took 17.9 us per launch
   // with either the VALU or the matrix pipe doing the arithmetic: the loop was a chain of load -> barrier -> multiply)
@@ -351,7 +505,10 @@ __global__ __launch_bounds__(256) void bmm_small_kernel(const float* A, const fl
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = m0 + wm + 8 * (r >> 2) + 4 * kk + (r & 3);
-    if (row < M && col < N) Cm[((size_t)g * M + row) * N + col] = alpha * acc[r] + (row == col ? diag : 0.f);
+    if (row < M && col < N) {
+      Cm[((size_t)g * M + row) * N + col] = alpha * acc[r] + (row == col ? diag : 0.f);
+      if (Cm2) Cm2[((size_t)g * M + row) * N + col] = alpha2 * acc[r] + (row == col ? diag2 : 0.f);      // a second affine form of the same product
+    }
   }
 }
 
@@ -534,13 +691,28 @@ extern "C" int ud_v1_op(const UdV1Op* desc, void* stream) {
     case UD_V1_SH_EMBED: {       // a = rays fp32 [nb,3,Hn,Wn], out fp16 [nb*rows_per_img, ldo]; i = nb, Hn, Wn, h, w, ldo, rows_per_img; f[0] = eps
       if (!d.a || !d.out || i[0] <= 0 || i[5] < 81 || i[3] <= 0 || i[4] <= 0) break;
       const long long ntok = (long long)i[0] * i[3] * i[4];
-      hipLaunchKernelGGL(sh_embed_kernel, dim3((unsigned)((ntok + 3) / 4)), dim3(256), 0, s, (const float*)d.a, (half_t*)d.out, i[0], i[1], i[2], i[3], i[4], i[5], i[6], d.f[0]);
+      // tokens per wave: 64 where there are enough tokens to fill the chip with such waves (phase 2 at full lane use), fewer at the coarse
+      // levels, whose footprints are large (phase 1 dominates) and whose token counts are small (measured with 64 everywhere at bs 16:
+      // 470 us at the 1/16 level -- 300 waves walking 64 x 1024 taps each -- against 71 us for one token per wave)
+      int tpw = 64;
+      while (tpw > 1 && ntok / tpw < 4096) tpw >>= 1;
+      const bool own = (long long)i[1] * i[2] <= 16LL * i[3] * i[4];      // footprint <= ~8 x 8 taps: every lane averages its own
+      const int ntw = own ? 64 : tpw;
+      if (own) tpw = -1;
+      hipLaunchKernelGGL(sh_embed_kernel, dim3((unsigned)((ntok + 4 * ntw - 1) / (4 * ntw))), dim3(256), 0, s, (const float*)d.a, (half_t*)d.out, i[0], i[1], i[2], i[3], i[4], i[5],
+                         i[6], d.f[0], tpw);
       UD_CHECK_LAUNCH("ud_v1_op(sh_embed) launch");
       return UD_OK;
     }
     case UD_V1_SOFTMAX: {        // a = scores fp32, out = fp16 (i[4] = 0) or fp32 (1); i = rows_lo, N, ldi, ldo, out_f32, rows_hi; f[0] = scale
       const long long rows = ((long long)i[5] << 31) + i[0];
       if (!d.a || !d.out || rows <= 0 || i[1] <= 0 || i[3] < i[1]) break;
+      if (!i[4] && !(i[1] & 3) && !(i[2] & 3) && !(i[3] & 3) && i[1] > 256 && i[1] <= 5120 && !((size_t)d.a & 15) && !((size_t)d.out & 7)) {
+        if (i[1] <= 1280) hipLaunchKernelGGL((softmax_rows_reg_kernel<5>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const float*)d.a, (half_t*)d.out, rows, i[1], i[2], i[3], d.f[0]);
+        else hipLaunchKernelGGL((softmax_rows_reg_kernel<20>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const float*)d.a, (half_t*)d.out, rows, i[1], i[2], i[3], d.f[0]);
+        UD_CHECK_LAUNCH("ud_v1_op(softmax, register rows) launch");
+        return UD_OK;
+      }
       hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const float*)d.a, d.out, rows, i[1], i[2], i[3], d.f[0], i[4]);
       UD_CHECK_LAUNCH("ud_v1_op(softmax) launch");
       return UD_OK;
@@ -568,9 +740,10 @@ extern "C" int ud_v1_op(const UdV1Op* desc, void* stream) {
       UD_CHECK_LAUNCH("ud_v1_op(segment_mean) launch");
       return UD_OK;
     }
-    case UD_V1_BMM: {            // a, b fp32, out fp32: out[g] = f[1] * I + f[0] * a[g] b[g]; i = G, M, N, K
+    case UD_V1_BMM: {            // a, b fp32, out fp32: out[g] = f[1] * I + f[0] * a[g] b[g]; optional out2[g] = f[3] * I + f[2] * a[g] b[g]; i = G, M, N, K
       if (!d.a || !d.b || !d.out || i[0] <= 0 || i[1] <= 0 || i[2] <= 0 || i[3] <= 0) break;
-      hipLaunchKernelGGL(bmm_small_kernel, dim3((i[2] + 63) / 64, (i[1] + 63) / 64, i[0]), dim3(256), 0, s, (const float*)d.a, (const float*)d.b, (float*)d.out, i[1], i[2], i[3], d.f[0], d.f[1]);
+      hipLaunchKernelGGL(bmm_small_kernel, dim3((i[2] + 63) / 64, (i[1] + 63) / 64, i[0]), dim3(256), 0, s, (const float*)d.a, (const float*)d.b, (float*)d.out, i[1], i[2], i[3], d.f[0], d.f[1],
+                         (float*)d.out2, d.f[2], d.f[3]);
       UD_CHECK_LAUNCH("ud_v1_op(bmm) launch");
       return UD_OK;
     }

@@ -1008,8 +1008,7 @@ class _FullPlan:
             P.v1(L.UD_V1_PINV_INIT, a=K2, out=Z, i=(G, Lm), tag="pinv")
             za, zb = Z, Zn
             for _ in range(6):
-                P.v1(L.UD_V1_BMM, a=K2, b=za, out=KZ, i=(G, Lm, Lm, Lm), f=(1.0, 0.0), tag="pinv")        # KZ
-                P.v1(L.UD_V1_BMM, a=K2, b=za, out=T1, i=(G, Lm, Lm, Lm), f=(-1.0, 7.0), tag="pinv")       # 7 I - KZ
+                P.v1(L.UD_V1_BMM, a=K2, b=za, out=KZ, out2=T1, i=(G, Lm, Lm, Lm), f=(1.0, 0.0, -1.0, 7.0), tag="pinv")   # KZ and 7 I - KZ
                 P.v1(L.UD_V1_BMM, a=KZ, b=T1, out=T2, i=(G, Lm, Lm, Lm), f=(-1.0, 15.0), tag="pinv")      # 15 I - KZ (7 I - KZ)
                 P.v1(L.UD_V1_BMM, a=KZ, b=T2, out=T1, i=(G, Lm, Lm, Lm), f=(-1.0, 13.0), tag="pinv")      # 13 I - KZ (...)
                 P.v1(L.UD_V1_BMM, a=za, b=T1, out=zb, i=(G, Lm, Lm, Lm), f=(0.25, 0.0), tag="pinv")       # Z <- 1/4 Z (...)
