@@ -127,8 +127,9 @@ ENGINE_R2 = {"": "h", "camera_layer": "x", "camera_layer.in_features": "h", "cam
 
 def main():
     torch.set_num_threads(int(os.environ.get("NT", "8")))
-    cfg = synth_v1.load_config_v1()
-    sd = synth_v1.make_synthetic_checkpoint_v1(cfg, 211)
+    vit = os.environ.get("ARCH", "cnvnxtl") == "vitl14"            # ARCH=vitl14: UniDepthV1 on the DINOv2 ViT-L/14 backbone
+    cfg = synth_v1.load_config_v1("vitl14" if vit else "cnvnxtl")
+    sd = synth_v1.make_synthetic_checkpoint_v1(cfg, 212 if vit else 211)
     cases = [(1, 240, 320), (1, 480, 640), (2, 200, 360)][: int(os.environ.get("NC", "3"))]
     refs, ins = {}, {}
     for c in cases:
@@ -155,6 +156,15 @@ def main():
         r.update({k.replace("__", "."): v for k, v in kw.items()})
         return r
 
+    if len(sys.argv) > 1 and sys.argv[1] == "placement_vit":
+        W_ALL = {**ENGINE_R2, "": "w", "camera_layer.in_features": "w", "camera_layer.aggregate.kv": "w"}
+        run("split weights everywhere", W_ALL)
+        run("ViT qkv + fc1 (LayerNorm-fed) single fp16, rest split", {**W_ALL, "attn.qkv": "h", "mlp.fc1": "h"})
+        run("ViT fc1 single fp16, rest split", {**W_ALL, "mlp.fc1": "h"})
+        run("ViT qkv single fp16, rest split", {**W_ALL, "attn.qkv": "h"})
+        run("ViT proj + fc2 single fp16, rest split", {**W_ALL, "attn.proj": "h", "mlp.fc2": "h"})
+        run("whole ViT encoder single fp16, decoder split", {**W_ALL, "pixel_encoder": "h"})
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "placement":
         # round 3: WHERE the weights have to be exact.  'w' = split-fp16 weights (A fp16, W ~fp32), 'h' = single fp16 weights.
         W_ALL = {**ENGINE_R2, "": "w", "camera_layer.in_features": "w", "camera_layer.aggregate.kv": "w"}
