@@ -726,7 +726,7 @@ def test_attention(ops, B, H, Nq, Nk, bc):
 
 
 @pytest.mark.parametrize("B,H,Nq,Nk,chunk", [(2, 2, 128, 4800, 320), (1, 2, 128, 4524, 64), (3, 4, 128, 1131, 448), (2, 1, 100, 700, 128), (1, 2, 128, 19200, 640),
-                                             (1, 1, 128, 64, 64)])
+                                             (1, 1, 128, 64, 64), (2, 3, 300, 1000, 256), (9, 1, 129, 200, 64)])
 def test_attention_split_keys(ops, B, H, Nq, Nk, chunk):
     """Split-key mode of ud_attention_f16 (UdAttention.k_chunk / part) + ud_attention_merge_f32: softmax(q k^T scale) v for few queries over many
     keys -- the Nystrom kernel_3 product.  Chunked partials (un-normalised o, running max in natural-log units, row sum) merged into the
