@@ -17,6 +17,10 @@
 // rows, the 16-byte chunk index XOR-swizzled by (row >> 1) & 7 -- applied to the per-lane global SOURCE address of the
 // DMA (its LDS destination is lane-linear) and to the ds_read_b128 address: conflict-free fragment reads.
 #include "ud_common.h"
+#include <type_traits>
+#ifndef UD_ATTN_SPLIT_SM
+#define UD_ATTN_SPLIT_SM 0
+#endif
 
 namespace {
 
@@ -218,6 +222,57 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const UdAttention p,
           for (int r = 0; r < 16; ++r) s[kb][r] -= d;
       }
       const half2v ones = {(half_t)1.0f, (half_t)1.0f};
+#if UD_ATTN_SPLIT_SM
+      // The tile in two key-block halves: exp / pack / sum of block 0, then the four P V MFMAs of block 0 with the exp / pack / sum of
+      // block 1 placed in their shadows (an MFMA occupies the issue port for one pass of its eight; the wave's own independent VALU
+      // work can issue behind it), then the four MFMAs of block 1.  Same arithmetic per element; the row sum is formed per block.
+      float lsb[2] = {0.0f, 0.0f};
+      auto sm_half = [&](auto KB) {
+        constexpr int kb = decltype(KB)::value;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            f32x2 pv;
+            pv[0] = __builtin_amdgcn_exp2f(s[kb][t * 8 + e]);
+            pv[1] = __builtin_amdgcn_exp2f(s[kb][t * 8 + e + 1]);
+            const half2v ph = __builtin_convertvector(pv, half2v);
+            if constexpr (MODE == 2) lsb[kb] = __builtin_amdgcn_fdot2(ph, ones, lsb[kb], false);
+            else lsb[kb] += pv[0] + pv[1];
+            pf[kb][t][e] = ph[0];
+            pf[kb][t][e + 1] = ph[1];
+          }
+      };
+      const char* vs2 = sb + KS_BYTES;
+      auto pv_half = [&](auto KB) {
+        constexpr int kb = decltype(KB)::value;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            const half8 vf = *(const half8*)(vs2 + (db * 32 + ql) * 128 + ((((kb * 2 + t) * 2 + hh) ^ kswz) << 4));
+            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][t], o[db], 0, 0, 0);
+          }
+      };
+      sm_half(std::integral_constant<int, 0>{});
+      __builtin_amdgcn_sched_barrier(0);
+      pv_half(std::integral_constant<int, 0>{});
+      sm_half(std::integral_constant<int, 1>{});
+      // block-0 MFMAs interleaved with block 1's softmax: per MFMA its V^T fragment read, 4 transcendentals, 6 plain VALU (2 pack + 4 adds)
+      // (V^T fragment reads run one group ahead of their MFMA: two up front, then one per group)
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+        if (g < 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      pv_half(std::integral_constant<int, 1>{});
+      l_i += lsb[0] + lsb[1];
+    }
+#else
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -234,10 +289,15 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const UdAttention p,
             pf[kb][t][e + 1] = ph[1];
           }
     }
+#endif
     l_i += ls;
 
     // ---- O^T += V^T P^T
     const char* vs = sb + KS_BYTES;
+#if UD_ATTN_SPLIT_SM
+    if constexpr (MODE == 0)
+#endif
+    {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
@@ -256,6 +316,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const UdAttention p,
         }
     }
     __builtin_amdgcn_s_setprio(0);
+    }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt+1 landed; the barrier covers the others'
     if constexpr (!(ABL & 16)) __syncthreads();
