@@ -320,6 +320,33 @@ def test_v1_convnext_fc1_is_the_one_unsplit_weight():
     assert w["ds.1.w"].shape[1] == 2 * 4 * dims[0] and w["stem.w"].shape[1] == 128
 
 
+def test_v1_nystrom_plan_and_fused_kv_packing():
+    """Host side of the Nystrom stages as flash attention: the split-key plan covers every 64-key tile exactly once with no empty chunk and
+    lands near the workgroup target; the decoder packer stores ONE [K | V] weight per Nystrom block (K rows first, as the reference's
+    `kv` Linear + 'b n (kv h d)' rearrange orders them, layers/nystrom_attention.py:59-62) with the context LayerNorm folded in."""
+    from unidepth_amd import unidepthv1 as U
+    from oracle import synth_v1
+    for nt in (1, 2, 18, 75, 76, 300, 301, 1200):
+        for pairs in (1, 2, 8, 32, 64, 256, 4096):
+            tpc, nc = U.nystrom_key_chunks(nt, pairs)
+            assert tpc >= 1 and nc >= 1 and (nc - 1) * tpc < nt <= nc * tpc, (nt, pairs, tpc, nc)
+            assert nc == 1 or pairs * nc <= 2 * 1024 or tpc == 1, (nt, pairs, tpc, nc)
+    assert U.nystrom_key_chunks(300, 32) == (10, 30) and U.nystrom_key_chunks(75, 64) == (5, 15)      # bs 16 at 640x480: 1/4 and 1/8 levels
+    assert U.NYS_FLASH
+    cfg = synth_v1.load_config_v1()
+    sd = synth_v1.make_synthetic_checkpoint_v1(cfg, 211)
+    w = U.pack_v1_decoder(cfg, sd, torch.device("cpu"))
+    C = cfg["model"]["pixel_decoder"]["hidden_dim"]
+    for nm, d in (("layers_8", C // 2), ("layers_4", C // 4)):
+        kv = w[f"{nm}.0.kv.w"]
+        assert kv.shape == (2 * d, 2 * d) and f"{nm}.0.k.w" not in w                 # [K | V] rows, two fp16 terms along K
+        src = f"pixel_decoder.depth_layer.{nm}.0."
+        g = sd[src + "norm_attnctx.weight"].float()
+        want = sd[src + "kv.weight"].float() * g[None, :]
+        got = kv[:, :d].float() + kv[:, d:].float()
+        assert (got - want).abs().max() < 2 ** -20 * want.abs().max()
+
+
 def test_v1_vit_position_embedding_scale_factor_form():
     """UniDepthV1 builds its DINOv2 with interpolate_offset = 0.1: the position embedding is resampled with scale factors (h + 0.1) / 37, not
     with an output size (backbones/dinov2.py:283-296) -- the engine's host-side resample against the pinned oracle's, and against the V2 form

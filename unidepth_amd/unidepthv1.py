@@ -49,6 +49,14 @@ WSPLIT = _WSPLIT_ENV != "0"
 WSPLIT_CONVNEXT_FC1 = _WSPLIT_ENV == "all"
 
 
+def nystrom_key_chunks(n_tiles: int, pairs: int, target_workgroups: int = 1024):
+    """Split-key plan of the Nystrom kernel_3 product (ud_attention_f16, UdAttention.k_chunk): the n_tiles 64-key tiles of every
+    (image, head) pair are cut into chunks of `tiles_per_chunk` whole tiles so that pairs x chunks is about target_workgroups (4 per CU)
+    -> (tiles_per_chunk, chunks); every tile belongs to exactly one chunk and no chunk is empty."""
+    tpc = max(1, -(-n_tiles // max(1, target_workgroups // max(1, pairs))))
+    return tpc, -(-n_tiles // tpc)
+
+
 def _padk16(w: torch.Tensor, split: Optional[bool] = None) -> torch.Tensor:
     """[N, K] fp32 -> fp16 GEMM operand, K zero-padded to a multiple of 64; split: [hi | lo] halves of the padded width each."""
     split = WSPLIT if split is None else split
@@ -1041,9 +1049,7 @@ class _FullPlan:
                        gW=Lm * Cl, gOut=Lm * Lm, tag="v1.nys.k2")
                 P.v1(L.UD_V1_SOFTMAX, a=S2, out=K2[hd * B * Lm:(hd + 1) * B * Lm], i=(B * Lm, Lm, Lm, Lm, 1, 0), f=(sc,), tag="softmax")
             # kernel_3 v: ~1024 workgroups (chunks of whole 64-key tiles), then the merge into the (head, image)-major fp32 batch
-            nt = npad // 64
-            tpc = max(1, -(-nt // max(1, 1024 // G)))
-            nc = -(-nt // tpc)
+            tpc, nc = nystrom_key_chunks(npad // 64, G)
             part = z(B * nc * nh * Lm, L.UD_ATTN_PART_LD, dtype=f32); k3 = z(G * Lm, 64, dtype=f32)
             P.attention(Q=ql, K=k, Vt=vt, O=None, B=B, H=nh, Nq=Lm, Nk=n, ldq=Cl, ldk=Cl, ldo=Cl, kv_ld=npad, q_rows_per_img=Lm, k_rows_per_img=n, scale=sc,
                         k_chunk=tpc * 64, part=part, tag="v1.nys.k3v")
