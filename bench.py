@@ -228,8 +228,15 @@ def main():
     if rank == 0:
         fl = flops_per_image()
         result["model_tflops_per_s"] = round(value * fl["total"] / 1e12 / world, 2)
+        # the metric is "images/sec + p50 latency": both halves also inside `config` / `roofline`, the objects every consumer of the line keeps
+        result["config"].update({"value_one_call": result["value_one_call"], "p50_latency_ms": result["p50_latency_ms"],
+                                 "p90_latency_ms": result["p90_latency_ms"], "inflight": result["inflight"]})
         if not args.no_kernel_timing:
             result.update(kernel_timing(torch, model, fl, B, args.dump_ops))
+            scope = result["roofline_enc_attention_mlp"]
+            result["roofline"].update({"scope_frac": scope["frac"], "scope_achieved": scope["achieved"], "scope_ms_per_step": scope["ms_per_step"],
+                                       "scope": "encoder attention + MLP blocks (north_star target 0.60): see roofline_enc_attention_mlp",
+                                       "one_call_p50_ms": result["p50_latency_ms"], "one_call_images_per_s": result["value_one_call"]})
         if world == 1 and not args.no_extra_configs and args.arch == "vitl14" and tuple(args.size) == (518, 518):
             del pipe
             model.clear_plans()
@@ -370,7 +377,7 @@ def kernel_timing(torch, model, fl, B, dump=""):
                  for k, v in sorted(tot.items(), key=lambda kv: -kv[1]["ms"])}
     # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the json)
     traffic, traffic_src = None, None
-    for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    for name in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if traffic is None and os.path.exists(tpath):
             short = dom.replace("Cfg<", "(anonymous namespace)::Cfg<")
@@ -600,7 +607,22 @@ def cpu_baseline(torch, cfg, sd, H, W):
             "sample": f"oracle/restate.py fp32, {H}x{W}, bs={nimg} (the bench workload): one pass per candidate thread count, then {reps} passes at the best "
                       f"({n} threads), p50",
             "config0_vits_462x616_bs1": {"value": round(1.0 / statistics.median(t1), 3), "unit": "images/s", "p50_s": round(statistics.median(t1), 4),
-                                         "passes": 5}}
+                                         "passes": 5},
+            **_port_vs_reference(nimg / p50)}
+
+
+def _port_vs_reference(port_value):
+    """The `port` (oracle/restate.py) skips dead work the live reference performs.  Both were timed once on identical input and
+    threads in the authoring container (tools/port_vs_reference.py -> profiles/r04_port_vs_reference.json; /root/reference does not exist on
+    the GPU box): the ratio corrects the port number to what the reference itself would reach on these cores."""
+    try:
+        r = json.load(open(os.path.join(ROOT, "profiles", "r04_port_vs_reference.json")))
+        ratio = float(r["port_vs_reference"])
+        return {"port_vs_reference": ratio, "reference_equivalent_value": round(port_value / ratio, 4),
+                "port_vs_reference_source": f"profiles/r04_port_vs_reference.json ({r['workload']}, {r['threads']} threads: port {r['port_s']} s, "
+                                            f"live reference {r['reference_s']} s per call)"}
+    except Exception:
+        return {"port_vs_reference": None}
 
 
 if __name__ == "__main__":

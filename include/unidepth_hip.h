@@ -84,7 +84,9 @@ typedef struct UdGemm {
                                   5 / 6 = 128x128 tiles: plain 2-stage kernel / 4-stage pipelined ring (6 is what auto picks when the
                                   tile count is at most the CU count and K >= 512), 7 = 6 + the two-way K split below,
                                   8 = row-balanced schedule of the 256-column kernel (dense A; auto picks it when the tile list
-                                  would leave the last round partly empty) */
+                                  would leave the last round partly empty), 9 = 192x256 tiles with the 2-deep weight ring (dense
+                                  192-row launches otherwise fetch the weight operand two K-tiles ahead through a 3-deep LDS ring:
+                                  same bits, the weights of a layer are cold in every step) */
   /* optional scratch for the two-way K split of small problems (at most 128 tiles of 128x128, K >= 1024, dense A, F16 / F32
    * epilogues): two workgroups on different CUs each take half of K, the later one adds the other's fp32 partial tile (a + b is
    * order-independent, so results do not depend on timing) and runs the epilogue.  splitk_ws: 2 * tiles * 64 KB; splitk_cnt: one

@@ -364,3 +364,42 @@ def test_v1_vit_position_embedding_scale_factor_form():
     v2 = torch.nn.functional.interpolate(grid, size=(33, 44), mode="bicubic", antialias=False).permute(0, 2, 3, 1).reshape(33 * 44, 64)
     assert (got[1:] - v2).abs().max() > 1e-3
     assert torch.equal(vit_pos_embed_v1(pe, 37, 37), pe[0])
+
+
+def test_engine_classes_are_nn_modules(tmp_path):
+    """Reference: `class UniDepthV2(nn.Module, PyTorchModelHubMixin, ...)` (unidepthv2.py:111-117; V1: unidepthv1.py:97-103).  Code written
+    against it may type-check, call, cast or walk the model: the engine classes answer those calls (unidepth_amd/module.py) -- no
+    registered parameters (weights live as repacked device buffers), casts are warned no-ops, train(True) is refused, state_dict() is the
+    fp32 reference-keyed dict, save_pretrained / from_pretrained round-trip in the HF layout, push_to_hub exists with huggingface_hub."""
+    import warnings
+    import torch
+    from oracle import synth, synth_v1
+    from unidepth_amd import UniDepthV1, UniDepthV2
+    from unidepth_amd.export import UniDepthV2ONNX
+    cfg = synth.load_config("vits14")
+    sd = synth.make_synthetic_checkpoint(cfg, 3)
+    for cls in (UniDepthV2, UniDepthV2ONNX):
+        m = cls(cfg).load_state_dict(sd)
+        assert isinstance(m, torch.nn.Module) and list(m.parameters()) == [] and m.training is False
+        assert m.eval() is m and m.train(False) is m and m.requires_grad_(False) is m and m.cpu() is m
+        with pytest.raises(RuntimeError):
+            m.train()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert m.half() is m and m.float() is m and m.bfloat16() is m and m.to(torch.float16) is m and m.to(dtype=torch.float32) is m
+        assert len(w) == 5 and all("no-op" in str(x.message) for x in w)
+        got = m.state_dict()
+        assert set(got) == set(sd) and all(got[k].dtype == torch.float32 and torch.equal(got[k], sd[k].float()) for k in sd)
+        with pytest.raises(RuntimeError, match="ROCm GPU only"):        # model(...) is infer(): no CPU path, and it says so
+            m(torch.zeros(1, 3, 28, 28))
+    m.save_pretrained(tmp_path / "v2")
+    m2 = UniDepthV2.from_pretrained(str(tmp_path / "v2"))
+    assert all(torch.equal(m2.state_dict()[k], got[k]) for k in got) and m2.config == cfg
+    try:
+        import huggingface_hub  # noqa: F401
+        assert callable(getattr(m, "push_to_hub", None))
+    except ImportError:
+        pass
+    cfg1 = synth_v1.load_config_v1("cnvnxtl")
+    v1 = UniDepthV1(cfg1)
+    assert isinstance(v1, torch.nn.Module) and v1.eval() is v1 and v1.device.type == "cpu"

@@ -118,6 +118,45 @@ def test_gemm_big_tiles_persistent(ops, hint):
     assert vt_unused_zero(vt, Npad)
 
 
+@pytest.mark.parametrize("M,N,K", [(11008, 1024, 1024), (11008, 1024, 4096), (2752, 768, 128), (5000, 1792, 192), (11008, 3072, 1024)])
+def test_gemm_weight_ring_depth_is_bit_identical(ops, M, N, K):
+    """192-row tile list: the default form fetches the weight operand TWO K-tiles ahead through a 3-deep LDS ring (counted vmcnt across the
+    barrier, W stream continuous over tile boundaries), tile_hint 9 keeps the 2-deep ring.  Only the prefetch distance differs: every output
+    must carry the same bits -- fp16 + GELU, fp32 accumulate with the fp16 copy, Q|K + V^T -- at K = 2 .. 64 K-tiles, one and several
+    tiles per workgroup, partial edge tiles; and the result must be right (fp32 torch statement)."""
+    A = rnd(M, K, seed=1).half()
+    W = rnd(N, K, scale=K ** -0.5, seed=2).half()
+    bias = rnd(N, seed=3)
+    ref = A.float() @ W.float().t() + bias
+    outs = []
+    for hint in (3, 9):
+        o = torch.zeros(M, N, dtype=torch.half, device="cuda")
+        ops.gemm(A=A, W=W, bias=bias, out=o, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, epi=ops.UD_EPI_F16, act=ops.UD_ACT_GELU, tile_hint=hint)
+        x = rnd(M, N, seed=5)
+        x16 = torch.zeros(M, N, dtype=torch.half, device="cuda")
+        ops.gemm(A=A, W=W, bias=bias, out=x, out2=x16, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, ldc2=N, epi=ops.UD_EPI_F32, accumulate=1, tile_hint=hint)
+        torch.cuda.synchronize()
+        outs.append((o, x, x16))
+    assert rel(outs[0][0].float(), F.gelu(ref)) < 1e-3
+    assert rel(outs[0][1], rnd(M, N, seed=5) + ref) < 2e-5
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    if N % 768 == 0 and M % 1376 == 0:               # Q|K + V^T epilogue (N = 3 D, D % 256 == 0)
+        D, H, Npad, kv_ld = N // 3, N // 3 // 64, 1376, 1408
+        B = M // Npad
+        res = []
+        for hint in (3, 9):
+            qk = torch.zeros(M, 2 * D, dtype=torch.half, device="cuda")
+            vt = torch.zeros(B, H, 64, kv_ld, dtype=torch.half, device="cuda")
+            ops.gemm(A=A, W=W, bias=bias, out=qk, out2=vt, M=M, N=N, K=K, lda=K, ldw=K, ldc=2 * D, epi=ops.UD_EPI_QKV,
+                     vsplit=2 * D, tok_per_img=Npad, kv_ld=kv_ld, heads_v=H, tile_hint=hint)
+            torch.cuda.synchronize()
+            res.append((qk, vt))
+        assert rel(res[0][0].float(), ref[:, :2 * D]) < 1e-3
+        assert rel(res[0][1][..., vt_cols(Npad)].float(), ref[:, 2 * D:].view(B, Npad, H, 64).permute(0, 2, 3, 1)) < 1e-3
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 def test_gemm_row_balanced_schedule_is_bit_identical(ops):
     """tile_hint 8 (row-balanced spans cut into 128 / 192 / 256-row tiles, one column group of workgroups per 256 outputs) only
     re-orders WHICH workgroup computes a row: every output element must carry the same bits as the classic tile list gives it --

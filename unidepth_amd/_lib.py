@@ -179,10 +179,8 @@ def _load():
     lib.ud_last_error.argtypes = []
     lib.ud_last_error.restype = C.c_char_p
     for i, st in enumerate([UdGemm, UdLayerNorm, UdAttention, UdPreprocess, UdRayEmbed, UdUpsample2x, UdResizeAC, UdFinalize, UdLinearF32, UdDwConv7, UdV1Op, UdKnn, UdExtractPatches]):
-        # UNIDEPTH_HIP_LIB_ALLOW_OLDER (tools/ab_bench.sh only): an older build passed via UNIDEPTH_HIP_LIB may know a PREFIX of a descriptor
-        # (fields are only ever appended); anything else is a hard error
-        if os.environ.get("UNIDEPTH_HIP_LIB_ALLOW_OLDER") and "UNIDEPTH_HIP_LIB" in os.environ and 0 < lib.ud_struct_size(i) <= C.sizeof(st):
-            continue
+        # a library whose descriptors differ from this mirror in ANY way is a hard error (A/B runs rebuild both arms from one tree:
+        # an older .so would read the appended fields -- a_wrap, row_stats_*, k_chunk -- as garbage or not at all)
         if lib.ud_struct_size(i) != C.sizeof(st):
             raise ImportError(f"ctypes mirror of {st.__name__} is out of sync with include/unidepth_hip.h "
                               f"({C.sizeof(st)} vs {lib.ud_struct_size(i)} bytes)")

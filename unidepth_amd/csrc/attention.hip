@@ -21,6 +21,27 @@
 #ifndef UD_ATTN_SPLIT_SM
 #define UD_ATTN_SPLIT_SM 0
 #endif
+// Round-4 compile-time variants (tools/r4_attn_variants.sh builds one library per combination; DESIGN 10.2 has the measurements):
+//   UD_ATTN_NSTAGE  K / V^T ring depth (2 = one tile ahead, awaited with vmcnt(0) at the end of every tile; 3 / 4 = two / three tiles
+//                   ahead, the end-of-tile wait is a COUNTED vmcnt that leaves the younger tiles in flight, raw s_barrier)
+//   UD_ATTN_NOPRIO  no s_setprio(1) around the P V MFMAs
+//   UD_ATTN_OAGPR   the O^T accumulators pinned to AGPRs (inline-asm MFMA, "+a"): the P V MFMAs then read / write C and D through the
+//                   accumulator file instead of the VGPR ports the other waves' VALU work needs
+//   UD_ATTN_NOMAX   MODE 1: no per-tile row maximum.  P = exp2(S - m) is formed optimistically against the running offset m and the tile is
+//                   redone on the slow path (exact maximum, rescale) only when a lane's partial row sum exceeds 2^15 -- every P <= 2^15 is
+//                   exactly representable in fp16 range and the statistics are fp32.  The first tile of a workgroup always takes the slow path.
+#ifndef UD_ATTN_NSTAGE
+#define UD_ATTN_NSTAGE 2
+#endif
+#ifndef UD_ATTN_NOPRIO
+#define UD_ATTN_NOPRIO 0
+#endif
+#ifndef UD_ATTN_OAGPR
+#define UD_ATTN_OAGPR 0
+#endif
+#ifndef UD_ATTN_NOMAX
+#define UD_ATTN_NOMAX 0
+#endif
 
 namespace {
 
@@ -46,7 +67,8 @@ constexpr int STAGE = KS_BYTES + VS_BYTES;
 // kernel_3 product: 128 landmark queries x up to 19200 keys per (image, head) -- one workgroup per pair would walk 300 key tiles alone).
 template <int ABL, int MODE, int NW = 4, bool SPLIT = false>
 __global__ __launch_bounds__(NW * 64) void attention_kernel(const UdAttention p, const float defer_thr) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  constexpr int NST = UD_ATTN_NSTAGE;
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,56 +144,111 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const UdAttention p,
   float l_i = 0.0f;
   const float c = p.scale * 1.4426950408889634f;
 
-  issue(kt0, 0);
+  // ring prologue: tiles kt0 .. kt0 + NST - 2 go out, all of them awaited once (a few hundred ns per workgroup, off the per-tile path)
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i)
+    if (kt0 + i < kt1) issue(kt0 + i, i);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const int kswz = (ql >> 1) & 7;   // (key >> 1) & 7 for key = kb*32 + ql
+  int st_cur = 0, st_new = NST - 1;   // ring slots of tile kt and of the tile issued during it (kt + NST - 1)
   for (int kt = kt0; kt < kt1; ++kt) {
+    const bool ahead = kt + NST - 1 < kt1;
     if constexpr (!(ABL & 8)) {
-      if (kt + 1 < kt1) issue(kt + 1, (kt + 1 - kt0) & 1);   // every wave passed the barrier that ended tile kt-1: that stage is free
+      if (ahead) issue(kt + NST - 1, st_new);   // every wave passed the barrier that ended tile kt-1, the last reader of that slot
     }
-    const char* sb = smem + ((ABL & 8) ? 0 : ((kt - kt0) & 1)) * STAGE;
+    const char* sb = smem + ((ABL & 8) ? 0 : st_cur) * STAGE;
 
-    // ---- S^T = K Q^T  (two 32-key blocks)
+    // ---- S^T = K Q^T  (two 32-key blocks), MODE >= 1: minus the running offset m_i
     f32x16 s[2];
+    auto scores = [&]() {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+      for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kb][r] = MODE ? -m_i : 0.0f;
-      const char* kp = sb + (kb * 32 + ql) * 128;
+        for (int r = 0; r < 16; ++r) s[kb][r] = MODE ? -m_i : 0.0f;
+        const char* kp = sb + (kb * 32 + ql) * 128;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const half8 kf = *(const half8*)(kp + (((ks * 2 + hh) ^ kswz) << 4));
-        if constexpr (ABL & 4) {
-          asm volatile("" ::"v"(kf));
-          s[kb][ks] += (float)kf[0];
-        } else {
-          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kb], 0, 0, 0);
+        for (int ks = 0; ks < 4; ++ks) {
+          const half8 kf = *(const half8*)(kp + (((ks * 2 + hh) ^ kswz) << 4));
+          if constexpr (ABL & 4) {
+            asm volatile("" ::"v"(kf));
+            s[kb][ks] += (float)kf[0];
+          } else {
+            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kb], 0, 0, 0);
+          }
         }
       }
-    }
-    // ---- mask the key tail (last tile only)
-    if (kt == nt - 1 && (p.Nk & (KT - 1))) {
-      const int kbase = kt * KT + 4 * hh;
+      // ---- mask the key tail (last tile only)
+      if (kt == nt - 1 && (p.Nk & (KT - 1))) {
+        const int kbase = kt * KT + 4 * hh;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2);
+            if (key >= p.Nk) s[kb][r] = -1.0e30f;
+          }
+      }
+    };
+    constexpr bool NOMAX = UD_ATTN_NOMAX && MODE == 1 && !UD_ATTN_SPLIT_SM;
+    if constexpr (!NOMAX) scores();
+    // ---- online softmax (lane-local + partner lane ^ 32), max update deferred until it grows by > 2^8 (fp16 P has
+    //      constant relative precision, so P up to 256 costs no accuracy; accumulation is fp32)
+    auto rowmax = [&]() {
+      float mt = s[0][0];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2);
-          if (key >= p.Nk) s[kb][r] = -1.0e30f;
-        }
-    }
-    // ---- online softmax (lane-local + partner lane ^ 32), max update deferred until it grows by > 2^8 (fp16 P has
-    //      constant relative precision, so P up to 256 costs no accuracy; accumulation is fp32)
-    float mt = s[0][0];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) mt = fmaxf(fmaxf(mt, s[kb][r]), s[kb][r + 1]);
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        for (int r = 0; r < 16; r += 2) mt = fmaxf(fmaxf(mt, s[kb][r]), s[kb][r + 1]);
+      return fmaxf(mt, __shfl_xor(mt, 32, 64));
+    };
+    float mt = 0.0f;
+    if constexpr (!NOMAX) mt = rowmax();
     float ls = 0.0f;
     half8 pf[2][2];
+    if constexpr (NOMAX) {
+      // optimistic tile: P = exp2(S - m_i) with the offset as it stands; redone with the exact maximum only if a partial row sum says a P
+      // may have left the fp16 range (or on the first tile, where m_i is not yet a maximum of anything)
+      bool slow = kt == kt0;
+      for (;;) {
+        scores();
+        if (slow) {
+          const float mx = rowmax();
+          const float d = kt == kt0 ? mx : fmaxf(mx, 0.0f);
+          m_i += d;
+          if (kt != kt0) {
+            const float alpha = __builtin_amdgcn_exp2f(-d);
+            l_i *= alpha;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+          }
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] -= d;
+        }
+        ls = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+              f32x2 pv;
+              pv[0] = __builtin_amdgcn_exp2f(s[kb][t * 8 + e]);
+              pv[1] = __builtin_amdgcn_exp2f(s[kb][t * 8 + e + 1]);
+              ls += pv[0] + pv[1];
+              const half2v ph = __builtin_convertvector(pv, half2v);
+              pf[kb][t][e] = ph[0];
+              pf[kb][t][e + 1] = ph[1];
+            }
+        if (slow || !__any(!(ls <= 32768.0f))) break;      // NaN / inf safe: anything not provably small redoes the tile
+        slow = true;
+      }
+    } else
     if constexpr (MODE == 0) {
       if (__any((mt - m_i) * c > defer_thr)) {
         const float m_new = fmaxf(m_i, mt);
@@ -298,7 +375,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const UdAttention p,
     if constexpr (MODE == 0)
 #endif
     {
-    __builtin_amdgcn_s_setprio(1);
+    if constexpr (!UD_ATTN_NOPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
       const char* vrow = vs + (db * 32 + ql) * 128;      // (row >> 1) & 7 == kswz for row = db*32 + ql
@@ -311,15 +388,31 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const UdAttention p,
             asm volatile("" ::"v"(vf), "v"(pf[kb][t]));
             o[db][kb * 2 + t] += (float)vf[0];
           } else {
+#if UD_ATTN_OAGPR
+            // s_nop 1: the packed P registers may have been written by the VALU instruction just before (VALU write -> MFMA SrcA/B hazard)
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(o[db]) : "v"(vf), "v"(pf[kb][t]));
+#else
             o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][t], o[db], 0, 0, 0);
+#endif
           }
         }
     }
-    __builtin_amdgcn_s_setprio(0);
+    if constexpr (!UD_ATTN_NOPRIO) __builtin_amdgcn_s_setprio(0);
     }
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt+1 landed; the barrier covers the others'
-    if constexpr (!(ABL & 16)) __syncthreads();
+    if constexpr (NST == 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt+1 landed; the barrier covers the others'
+      if constexpr (!(ABL & 16)) __syncthreads();
+    } else {
+      // deeper ring: tile kt+1 was issued NST-2 tiles ago; leave the younger tiles' DMAs (2 * PW instructions each) in flight.  Raw barrier:
+      // __syncthreads() would make the compiler drain vmcnt to 0 (an LDS-DMA is a pending LDS write to its fence).
+      if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((NST - 2) * 2 * PW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
+    }
+    st_cur = st_cur + 1 == NST ? 0 : st_cur + 1;
+    st_new = st_new + 1 == NST ? 0 : st_new + 1;
   }
 
   const float l_tot = l_i + __shfl_xor(l_i, 32, 64);

@@ -750,10 +750,20 @@ __device__ __forceinline__ void ud_interleave_reads() {
 // weights sit gW apart) run as ONE tile list over G * M rows: the group of a tile is m0 / grp_rows (grp_rows % tile height == 0, so no
 // tile straddles two groups) and only moves the W rows and the bias; with gA == 0 all groups read the same A.  The 128-row kernel runs
 // such problems as blockIdx.z slices at ~480 TFLOP/s (K = 512: four short K loops per CU); here they share the persistent tile stream.
-template <int MH, int EPI, int AMODE, bool BAL = false, bool LNC = false, bool GRP = false>
+// W3 (round 4; dense A, tile list, K >= 128): the WEIGHT operand gets a 3-deep LDS ring and is fetched TWO K-tiles ahead, the activation
+// operand keeps its 2-deep ring (192-row tiles: 2 x 24 KB + 3 x 32 KB = 144 KB).  In the step every layer's weights are cold -- last
+// touched one step = ~3 GB of traffic ago, so each of the 8 XCDs pulls its W panels from HBM -- while the activations were written by the
+// previous launch and mostly sit in the Infinity Cache; with everything one K-tile (~1.3 us) ahead the HBM round trip of the weight
+// lines was exposed in every K-tile (tools/r4_insitu.py: fc2 95 us with warm operands, 107 us when only the weights rotate through 24
+// layers, 114 us in the step).  The end-of-K-tile wait becomes a COUNTED vmcnt(4): A(kt+1) and W(kt+1) have landed, the four DMA
+// instructions of W(kt+2) stay in flight across the barrier (loads retire in order among themselves; stores only make the count
+// conservative).  The stream stays continuous across the workgroup's tiles: W runs two K-tiles ahead over the tile boundary as well.
+template <int MH, int EPI, int AMODE, bool BAL = false, bool LNC = false, bool GRP = false, bool W3 = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using C = BigCfg<MH>;
+  static_assert(!W3 || (AMODE == UD_A_DENSE && !BAL && !GRP), "W3: dense A, tile list");
+  constexpr int RING_BYTES = W3 ? 2 * C::A_BYTES + 3 * 32768 : 2 * C::STAGE;     // LDS behind the operand ring: LNC tables / ticket flag
   static_assert(!LNC || (AMODE == UD_A_DENSE && (EPI == UD_EPI_F16 || EPI == UD_EPI_QKV)), "LayerNorm-folded consumer: dense A, fp16 outputs");
   constexpr int BM = C::BM;
   constexpr int TM = 2 * MH;
@@ -794,7 +804,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   unsigned cyx[C::A_LOADS];       // conv: (y << 16) | x of the row's pixel (y = 0x4000 for rows past the image: always padding)
   unsigned pb[4];
   const float inv_cc = (AMODE != UD_A_DENSE) ? 1.0f / (float)(p.Cin >> 3) : 0.0f;
-  auto setup = [&](int m0, int n0, int mh) {
+  auto setupA = [&](int m0, int mh) {
     int grp = 0;
     if constexpr (GRP) grp = m0 / p.grp_rows;
 #pragma unroll
@@ -815,6 +825,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
         cyx[i] = pp < p.Himg * p.Wimg ? ((unsigned)y << 16) | (unsigned)(pp - y * p.Wimg) : 0x40000000u;
       }
     }
+  };
+  auto setupB = [&](int m0, int n0) {
+    int grp = 0;
+    if constexpr (GRP) grp = m0 / p.grp_rows;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int n = n0 + lrow + 64 * i;
@@ -823,11 +837,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
       if constexpr (GRP) pb[i] += (unsigned)grp * (unsigned)p.gW * 2u;
     }
   };
+  auto setup = [&](int m0, int n0, int mh) {
+    setupA(m0, mh);
+    setupB(m0, n0);
+  };
   // split-fp16 products by K concatenation (UdGemm.a_wrap / w_wrap): the K index wraps around once inside the narrower operand
   const int a_wt = p.a_wrap > 0 ? (AMODE == UD_A_DENSE ? p.a_wrap >> 6 : p.a_wrap) : 0x7fffffff;
   const int w_wt = p.w_wrap > 0 ? p.w_wrap >> 6 : 0x7fffffff;
-  auto issue = [&](int kt, int stg, int mh) {
-    char* sb = smem + stg * C::STAGE + wv * 1024;
+  // LDS address of ring slot `stg` of either operand (W3: separate rings, A 2-deep then W 3-deep; else [A | W] per stage)
+  auto a_stage = [&](int stg) -> char* { return smem + stg * (W3 ? C::A_BYTES : C::STAGE); };
+  auto b_stage = [&](int stg) -> char* { return W3 ? smem + 2 * C::A_BYTES + stg * 32768 : smem + stg * C::STAGE + C::A_BYTES; };
+  auto issueA = [&](int kt, int stg, int mh) {
+    char* sb = a_stage(stg) + wv * 1024;
     if constexpr (AMODE == UD_A_DENSE) {
       const int ka = kt >= a_wt ? kt - a_wt : kt;
 #pragma unroll
@@ -852,27 +873,33 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
         ud_bufl16(rA, off, 0, sb + i * 8192);
       }
     }
-    {
-      const int kb = kt >= w_wt ? kt - w_wt : kt;
+  };
+  auto issueB = [&](int kt, int stg) {
+    char* sb = b_stage(stg) + wv * 1024;
+    const int kb = kt >= w_wt ? kt - w_wt : kt;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) ud_bufl16(rW, pb[i], kb * 128, sb + C::A_BYTES + i * 8192);
-    }
+    for (int i = 0; i < 4; ++i) ud_bufl16(rW, pb[i], kb * 128, sb + i * 8192);
+  };
+  auto issue = [&](int kt, int stg, int mh) {
+    issueA(kt, stg, mh);
+    issueB(kt, stg);
   };
 
   // ---------------- fragment read offsets inside a stage: row-major [row][64 halves], chunk index swizzled by (row >> 1) & 7
   const int fswz = (lane & 15) >> 1;
   const int c0 = ((lane >> 4) ^ fswz) << 4;          // k-step 0
   const int c1 = ((4 + (lane >> 4)) ^ fswz) << 4;    // k-step 1
-  const int b_off = C::A_BYTES + (wn * 64 + (lane & 15)) * 128;
+  const int b_off = (wn * 64 + (lane & 15)) * 128;     // inside a W stage
 
   f32x4 acc[TM][4];
   half8 a0[MH], a1[MH], b0[4], b1[4];
-  int stg = 0;                                 // ring stage holding the K-tile about to be multiplied
+  int stg = 0;                                 // ring stage holding the K-tile about to be multiplied (W3: of the A ring)
+  int stgb = 0;                                // W3: the same for the 3-deep W ring
 
   constexpr bool ACC_EPI = (EPI == UD_EPI_F32);        // `out (+)= ...`: old values are preloaded into the accumulators
 
   // ---------------- LNC: (rstd, -mean) of the rows of EVERY tile this workgroup will visit, parked in LDS once at kernel start
-  float* const lds_rstd = (float*)(smem + 2 * C::STAGE);        // [LNC_TILES][256] rstd, then [LNC_TILES][256] -mean * rstd
+  float* const lds_rstd = (float*)(smem + RING_BYTES);        // [LNC_TILES][256] rstd, then [LNC_TILES][256] -mean * rstd
   float* const lds_nm = lds_rstd + UD_LNC_PLANE;
   int tl = 0;                                                    // local index of the current tile = its table
 
@@ -922,6 +949,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   tile_at(t, m0, n0, mhc);
   setup(m0, n0, mhc);
   issue(0, 0, mhc);
+  if constexpr (W3) issueB(1, 1);                  // W runs two K-tiles ahead (K >= 128 is a launch condition)
   // fill a statistics table by LDS-DMA (4 bytes per lane, lane-linear destination = 64 consecutive rows of one plane): no VGPR holds the
   // values and nothing waits here -- they land with the tile's first operand K-tile.  (Loading them through registers before the
   // first barrier cost 10-15 us per launch.)
@@ -977,27 +1005,52 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
       first = false;
     }
     {  // first fragments of this tile (its K-tile 0 landed before the barrier that ended the previous tile's K loop)
-      const char* sb0 = smem + stg * C::STAGE;
+      const char* sa0 = a_stage(stg);
+      const char* sb0 = b_stage(W3 ? stgb : stg);
 #pragma unroll
-      for (int i = 0; i < MHC; ++i) a0[i] = *(const half8*)(sb0 + a_off + i * 2048 + c0);
+      for (int i = 0; i < MHC; ++i) a0[i] = *(const half8*)(sa0 + a_off + i * 2048 + c0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) b0[j] = *(const half8*)(sb0 + b_off + j * 2048 + c0);
     }
 
     // ---- one K-tile: SW = operand order, LAST = last K-tile of the output tile (prefetches the next tile's first K-tile
     //      instead of this tile's next one)
-    auto ktile = [&](auto SW, auto LASTT, int kt) {
+    // PH (W3 only): 0 = a K-tile with two more to come, 1 = the second-last one (its W prefetch belongs to the next tile), 2 = the last
+    auto ktile = [&](auto SW, auto LASTT, int kt, auto PHT) {
       constexpr bool SWAP = decltype(SW)::value;
       constexpr bool LAST = decltype(LASTT)::value;
-      const char* sb = smem + stg * C::STAGE;
-      const char* sbn = smem + (stg ^ 1) * C::STAGE;
+      constexpr int PH = decltype(PHT)::value;
+      const int stgb1 = stgb == 2 ? 0 : stgb + 1, stgb2 = stgb == 0 ? 2 : stgb - 1;     // W3: slots of W(kt+1), W(kt+2)
+      const char* sa = a_stage(stg);
+      const char* sb = b_stage(W3 ? stgb : stg);
+      const char* san = a_stage(stg ^ 1);
+      const char* sbn = b_stage(W3 ? stgb1 : stg ^ 1);
 #define UD_MFMA_HALF(ROW0, AF, BF)                                                                               \
   _Pragma("unroll") for (int i = 0; i < MHC; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) {               \
     if constexpr (SWAP) acc[ROW0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[j], AF[i], acc[ROW0 + i][j], 0, 0, 0); \
     else acc[ROW0 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AF[i], BF[j], acc[ROW0 + i][j], 0, 0, 0);   \
   }
       // ---- phase (k0, m-half 0): DMA of the whole next K-tile goes out first
-      if constexpr (LAST) {
+      if constexpr (W3) {
+        // issue order matters for the counted wait below: everything that must have landed by the end of this K-tile first, W(kt+2) last
+        if constexpr (PH == 2) {
+          if (has_next) {
+            if constexpr (LNC) stats_dma(m0n, mhn, (tl + 1) & 1);
+            setupA(m0n, mhn);
+            issueA(0, stg ^ 1, mhn);
+            issueB(1, stgb2);                                          // pb already points at the next tile (set in the second-last K-tile)
+          }
+        } else if constexpr (PH == 1) {
+          issueA(kt + 1, stg ^ 1, MHC);
+          if (has_next) {
+            setupB(m0n, n0n);
+            issueB(0, stgb2);
+          }
+        } else {
+          issueA(kt + 1, stg ^ 1, MHC);
+          issueB(kt + 2, stgb2);
+        }
+      } else if constexpr (LAST) {
         if (has_next) {
           setup(m0n, n0n, mhn);
           issue(0, stg ^ 1, mhn);
@@ -1007,13 +1060,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
         issue(kt + 1, stg ^ 1, MHC);
       }
 #pragma unroll
-      for (int i = 0; i < MHC; ++i) a1[i] = *(const half8*)(sb + a_off + (MHC + i) * 2048 + c0);
+      for (int i = 0; i < MHC; ++i) a1[i] = *(const half8*)(sa + a_off + (MHC + i) * 2048 + c0);
       UD_MFMA_HALF(0, a0, b0)
       ud_interleave_reads<MHC, 4 * MHC>();
       __builtin_amdgcn_sched_barrier(0);
       // ---- phase (k0, m-half 1)
 #pragma unroll
-      for (int i = 0; i < MHC; ++i) a0[i] = *(const half8*)(sb + a_off + i * 2048 + c1);
+      for (int i = 0; i < MHC; ++i) a0[i] = *(const half8*)(sa + a_off + i * 2048 + c1);
 #pragma unroll
       for (int j = 0; j < 4; ++j) b1[j] = *(const half8*)(sb + b_off + j * 2048 + c1);
       UD_MFMA_HALF(MHC, a1, b0)
@@ -1021,17 +1074,23 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
       __builtin_amdgcn_sched_barrier(0);
       // ---- phase (k1, m-half 0)
 #pragma unroll
-      for (int i = 0; i < MHC; ++i) a1[i] = *(const half8*)(sb + a_off + (MHC + i) * 2048 + c1);
+      for (int i = 0; i < MHC; ++i) a1[i] = *(const half8*)(sa + a_off + (MHC + i) * 2048 + c1);
       UD_MFMA_HALF(0, a0, b1)
       ud_interleave_reads<MHC, 4 * MHC>();
       __builtin_amdgcn_sched_barrier(0);
       // ---- phase (k1, m-half 1): next K-tile must have landed for every wave before anyone reads it
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      if constexpr (W3) {
+        // A(kt+1) and W(kt+1) landed; the 4 DMA instructions of W(kt+2), issued last, may stay in flight (none were issued: wait for all)
+        if (PH == 0 || has_next) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if constexpr (!LAST) {                   // (the next TILE's first fragments are read after the epilogue: 32 registers less there)
 #pragma unroll
-        for (int i = 0; i < MHC; ++i) a0[i] = *(const half8*)(sbn + a_off + i * 2048 + c0);
+        for (int i = 0; i < MHC; ++i) a0[i] = *(const half8*)(san + a_off + i * 2048 + c0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) b0[j] = *(const half8*)(sbn + b_off + j * 2048 + c0);
       }
@@ -1040,11 +1099,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
       __builtin_amdgcn_sched_barrier(0);
 #undef UD_MFMA_HALF
       stg ^= 1;
+      if constexpr (W3) stgb = stgb1;
     };
 
     auto kloop = [&](auto SW) {
-      for (int kt = 0; kt < nk - 1; ++kt) ktile(SW, BoolTag<false>{}, kt);
-      ktile(SW, BoolTag<true>{}, nk - 1);
+      if constexpr (W3) {
+        for (int kt = 0; kt < nk - 2; ++kt) ktile(SW, BoolTag<false>{}, kt, IntTag<0>{});
+        ktile(SW, BoolTag<false>{}, nk - 2, IntTag<1>{});
+        ktile(SW, BoolTag<true>{}, nk - 1, IntTag<2>{});
+      } else {
+        for (int kt = 0; kt < nk - 1; ++kt) ktile(SW, BoolTag<false>{}, kt, IntTag<0>{});
+        ktile(SW, BoolTag<true>{}, nk - 1, IntTag<0>{});
+      }
     };
     UD_STAMP(1);
     if constexpr (EPI == UD_EPI_QKV) {
@@ -1194,7 +1260,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (tid == 0) ticket_val = atomicAdd(p.row_stats_ticket + m0 / BMC, 1u);
+            if (tid == 0) ticket_val = atomicInc(p.row_stats_ticket + m0 / BMC, (unsigned)tiles_n - 1u);
             ticket_taken = true;
           }
         }
@@ -1310,19 +1376,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
       if (p.row_stats_final) {
         // ---- LayerNorm statistics of the rows of this row tile: the LAST of the tiles_n workgroups to get here reduces the partial sums
         // of all column tiles (ascending slab order: one summation order per row) -- no separate reduction launch (~7.5 us each, 47
-        // per step).  Tickets count arrivals per row tile and are never reset: tiles_n arrivals per launch.
-        unsigned* flag = (unsigned*)(smem + 2 * C::STAGE);
+        // per step).  A ticket counts the arrivals of one row tile and wraps to 0 with the last one (atomicInc with bound tiles_n - 1):
+        // every completed launch leaves the set at zero, whatever tiles_n is and however often the plan is replayed.
+        unsigned* flag = (unsigned*)(smem + RING_BYTES);
         if (ticket_taken) {                       // straight-line epilogue: partial sums and ticket went out ahead of the row stores
           if (tid == 0) *flag = ticket_val;
         } else {                                  // edge tiles: after the stores
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
-          if (tid == 0) *flag = atomicAdd(p.row_stats_ticket + m0 / BMC, 1u);
+          if (tid == 0) *flag = atomicInc(p.row_stats_ticket + m0 / BMC, (unsigned)tiles_n - 1u);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const unsigned arrived = *flag;
-        if (arrived % (unsigned)tiles_n == (unsigned)tiles_n - 1u) {
+        if (arrived == (unsigned)tiles_n - 1u) {
           const int slabs = p.N >> 6;
           if (tid < BMC && m0 + tid < p.M) {
             const float* src = p.row_stats_out + (size_t)(m0 + tid) * slabs * 2;
@@ -1371,10 +1438,32 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   }
 }
 
+// W3 form of the 192-row tile list (3-deep weight ring, see the kernel): dense problems with at least two K-tiles.  UD_GEMM_W3=0 in the
+// environment keeps the 2-deep form (A/B runs; read once per process).
+inline bool w3_enabled() {
+  static const int on = [] { const char* e = getenv("UD_GEMM_W3"); return (e && e[0] == '0') ? 0 : 1; }();
+  return on != 0;
+}
+
 template <int MH, int EPI, int AMODE, bool LNC = false, bool GRP = false>
 int launch256(const UdGemm& d, hipStream_t s) {
   constexpr int BM = BigCfg<MH>::BM;
   const int tiles = ((d.N + 255) >> 8) * ((d.M + BM - 1) / BM);
+  if constexpr (MH == 3 && AMODE == UD_A_DENSE && !GRP) {
+    if (d.K >= 128 && d.tile_hint != 9 && w3_enabled()) {
+      const int lds3 = 2 * BigCfg<MH>::A_BYTES + 3 * 32768 + (LNC ? LNC_LDS : 0) + (EPI == UD_EPI_F32 ? 64 : 0);
+      static bool attr3_set[UD_MAX_DEVICES];
+      if (!ud_attr_once(attr3_set)) {
+        if (hipFuncSetAttribute((const void*)gemm256_kernel<MH, EPI, AMODE, false, LNC, GRP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds3) != hipSuccess) {
+          ud_set_error("ud_gemm_f16: cannot reserve the LDS rings of the large-tile kernel (3-deep weight ring)");
+          return UD_ERR_LAUNCH;
+        }
+      }
+      hipLaunchKernelGGL((gemm256_kernel<MH, EPI, AMODE, false, LNC, GRP, true>), dim3(tiles < 256 ? tiles : 256), dim3(512), lds3, s, d);
+      UD_CHECK_LAUNCH("ud_gemm_f16 (large tile, 3-deep weight ring) launch");
+      return UD_OK;
+    }
+  }
   const int lds = 2 * BigCfg<MH>::STAGE + (LNC ? LNC_LDS : 0) + (EPI == UD_EPI_F32 ? 64 : 0);
   static bool attr_set[UD_MAX_DEVICES];
   if (!ud_attr_once(attr_set)) {
@@ -1437,9 +1526,9 @@ inline int pick_tiles(const UdGemm& d) {
     if (a_bytes >= 2147483648.0 || 2.0 * d.N * d.ldw >= 2147483648.0) return 0;
   }
   if (d.epi == UD_EPI_QKV && (d.vsplit & 255)) return 0;
-  if (d.tile_hint == 1 || (d.tile_hint >= 5 && d.tile_hint != 8)) return 0;
+  if (d.tile_hint == 1 || (d.tile_hint >= 5 && d.tile_hint != 8 && d.tile_hint != 9)) return 0;
   if (d.tile_hint == 2) return 4;
-  if (d.tile_hint == 3) return 3;
+  if (d.tile_hint == 3 || d.tile_hint == 9) return 3;      // 9: 192-row tile list with the 2-deep weight ring (A/B and tests of the 3-deep form)
   const bool bal_ok = d.amode == UD_A_DENSE && (d.epi == UD_EPI_F16 || d.epi == UD_EPI_F32 || d.epi == UD_EPI_QKV) && bal_cpc(d) > 0;
   if (d.tile_hint == 8 && bal_ok) return 8;
   const double kk = (double)d.K / 1024.0;
@@ -1854,8 +1943,9 @@ extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
       ud_set_error("ud_gemm_f16: row_stats_out needs the fp32 epilogue, N % 64 == 0 and 64-column wave tiles (N > 64, no groups)");
       return UD_ERR_UNSUPPORTED;
     }
-    if (d.row_stats_final && (bt == 0 || !d.row_stats_ticket || d.ln_D <= 0 || d.N > 1024 || d.groups > 1)) {
-      ud_set_error("ud_gemm_f16: row_stats_final (in-kernel reduction of the row statistics) needs the large-tile kernel, a ticket buffer, ln_D and N <= 1024");
+    if (d.row_stats_final && (bt == 0 || !d.row_stats_ticket || d.ln_D <= 0 || d.N > 1024 || (d.N & 127) || d.groups > 1)) {
+      ud_set_error("ud_gemm_f16: row_stats_final (in-kernel reduction of the row statistics) needs the large-tile kernel, a ticket buffer, ln_D, "
+                   "N <= 1024 and N % 128 == 0 (the finalizer reads the 64-column slabs in pairs)");
       return UD_ERR_UNSUPPORTED;
     }
   } else if (d.row_stats_final) {
@@ -1953,7 +2043,8 @@ extern "C" int ud_gemm_pick(const UdGemm* desc) {
   }
   if (conv_tile_ok(d) && (d.epi == UD_EPI_HEAD || d.epi == UD_EPI_F16)) return 5;
   if (d.epi != UD_EPI_HEAD) {
-    const int bt = pick_tiles(d);
+    int bt = pick_tiles(d);
+    if (bt == 8 && d.row_stats_final) bt = 3;          // launch_big: the in-kernel statistics reduction runs on the 192-row tile list
     if (bt) return bt + (d.row_stats_in ? 16 : 0);
   }
   if (d.N > 64 && d.epi != UD_EPI_D2S) {

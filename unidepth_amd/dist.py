@@ -5,6 +5,7 @@ variable-length gathers (unidepth/utils/distributed.py:153-176: size all-gather 
 followed for uneven shards."""
 from __future__ import annotations
 
+import os
 from typing import Dict, Iterable, List, Optional, Tuple
 
 import torch
@@ -201,10 +202,18 @@ def infer_mixed(model, images: List[torch.Tensor], cameras: Optional[List[Option
     if inflight > 1 and hasattr(model, "_plans") and images and images[0].is_cuda:
         from .pipeline import InferPipeline
         pipe = InferPipeline(model, depth=inflight)
+    prev_max_plans = getattr(model, "max_plans", None)
     if hasattr(model, "reserve_plans"):
-        # every (micro-batch size, shape, camera mode) of this rank may land on every pipeline slot: keep the whole cycle cached
+        # every (micro-batch size, shape, camera mode) of this rank may land on every pipeline slot: keep the whole cycle cached for the
+        # duration of THIS call, bounded by UNIDEPTH_MIXED_MAX_PLANS (a list with dozens of distinct shapes must not pin dozens of ~2.6 GB
+        # plans); the previous bound comes back when the call returns (_restore_plans) and the LRU evicts down to it
         sigs = {(len(idx), s, bool(cameras is not None and any(cameras[i] is not None for i in idx))) for (s, idx), r in zip(micro, owner) if r == rank}
-        model.reserve_plans(len(sigs) * max(1, inflight) + 2)
+        cap = int(os.environ.get("UNIDEPTH_MIXED_MAX_PLANS", "24"))
+        model.reserve_plans(min(len(sigs) * max(1, inflight) + 2, max(cap, prev_max_plans or 0)))
+
+    def _restore_plans():
+        if prev_max_plans is not None and hasattr(model, "trim_plans"):
+            model.trim_plans(prev_max_plans)
     submitted = []
     for (s, idx), r in zip(micro, owner):
         if r != rank:
@@ -227,6 +236,7 @@ def infer_mixed(model, images: List[torch.Tensor], cameras: Optional[List[Option
                 results[i] = {k: out[k][b] for k in keys}
     for out in submitted:                              # only now: a wait on the caller's stream would order later submissions behind it
         pipe.wait(out)
+    _restore_plans()
     if not distributed:
         return results  # type: ignore[return-value]
     for s in sorted({m[0] for m in micro}):

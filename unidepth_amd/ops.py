@@ -105,8 +105,11 @@ class Program:
         # algorithmic reduction length: a split-fp16 product (a_wrap / w_wrap: K concatenation, include/unidepth_hip.h) multiplies
         # every (m, n, k) of the layer two or three times -- that is the price of the precision, not additional algorithmic work
         k_alg = kw["K"]
-        if kw.get("a_wrap") or kw.get("w_wrap"):
-            k_alg = kw["K"] * kw["a_wrap"] // kw["Cin"] if kw.get("amode", 0) else (kw.get("a_wrap") or kw.get("w_wrap"))
+        if kw.get("a_wrap") or kw.get("w_wrap"):      # (a conv amode with w_wrap is rejected by the C side: leave k_alg alone and let it say so)
+            if not kw.get("amode", 0):
+                k_alg = kw.get("a_wrap") or kw.get("w_wrap")
+            elif kw.get("a_wrap") and kw.get("Cin"):
+                k_alg = kw["K"] * kw["a_wrap"] // kw["Cin"]
         tag, flops = kw.pop("tag", None), kw.pop("flops", 2.0 * kw["M"] * n * k_alg * g)
         tiles = -(-kw["M"] // 128) * -(-n // 128)
         if (g == 1 and kw.get("amode", 0) == UD_A_DENSE and kw.get("epi", 0) in (UD_EPI_F16, UD_EPI_F32) and tiles <= 128

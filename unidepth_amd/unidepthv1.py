@@ -19,6 +19,7 @@ from typing import List, Optional
 import torch
 
 from . import ops
+from .module import EngineModule
 from .ops import UD_ACT_GELU, UD_EPI_F16, UD_EPI_F32
 
 CONVNEXT = {"convnext_large": dict(depths=(3, 3, 27, 3), dims=(192, 384, 768, 1536))}     # models/encoder.py:127-136
@@ -428,10 +429,12 @@ class _EncPlanViT:
         self.keep = [x, xn, qk, vt, ao, hid, patches, pos, cls_row]
 
 
-class UniDepthV1:
-    """Engine counterpart of the reference's UniDepthV1 (unidepthv1.py:101).  See the module docstring for what runs today."""
+class UniDepthV1(EngineModule):
+    """Engine counterpart of the reference's UniDepthV1 (unidepthv1.py:97-103: nn.Module + PyTorchModelHubMixin).  See the module docstring for
+    what runs today; the nn.Module surface is unidepth_amd/module.py."""
 
     def __init__(self, config: dict, eps: float = 1e-6, **kwargs):
+        super().__init__()
         self.config = config
         name = config["model"]["pixel_encoder"]["name"]
         if name in VIT:                              # DINOv2 ViT-L/14 (config_v1_vitl14): levels = block ranges ending at output_idx
@@ -455,7 +458,6 @@ class UniDepthV1:
         self.image_shape = list(config["data"]["image_shape"])                         # unidepthv1.py:444
         self._sd = None
         self._w = None
-        self._device = torch.device("cpu")
         self._plans = OrderedDict()                 # LRU: a plan owns all activation buffers of its signature (same policy as UniDepthV2)
         self.max_plans = max(1, int(os.environ.get("UNIDEPTH_MAX_PLANS", "4")))
 
@@ -477,13 +479,6 @@ class UniDepthV1:
             sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu", weights_only=True)
         return model.load_state_dict(sd)
 
-    def save_pretrained(self, path: str):
-        from safetensors.torch import save_file
-        os.makedirs(path, exist_ok=True)
-        with open(os.path.join(path, "config.json"), "w") as f:
-            json.dump(self.config, f)
-        save_file({k: v.contiguous() for k, v in self._sd.items()}, os.path.join(path, "model.safetensors"))
-
     def load_state_dict(self, state_dict: dict, strict: bool = False):
         if "model" in state_dict and not torch.is_tensor(state_dict["model"]):
             state_dict = state_dict["model"]                                            # unidepthv1.py:381-385
@@ -492,28 +487,9 @@ class UniDepthV1:
         self._plans.clear()
         return self
 
-    def state_dict(self):
-        return dict(self._sd)
-
-    @property
-    def device(self):
-        return self._device
-
-    def to(self, device):
-        device = torch.device(device)
-        if device.type == "cuda" and device.index is None:
-            device = torch.device("cuda", torch.cuda.current_device())
-        if device != self._device:
-            self._device = device
-            self._w = None
-            self._plans.clear()
-        return self
-
-    def cuda(self):
-        return self.to("cuda")
-
-    def eval(self):
-        return self
+    def _move(self, device):          # EngineModule.to(): packed weights and plans belong to a device
+        self._w = None
+        self._plans.clear()
 
     def _ensure_packed(self):
         if self._device.type != "cuda":

@@ -28,6 +28,7 @@ from .ops import (UD_A_CONV3_REFLECT, UD_A_CONV3_REFLECT_UP, UD_A_CONV3_ZERO, UD
 from .cameras import GT_OPENCV, GT_PINHOLE, as_camera
 
 GT_GIVEN_RAYS = 15          # plan tag: the ray map itself is supplied (pixel_decoder seam, decoder.py:400 `rays_gt`)
+from .module import EngineModule
 from .weights import arch_of, pack
 
 IMAGENET_DATASET_MEAN = (0.485, 0.456, 0.406)      # unidepth/utils/constants.py:12
@@ -128,10 +129,19 @@ class _Plan:
         P.fill_rows(x, cls_row, B, Np, 0, D, D)
         tap("tokens0", lambda: x.view(B, Np, D)[:, :N].clone())                 # cls + patches + pos_embed (dinov2.py:306-322)
         xn = z(M, D)
-        qk = z(M, 2 * D)
         vt = z(B, heads, 64, Nkp)
-        ao = z(M, D)
         hid = z(M, 4 * D)
+        # Q|K and the attention output live inside `hid`: between fc2 of block i and fc1 of block i+1 the hidden activations are dead, and
+        # q|k / ao are dead while fc1 / fc2 run.  The block's working set drops from 272 MB to 204 MB at bs = 8 (ViT-L) -- under the 256 MB
+        # Infinity Cache, so what one launch writes the next one reads on-die (tools/r4_insitu.py: the step's launches ran 36 us per block
+        # behind the same launches on warm operands).  V^T keeps its own buffer: its pad columns must stay zero.  UNIDEPTH_ALIAS=0: separate.
+        if os.environ.get("UNIDEPTH_ALIAS", "1") != "0":
+            flat = hid.view(-1)
+            qk = flat[: M * 2 * D].view(M, 2 * D)
+            ao = flat[M * 2 * D: M * 3 * D].view(M, D)
+        else:
+            qk = z(M, 2 * D)
+            ao = z(M, D)
         featn_all = z(4, B * hwp, D)                                  # stacked: the 4 levels are processed by grouped launches
         featn = [featn_all[j] for j in range(4)]
         clsn = [z(_rup(B, 8), D, dtype=f32) for _ in range(4)]       # final-LN'd cls tokens stay fp32: they feed the fp32 camera head
@@ -391,23 +401,22 @@ class _Plan:
         ops.check(ops.lib.ud_finalize_outputs(C.byref(d), ops.cur_stream()), "ud_finalize_outputs")
 
 
-class UniDepthV2:
-    """Drop-in for the reference class (unidepthv2.py:111): from_pretrained / to / eval / infer, attributes
-    `resolution_level`, `interpolation_mode`, `shape_constraints`, `device`."""
+class UniDepthV2(EngineModule):
+    """Drop-in for the reference class (unidepthv2.py:111-117: nn.Module + PyTorchModelHubMixin): from_pretrained / to / eval / infer,
+    attributes `resolution_level`, `interpolation_mode`, `shape_constraints`, `device`; the nn.Module surface is unidepth_amd/module.py."""
 
     def __init__(self, config: dict, eps: float = 1e-6, **kwargs):
+        super().__init__()
         self.config = config
         self._arch = arch_of(config)
         self.shape_constraints = config["data"]["augmentations"]["shape_constraints"]   # unidepthv2.py:459
         self.interpolation_mode = "bilinear"                                            # unidepthv2.py:460
         self._sd = None
         self._w = None
-        self._device = torch.device("cpu")
         self._plans: "collections.OrderedDict" = collections.OrderedDict()
         self.max_plans = int(os.environ.get("UNIDEPTH_MAX_PLANS", "6"))   # LRU bound on cached (batch, shape, camera, slot) plans
         self._pos_cache: dict = {}
         self.use_graph = False
-        self.training = False
 
     # ---- checkpoint I/O (HF mixin layout: config.json + model.safetensors / pytorch_model.bin) ----
     @classmethod
@@ -427,13 +436,6 @@ class UniDepthV2:
             sd = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu", weights_only=True)
         model.load_state_dict(sd)
         return model
-
-    def save_pretrained(self, path: str):
-        from safetensors.torch import save_file
-        os.makedirs(path, exist_ok=True)
-        with open(os.path.join(path, "config.json"), "w") as f:
-            json.dump(self.config, f)
-        save_file({k: v.contiguous() for k, v in self._sd.items()}, os.path.join(path, "model.safetensors"))
 
     def load_state_dict(self, state_dict: dict, strict: bool = False):
         if "model" in state_dict and not torch.is_tensor(state_dict["model"]):
@@ -455,33 +457,23 @@ class UniDepthV2:
         shapes x camera modes x pipeline slots); an LRU smaller than the cycle would rebuild a ~2.6 GB plan on every call."""
         self.max_plans = max(self.max_plans, int(n))
 
-    def state_dict(self):
-        return dict(self._sd)
+    def trim_plans(self, n: int):
+        """Set the LRU bound back to `n` and evict least-recently-used plans down to it (dist.infer_mixed after its call: the outputs it
+        returned are fresh tensors, no plan buffer is referenced by them)."""
+        self.max_plans = max(1, int(n))
+        if len(self._plans) > self.max_plans:
+            if self._device.type == "cuda":
+                torch.cuda.synchronize(self._device)      # evicted plans' programs may still be queued on pipeline streams
+            while len(self._plans) > self.max_plans:
+                self._plans.popitem(last=False)
 
     def load_pretrained(self, model_file):
         return self.load_state_dict(torch.load(model_file, map_location="cpu", weights_only=False))
 
-    # ---- nn.Module-like plumbing ----
-    @property
-    def device(self):
-        return self._device
-
-    def to(self, device):
-        device = torch.device(device)
-        if device.type == "cuda" and device.index is None:
-            device = torch.device("cuda", torch.cuda.current_device())
-        if device != self._device:
-            self._device = device
-            self._w = None
-            self._plans.clear()
-            self._pos_cache.clear()
-        return self
-
-    def cuda(self):
-        return self.to("cuda")
-
-    def eval(self):
-        return self
+    def _move(self, device):          # EngineModule.to(): packed weights, plans and resampled position embeddings belong to a device
+        self._w = None
+        self._plans.clear()
+        self._pos_cache.clear()
 
     def _ensure_packed(self):
         if self._device.type != "cuda":
