@@ -42,6 +42,36 @@
 #ifndef UD_ATTN_NOMAX
 #define UD_ATTN_NOMAX 0
 #endif
+#ifndef UD_ATTN_UNROLL2
+#define UD_ATTN_UNROLL2 0
+#endif
+#ifndef UD_ATTN_MFMASUM
+#define UD_ATTN_MFMASUM 0          // NOMAX only: row sums by v_mfma_f32_4x4x4_16b_f16 (A = ones) instead of 32 v_add_f32 per tile
+#endif
+#ifndef UD_ATTN_MINW
+#define UD_ATTN_MINW 1          // minimum waves per SIMD promised to the register allocator (4 = cap the kernel at 128 VGPRs)
+#endif
+
+#ifndef UD_ATTN_TRACE
+#define UD_ATTN_TRACE 0
+#endif
+#if UD_ATTN_TRACE
+// tools build only (tools/r4_attn_trace.py): per-wave sums of the shader-clock time between seven points of the tile loop, added to
+// ud_attn_trace_ptr[0..5] (+ [6] = wave-tiles counted) at the end of every wave.  s_memtime is an SMEM read, so every stamp also waits for
+// the wave's outstanding LDS reads: the stamped build runs a few percent slower and shows WHERE a tile's time goes, not how long it takes.
+__device__ unsigned long long* ud_attn_trace_ptr = nullptr;
+extern "C" int ud_attn_trace_set(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(ud_attn_trace_ptr), &buf, sizeof(buf)) == hipSuccess ? UD_OK : UD_ERR_LAUNCH;
+}
+#define UD_ATT_STAMP(i)                                        \
+  do {                                                         \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    if (i > 0) tsum[i - 1] += now_ - tprev;                    \
+    tprev = now_;                                              \
+  } while (0)
+#else
+#define UD_ATT_STAMP(i)
+#endif
 
 namespace {
 
@@ -66,7 +96,7 @@ constexpr int STAGE = KS_BYTES + VS_BYTES;
 // running maximum and row sum in `part`; attention_merge_kernel combines the chunks.  For few queries against many keys (the Nystrom
 // kernel_3 product: 128 landmark queries x up to 19200 keys per (image, head) -- one workgroup per pair would walk 300 key tiles alone).
 template <int ABL, int MODE, int NW = 4, bool SPLIT = false>
-__global__ __launch_bounds__(NW * 64) void attention_kernel(const UdAttention p, const float defer_thr) {
+__global__ __launch_bounds__(NW * 64, UD_ATTN_MINW) void attention_kernel(const UdAttention p, const float defer_thr) {
   constexpr int NST = UD_ATTN_NSTAGE;
   __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
   const int tid = threadIdx.x;
@@ -153,12 +183,20 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const UdAttention p,
 
   const int kswz = (ql >> 1) & 7;   // (key >> 1) & 7 for key = kb*32 + ql
   int st_cur = 0, st_new = NST - 1;   // ring slots of tile kt and of the tile issued during it (kt + NST - 1)
-  for (int kt = kt0; kt < kt1; ++kt) {
+#if UD_ATTN_TRACE
+  unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+#endif
+  // UD_ATTN_UNROLL2 (2-deep ring): the tile body is instantiated per ring slot and the loop walks two tiles per iteration, so every LDS
+  // address of a tile is the lane's base + an immediate offset (no per-tile v_add of the slot offset: ~8 VALU instructions per tile)
+  auto tile = [&](const int kt, auto SLOT) {
+    constexpr int CS = decltype(SLOT)::value;               // >= 0: compile-time ring slot of this tile (NST == 2), -1: st_cur / st_new
+    UD_ATT_STAMP(0);
     const bool ahead = kt + NST - 1 < kt1;
     if constexpr (!(ABL & 8)) {
-      if (ahead) issue(kt + NST - 1, st_new);   // every wave passed the barrier that ended tile kt-1, the last reader of that slot
+      if (ahead) issue(kt + NST - 1, CS >= 0 ? (CS ^ 1) : st_new);   // every wave passed the barrier that ended tile kt-1, the last reader of that slot
     }
-    const char* sb = smem + ((ABL & 8) ? 0 : st_cur) * STAGE;
+    const char* sb = smem + ((ABL & 8) ? 0 : (CS >= 0 ? CS : st_cur)) * STAGE;
+    UD_ATT_STAMP(1);                                       // [0] DMA issue
 
     // ---- S^T = K Q^T  (two 32-key blocks), MODE >= 1: minus the running offset m_i
     f32x16 s[2];
@@ -203,50 +241,73 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const UdAttention p,
         for (int r = 0; r < 16; r += 2) mt = fmaxf(fmaxf(mt, s[kb][r]), s[kb][r + 1]);
       return fmaxf(mt, __shfl_xor(mt, 32, 64));
     };
+#if UD_ATTN_TRACE
+    asm volatile("" : "+v"(s[0]), "+v"(s[1]));              // the scores are complete (MFMA results read) before the stamp
+    UD_ATT_STAMP(2);                                       // [1] K fragment reads + Q K^T MFMAs
+#endif
     float mt = 0.0f;
     if constexpr (!NOMAX) mt = rowmax();
     float ls = 0.0f;
     half8 pf[2][2];
     if constexpr (NOMAX) {
-      // optimistic tile: P = exp2(S - m_i) with the offset as it stands; redone with the exact maximum only if a partial row sum says a P
-      // may have left the fp16 range (or on the first tile, where m_i is not yet a maximum of anything)
-      bool slow = kt == kt0;
-      for (;;) {
-        scores();
-        if (slow) {
-          const float mx = rowmax();
-          const float d = kt == kt0 ? mx : fmaxf(mx, 0.0f);
-          m_i += d;
-          if (kt != kt0) {
-            const float alpha = __builtin_amdgcn_exp2f(-d);
-            l_i *= alpha;
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-          }
-#pragma unroll
-          for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] -= d;
-        }
+      // optimistic tile: P = exp2(S - m_i) against the offset as it stands; the tile is redone with its exact maximum (Q K^T again from the
+      // staged K tile, rescale of O and l) only if a lane's partial row sum says a P may have left the fp16 range -- or on the first tile,
+      // where m_i is not yet a maximum of anything.  Straight-line fast path: the redo is a forward branch that rejoins before P V.
+      auto exps = [&]() {
         ls = 0.0f;
+#if UD_ATTN_MFMASUM
+        // row sums on the matrix pipe: v_mfma_f32_4x4x4_16b_f16 with A = ones gives every lane the sum of ITS OWN four B halves (16 blocks
+        // of 4 lanes; D[b][i][j] = sum_k A[b][i][k] B[b][k][j]) -- 8 two-pass MFMAs per tile instead of 32 v_add_f32, and the sum is over
+        // the fp16-ROUNDED probabilities, i.e. exactly what P V multiplies
+        f32x4 la[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const half4 ones4 = {(half_t)1.0f, (half_t)1.0f, (half_t)1.0f, (half_t)1.0f};
+#endif
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-          for (int t = 0; t < 2; ++t)
+          for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
               f32x2 pv;
               pv[0] = __builtin_amdgcn_exp2f(s[kb][t * 8 + e]);
               pv[1] = __builtin_amdgcn_exp2f(s[kb][t * 8 + e + 1]);
+#if !UD_ATTN_MFMASUM
               ls += pv[0] + pv[1];
+#endif
               const half2v ph = __builtin_convertvector(pv, half2v);
               pf[kb][t][e] = ph[0];
               pf[kb][t][e + 1] = ph[1];
             }
-        if (slow || !__any(!(ls <= 32768.0f))) break;      // NaN / inf safe: anything not provably small redoes the tile
-        slow = true;
+#if UD_ATTN_MFMASUM
+            const half4 lo = __builtin_shufflevector(pf[kb][t], pf[kb][t], 0, 1, 2, 3), hi = __builtin_shufflevector(pf[kb][t], pf[kb][t], 4, 5, 6, 7);
+            la[0] = __builtin_amdgcn_mfma_f32_4x4x4f16(ones4, lo, la[0], 0, 0, 0);
+            la[1] = __builtin_amdgcn_mfma_f32_4x4x4f16(ones4, hi, la[1], 0, 0, 0);
+#endif
+          }
+#if UD_ATTN_MFMASUM
+        ls = la[0][0] + la[1][0];
+#endif
+      };
+      scores();
+      exps();
+      if (__builtin_expect(kt == kt0 || __any(!(ls <= 32768.0f)), 0)) {      // NaN / inf safe: anything not provably small redoes the tile
+        scores();
+        const float mx = rowmax();
+        const float d = kt == kt0 ? mx : fmaxf(mx, 0.0f);
+        m_i += d;
+        if (kt != kt0) {
+          const float alpha = __builtin_amdgcn_exp2f(-d);
+          l_i *= alpha;
+#pragma unroll
+          for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[kb][r] -= d;
+        exps();
       }
     } else
     if constexpr (MODE == 0) {
@@ -368,6 +429,10 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const UdAttention p,
     }
 #endif
     l_i += ls;
+#if UD_ATTN_TRACE
+    asm volatile("" : "+v"(pf[0][0]), "+v"(pf[0][1]), "+v"(pf[1][0]), "+v"(pf[1][1]), "+v"(l_i));
+    UD_ATT_STAMP(3);                                       // [2] softmax VALU (max, exchange, exp, sum, pack)
+#endif
 
     // ---- O^T += V^T P^T
     const char* vs = sb + KS_BYTES;
@@ -400,6 +465,13 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const UdAttention p,
     if constexpr (!UD_ATTN_NOPRIO) __builtin_amdgcn_s_setprio(0);
     }
 
+#if UD_ATTN_TRACE
+    UD_ATT_STAMP(4);                                       // [3] V^T fragment reads + P V MFMAs issued (the last MFMAs may still run)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    UD_ATT_STAMP(5);                                       // [4] wait for this wave's DMA pieces of the next tile
+    __builtin_amdgcn_s_barrier();
+    UD_ATT_STAMP(6);                                       // [5] barrier
+#else
     if constexpr (NST == 2) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt+1 landed; the barrier covers the others'
       if constexpr (!(ABL & 16)) __syncthreads();
@@ -411,10 +483,27 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const UdAttention p,
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
     }
+#endif
     st_cur = st_cur + 1 == NST ? 0 : st_cur + 1;
     st_new = st_new + 1 == NST ? 0 : st_new + 1;
+  };
+#if UD_ATTN_UNROLL2
+  static_assert(NST == 2, "UD_ATTN_UNROLL2 needs the 2-deep ring");
+  for (int kt = kt0; kt < kt1; kt += 2) {
+    tile(kt, std::integral_constant<int, 0>{});
+    if (kt + 1 < kt1) tile(kt + 1, std::integral_constant<int, 1>{});
   }
+#else
+  for (int kt = kt0; kt < kt1; ++kt) tile(kt, std::integral_constant<int, -1>{});
+#endif
 
+#if UD_ATTN_TRACE
+  if (ud_attn_trace_ptr && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) atomicAdd(ud_attn_trace_ptr + i, tsum[i]);
+    atomicAdd(ud_attn_trace_ptr + 6, (unsigned long long)(kt1 - kt0));
+  }
+#endif
   const float l_tot = l_i + __shfl_xor(l_i, 32, 64);
   const int qr = q0 + ql;
   if constexpr (SPLIT) {
