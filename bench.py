@@ -442,6 +442,46 @@ def _program_breakdown(torch, P, reps=2):
     return {k: [v[0], v[1], v[2] // reps] for k, v in tot.items()}
 
 
+def latency_bs1(torch, model_vitl, dev):
+    """p50 wall time of ONE bs=1 infer() (all 7 outputs on the device, synchronised per call), eager and graph replay, and whether the two
+    return the same bits.  The program of such a call is ~280 launches of 2-20 us: the host launch loop, not the kernels, paces it."""
+    import statistics
+    from oracle import synth
+    from unidepth_amd import UniDepthV2
+    rec = {"metric": "p50 latency of one bs=1 infer() call", "unit": "ms", "higher_is_better": False, "calls": 30}
+    cfg_s = synth.load_config("vits14")
+    m_s = UniDepthV2(cfg_s).load_state_dict(synth.make_synthetic_checkpoint(cfg_s, 7)).to(dev).eval()
+    m_s.resolution_level = 2
+    for tag, m, (H, W) in (("vitl14_518x518", model_vitl, (518, 518)), ("vits14_462x616", m_s, (462, 616))):
+        rgb = torch.randint(0, 256, (1, 3, H, W), dtype=torch.uint8, generator=torch.Generator().manual_seed(3)).to(dev)
+        r = {}
+        outs = {}
+        for mode in ("eager", "graph"):
+            m.use_graph = mode == "graph"
+            m.clear_plans()
+            for _ in range(4):                                # plan build, eager replay, graph record, first graph launch
+                o = m.infer(rgb)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(rec["calls"]):
+                t0 = time.perf_counter()
+                o = m.infer(rgb)
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            outs[mode] = o
+            r[mode + "_p50_ms"] = round(statistics.median(ts), 3)
+            r[mode + "_min_ms"] = round(min(ts), 3)
+        plan = next(reversed(m._plans.values()))
+        r["launches"] = len(plan.prog)
+        r["graphs_instantiated"] = plan.prog.graph_count()
+        r["graph_bit_identical"] = all(bool(torch.equal(outs["eager"][k], outs["graph"][k])) for k in outs["eager"])
+        m.use_graph = False
+        m.clear_plans()
+        rec[tag] = r
+    del m_s
+    return rec
+
+
 def extra_configs(torch, model_v2, dev, cpu=True):
     """The other BASELINE.json configurations that fit one GPU (configs[3], configs[4] on one GPU, the K-NN extension), each a few
     seconds of GPU time, after the timed region of the headline metric."""
@@ -507,6 +547,13 @@ def extra_configs(torch, model_v2, dev, cpu=True):
         model_v2.clear_plans()
     except Exception as e:
         out["mixed_644x966+518x518_bs32"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
+    # ---- small-batch latency: bs = 1 p50 per infer(), eager replay against the hipGraph replay of the same program
+    #      (csrc/program.cpp ud_program_run_graph), for ViT-L 518x518 and for BASELINE configs[0]'s shape (ViT-S, one 462x616 image)
+    try:
+        out["latency_bs1"] = latency_bs1(torch, model_v2, dev)
+    except Exception as e:
+        out["latency_bs1"] = {"error": repr(e)}
     torch.cuda.empty_cache()
     # ---- the reference's K-NN extension at the size its 3-D metrics run on (one 480x640 depth map per cloud)
     try:

@@ -337,6 +337,10 @@ int ud_spatial_mean_f32(const float* x, float* out, int B, int HW, int C, int ld
  *  PINV_INIT     Z0 = K^T / max column sum (iterative_pinv initialisation).  i = G, n
  *  ADD           out = a + b (fp32; latents + ray embedding, decoder.py:263,283,303).  i = n & 0x7fffffff, n >> 31
  *  COPY_ROWS     out[(img*rows_per_img + row_off + t)*ld + d] = a[(img*T + t)*D + d] (torch.cat of token groups).  i = n_img, T, rows_per_img, row_off, D, ld, to_f16
+ *                to_f16 == 2 (ld >= 2 D): the value as TWO fp16 terms, hi at column d and lo = fp16(x - hi) at column D + d -- the A operand
+ *                [A_hi | A_lo] of a three-term product against [W_hi | W_hi | W_lo] (UdGemm.a_wrap = 2 K)
+ *  RESIZE_AC_SPLIT  nn.UpsamplingBilinear2d (align_corners=True, layers/upsample.py:34) of an fp32 NHWC map, written as [hi | lo] fp16
+ *                (2 C channels per pixel) for the 3x3 convolution behind it.  i = B, Hin, Win, Hout, Wout, C (C % 4 == 0)
  *  TRANSPOSE16   fp32 [G, M, N] -> fp16 [G, N, ldo] transposed, zero padded.  i = G, M, N, ldo, nh, vt.  nh > 0: input groups (head, image)-major
  *                (g = head * G / nh + image), output groups (image, head)-major; vt != 0 (ldo % 16 == 0): output columns in the V^T block
  *                order of ud_attention_f16 -- together: T = pinv(kernel_2) kernel_3 v as the V^T operand of the Nystrom output attention
@@ -351,7 +355,8 @@ int ud_spatial_mean_f32(const float* x, float* out, int B, int HW, int C, int ld
  *  PREPROCESS    V1 network image (unidepthv1.py:305-321,50-56): [/255], ImageNet normalise, antialiased resize to (h, w), zero pad to (Hn, Wn).
  *                i = B, H, W, h, w, Hn, Wn, pad_l, pad_t, is_u8, div255, normalize */
 enum { UD_V1_RESIZE_AA = 1, UD_V1_SH_EMBED, UD_V1_SOFTMAX, UD_V1_ATTN_FEWQ, UD_V1_SEGMENT_MEAN, UD_V1_BMM, UD_V1_PINV_INIT, UD_V1_ADD,
-       UD_V1_COPY_ROWS, UD_V1_TRANSPOSE16, UD_V1_CAMERA, UD_V1_POINTS, UD_V1_MEAN3, UD_V1_PREPROCESS, UD_V1_VIT_TAP, UD_V1_ATTN_MERGE };
+       UD_V1_COPY_ROWS, UD_V1_TRANSPOSE16, UD_V1_CAMERA, UD_V1_POINTS, UD_V1_MEAN3, UD_V1_PREPROCESS, UD_V1_VIT_TAP, UD_V1_ATTN_MERGE,
+       UD_V1_RESIZE_AC_SPLIT };
 typedef struct UdV1Op {
   int kind;
   const void* a; const void* b; void* c; void* out; void* out2;
@@ -419,6 +424,12 @@ int ud_program_add_spatial_mean(UdProgram*, const float* x, float* out, int B, i
 int ud_program_add_v1_op(UdProgram*, const UdV1Op*);
 /* run ops [first, last) on `stream`; returns 0 or the first failing op's error code */
 int ud_program_run(const UdProgram*, int first, int last, void* stream);
+/* the same replay through a hipGraph (HIP graphs in place of the reference's eager module calls, unidepthv2.py:341-379): the first call
+ * for a range runs it eagerly, the second records + instantiates it, every later call is one hipGraphLaunch on `stream` (which may be the
+ * default stream).  Results are bit-identical to ud_program_run (same kernels, same order).  ud_program_graph_count: instantiated ranges. */
+int ud_program_run_graph(UdProgram*, int first, int last, void* stream);
+int ud_program_graph_count(const UdProgram*);
+void ud_program_drop_graphs(UdProgram*);
 
 /* library info; ud_struct_size(i): sizeof the i-th descriptor struct in declaration order (UdGemm = 0 ... UdLinearF32 = 8, UdDwConv7 = 9, UdV1Op = 10, UdKnn = 11, UdExtractPatches = 12) */
 int ud_version(void);

@@ -305,6 +305,54 @@ def test_v1_split_weight_packing_is_exact_to_22_bits():
     assert U._wk(U._padk16(U._conv3_rows(wc, split=False), split=False), 0, 64)["Cin"] == 64
 
 
+def test_v1_three_term_product_layout_removes_the_activation_rounding():
+    """Round 4: the ConvUpsample tails and output convs of UniDepthV1 multiply [A_hi | A_lo] with [W_hi | W_hi | W_lo], the
+    A index wrapping once after 2 K columns / 2 Cin channels (UdGemm.a_wrap).  Emulated here exactly as the kernels walk K (fp16 operands,
+    wide accumulate): the product matches the fp32 one to ~2^-21 where the two-term product ([A_hi] x [W_hi | W_lo]) keeps the 2^-11
+    activation rounding; the descriptor helper derives the fields from the packed width; the packed decoder uses the layout where the
+    seed study put the error."""
+    from unidepth_amd import unidepthv1 as U
+    g = torch.Generator().manual_seed(1)
+    M, N, K = 40, 24, 128
+    a = torch.randn(M, K, generator=g) * (1.0 + 3.0 * torch.rand(1, K, generator=g))           # channels of unequal scale, non-zero mean
+    a += 2.0
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    w3 = U._padk16_3(w)
+    assert w3.shape == (N, 3 * K) and U._wk(w3, K) == dict(K=3 * K, ldw=3 * K, a_wrap=2 * K)
+    a_hi = a.half()
+    a2 = torch.cat([a_hi, (a - a_hi.float()).half()], dim=1)                                  # what UD_V1_COPY_ROWS to_f16 = 2 writes
+    ka = torch.arange(3 * K)
+    ka = torch.where(ka >= 2 * K, ka - 2 * K, ka)                                              # the loader's wrap
+    y3 = a2[:, ka].double() @ w3.double().t()
+    ref = a.double() @ w.double().t()
+    w2 = U._padk16(w, split=True)
+    y2 = torch.cat([a_hi, a_hi], dim=1).double() @ w2.double().t()
+    e3, e2 = (y3 - ref).abs().max() / ref.abs().max(), (y2 - ref).abs().max() / ref.abs().max()
+    assert e3 < 2e-6 and e2 > 20 * e3, (float(e3), float(e2))
+    # 3x3: per tap [W_hi | W_hi | W_lo] against an image of 2 Cin channels
+    wc = torch.randn(8, 16, 3, 3, generator=g) * 144 ** -0.5
+    rows = U._conv3_rows_3(wc)
+    assert rows.shape == (8, 9 * 48) and torch.equal(rows.half().float(), rows)
+    r = rows.view(8, 9, 3, 16)
+    want = wc.permute(0, 2, 3, 1).reshape(8, 9, 16)
+    assert torch.equal(r[:, :, 0], r[:, :, 1]) and torch.equal(r[:, :, 0], want.half().float())
+    assert ((r[:, :, 0] + r[:, :, 2]) - want).abs().max() < 2 ** -20 * want.abs().max()
+    pk = U._padk16(U._conv3_rows_3(torch.randn(8, 64, 3, 3, generator=g)), split=False)
+    assert U._wk(pk, 0, 64) == dict(K=pk.shape[1], ldw=pk.shape[1], Cin=192, a_wrap=128)
+    # the packed decoder: three-term layout on up*.up.0 / up*.up.2 / out*, two-term elsewhere
+    from oracle import synth_v1
+    assert U.ASPLIT
+    cfg = synth_v1.load_config_v1()
+    C = cfg["model"]["pixel_decoder"]["hidden_dim"]
+    wd = U.pack_v1_decoder(cfg, synth_v1.make_synthetic_checkpoint_v1(cfg, 211), torch.device("cpu"))
+    for nm, d in (("up8", C), ("up4", C // 2), ("up2", C // 4)):
+        assert wd[f"{nm}.up0.w"].shape == (d // 2, 3 * d) and U._wk(wd[f"{nm}.up0.w"], d)["a_wrap"] == 2 * d
+        assert U._wk(wd[f"{nm}.up2.w"], 0, d // 2) == dict(K=27 * (d // 2), ldw=27 * (d // 2), Cin=3 * (d // 2), a_wrap=d)
+        assert U._wk(wd[f"{nm}.0.fc2.w"], 4 * d)["a_wrap"] == 4 * d                         # the CvnxtBlocks in front keep two terms
+    for nm, d in (("out8", C // 2), ("out4", C // 4), ("out2", C // 8)):
+        assert U._wk(wd[f"{nm}.w"], 0, d)["Cin"] == 3 * d
+
+
 def test_v1_convnext_fc1_is_the_one_unsplit_weight():
     """Default placement of the two-term weights (tools/v1_precision_study.py placement): every GEMM weight of the ConvNeXt encoder is
     [W_hi | W_lo] except the blocks' fc1 (A = LayerNorm output), whose fp16 rounding the depth error does not see."""
@@ -403,3 +451,35 @@ def test_engine_classes_are_nn_modules(tmp_path):
     cfg1 = synth_v1.load_config_v1("cnvnxtl")
     v1 = UniDepthV1(cfg1)
     assert isinstance(v1, torch.nn.Module) and v1.eval() is v1 and v1.device.type == "cpu"
+
+
+def test_v1_plan_builder_dry_run_validates_every_gemm_descriptor(monkeypatch):
+    """The launch program of a UniDepthV1 infer() is RECORDED on the host (host tensors stand in for the device buffers, nothing runs) and
+    every GEMM descriptor it records is handed to ud_gemm_f16: without a GPU the call must get past the C side's argument validation
+    (wrap / K / Cin / stride rules, include/unidepth_hip.h UdGemm) and fail only at the launch itself -- a builder bug (e.g. a three-term
+    weight against a two-term A stride) is caught here, not on the GPU box."""
+    import contextlib
+    from oracle import synth_v1
+    from unidepth_amd import UniDepthV1, _lib, ops, unidepthv1 as U
+    if torch.cuda.is_available():
+        pytest.skip("host-only dry run")
+    cfg = synth_v1.load_config_v1("cnvnxtl")
+    m = UniDepthV1(cfg).load_state_dict(synth_v1.make_synthetic_checkpoint_v1(cfg, 301))
+    dev = torch.device("cpu")
+    m._w = {**U.pack_convnext(cfg, m._sd, dev), **U.pack_v1_decoder(cfg, m._sd, dev)}
+    m._device = dev
+    monkeypatch.setattr(torch.cuda, "device", lambda d: contextlib.nullcontext())
+    monkeypatch.setattr(ops, "ptr", lambda t: None if t is None else (t if isinstance(t, int) else t.data_ptr()))
+    real_add, seen = _lib.lib.ud_program_add_gemm, []
+
+    def add(h, dref):
+        rc = _lib.lib.ud_gemm_f16(dref, None)
+        seen.append((rc, _lib.lib.ud_last_error().decode() if rc else "", dref._obj.M, dref._obj.N, dref._obj.K, dref._obj.a_wrap, dref._obj.Cin))
+        return real_add(h, dref)
+    monkeypatch.setattr(ops.lib, "ud_program_add_gemm", add)
+    plan = m._full_plan(1, 240, 320, True, False, True, 0, False)
+    assert len(plan.prog) > 400 and len(seen) > 150
+    bad = [r for r in seen if r[0] != -2]                     # -2 = UD_ERR_LAUNCH (include/unidepth_hip.h)
+    assert not bad, bad[:3]                                    # UD_ERR_BAD_ARG would mean a descriptor the kernels refuse
+    three = [r for r in seen if r[5] and (3 * r[5] == 2 * r[4] or (r[6] and 3 * r[5] == 2 * r[6]))]
+    assert len(three) == 9, three                              # up{8,4,2}.up.0, up{8,4,2}.up.2, out{8,4,2}

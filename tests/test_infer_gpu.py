@@ -197,3 +197,62 @@ def test_pipeline_two_calls_in_flight(engine_cls):
     for o, r in zip(outs, refs):
         for k in r:
             assert torch.equal(o[k], r[k]), k
+
+
+def test_interrupted_replay_leaves_no_state_behind(engine_cls):
+    """the LayerNorm fold hands row statistics from a producer launch (proj / fc2: partial sums, a ticket per row
+    tile, the last arriver reduces) to the consumer launch after it (qkv / fc1).  A replay that stops BETWEEN the two -- an exception in
+    a tap replay, a caller abandoning a call -- must not poison later replays of the same plan: every completed launch leaves its
+    tickets at zero (atomicInc with the arrival count as bound) and every statistic a consumer reads is rewritten by the producer in
+    front of it.  Here the plan of a folded ViT-L bs=4 call is (1) replayed in full, (2) replayed up to just after a producer, in the
+    middle of the encoder, (3) replayed from the middle of the encoder to just after a later producer (consumers fed with stale
+    statistics, result discarded), and then replayed in full again: the outputs must be the SAME BITS as (1)."""
+    case = cases.CASES["vitl_518x518_b1"]
+    cfg = synth.load_config(case["arch"])
+    sd = synth.make_synthetic_checkpoint(cfg, case["ckpt_seed"])
+    model = engine_cls(cfg).load_state_dict(sd).to("cuda").eval()
+    rgb = torch.randint(0, 256, (4, 3, 518, 518), dtype=torch.uint8, generator=torch.Generator().manual_seed(5)).cuda()
+    out0 = model.infer(rgb)
+    torch.cuda.synchronize()
+    plan = next(reversed(model._plans.values()))
+    tags = [m[1] for m in plan.prog.meta]
+    # the fold must be on for this plan (large-tile kernel, bs >= 4 for ViT-L), else the test tests nothing
+    assert plan.ln_fold and tags.count("enc.ln") <= 2, "the LayerNorm fold is expected to be active at bs=4 ViT-L (only block 0's norm1 stays a launch)"
+    prods = [i for i, t in enumerate(tags) if t in ("enc.proj", "enc.fc2")]
+    assert len(prods) == 48
+    stop_a = prods[7] + 1          # just after the proj of block 3: its consumer (fc1) never runs
+    start_b, stop_b = prods[20] + 2, prods[30] + 1
+    plan.prog.run(0, stop_a)
+    plan.prog.run(start_b, stop_b)       # starts on a consumer whose producer did not run in this replay
+    torch.cuda.synchronize()
+    assert int(plan.row_tickets.abs().sum()) == 0, "a completed launch must leave its tickets at zero"
+    out1 = model.infer(rgb)
+    torch.cuda.synchronize()
+    for k in out0:
+        assert torch.equal(out0[k], out1[k]), k
+
+
+def test_graph_replay_bit_identical(engine_cls):
+    """model.use_graph (csrc/program.cpp ud_program_run_graph: call 1 of a signature eager, call 2 recorded into a hipGraph and launched,
+    later calls one hipGraphLaunch): the same kernels in the same order -> the same bits as the eager replay, on fresh inputs too (the graph
+    reads the plan's input buffer, not a snapshot), for the launch-bound bs=1 shape of BASELINE configs[0] and with a GT camera."""
+    case = cases.CASES["vits_462x616_b1"]
+    cfg = synth.load_config(case["arch"])
+    sd = synth.make_synthetic_checkpoint(cfg, case["ckpt_seed"])
+    eager = engine_cls(cfg).load_state_dict(sd).to("cuda").eval()
+    graph = engine_cls(cfg).load_state_dict(sd).to("cuda").eval()
+    eager.resolution_level = graph.resolution_level = 2
+    graph.use_graph = True
+    g = torch.Generator().manual_seed(21)
+    K = torch.tensor([[500.0, 0.0, 308.0], [0.0, 500.0, 231.0], [0.0, 0.0, 1.0]])
+    for cam in (None, K):
+        for i in range(4):
+            rgb = torch.randint(0, 256, (1, 3, 462, 616), dtype=torch.uint8, generator=g).cuda()
+            a = eager.infer(rgb, None if cam is None else cam.cuda())
+            b = graph.infer(rgb, None if cam is None else cam.cuda())
+            torch.cuda.synchronize()
+            for k in a:
+                assert torch.equal(a[k], b[k]), (k, i, cam is not None)
+    counts = [p.prog.graph_count() for p in graph._plans.values()]
+    assert counts == [1, 1], counts                       # one instantiated graph per plan signature (no camera / GT camera)
+    assert all(p.prog.graph_count() == 0 for p in eager._plans.values())

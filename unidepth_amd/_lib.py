@@ -66,7 +66,7 @@ class UdExtractPatches(C.Structure):
 
 
 (UD_V1_RESIZE_AA, UD_V1_SH_EMBED, UD_V1_SOFTMAX, UD_V1_ATTN_FEWQ, UD_V1_SEGMENT_MEAN, UD_V1_BMM, UD_V1_PINV_INIT, UD_V1_ADD, UD_V1_COPY_ROWS,
- UD_V1_TRANSPOSE16, UD_V1_CAMERA, UD_V1_POINTS, UD_V1_MEAN3, UD_V1_PREPROCESS, UD_V1_VIT_TAP, UD_V1_ATTN_MERGE) = range(1, 17)
+ UD_V1_TRANSPOSE16, UD_V1_CAMERA, UD_V1_POINTS, UD_V1_MEAN3, UD_V1_PREPROCESS, UD_V1_VIT_TAP, UD_V1_ATTN_MERGE, UD_V1_RESIZE_AC_SPLIT) = range(1, 18)
 UD_ACT_CLAMPEXP = 3
 
 
@@ -167,6 +167,8 @@ def _load():
         "ud_knn_split": [P(UdKnn)],
         "ud_extract_patches": [P(UdExtractPatches), vp],
         "ud_program_run": [vp, i32, i32, vp],
+        "ud_program_run_graph": [vp, i32, i32, vp],
+        "ud_program_graph_count": [vp],
         "ud_version": [],
         "ud_struct_size": [i32],
     }
@@ -174,6 +176,8 @@ def _load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = None if name == "ud_program_destroy" else i32
+    lib.ud_program_drop_graphs.argtypes = [vp]
+    lib.ud_program_drop_graphs.restype = None
     lib.ud_program_create.argtypes = []
     lib.ud_program_create.restype = vp
     lib.ud_last_error.argtypes = []

@@ -2,6 +2,12 @@
 // (model, batch, shape) as a flat list of kernel descriptors and replayed with ONE call from Python, so the
 // per-launch host cost is a C++ switch instead of a ctypes round trip (the recorded range can also be captured
 // into a hipGraph by the caller: every launch goes to the stream passed to ud_program_run).
+// ud_program_run_graph does that capture itself: the second replay of a range records it on a private capture stream (the caller's stream
+// may be the legacy default stream, which cannot capture), instantiates the graph once and from then on a replay is ONE hipGraphLaunch --
+// the launch-bound small-batch programs (ViT-S bs=1: ~280 kernels of 2-10 us) no longer pay one host launch per kernel.
+#include <hip/hip_runtime.h>
+#include <map>
+#include <utility>
 #include <vector>
 #include <new>
 #include "../../include/unidepth_hip.h"
@@ -32,13 +38,26 @@ struct Op {
 };
 }  // namespace
 
-struct UdProgram { std::vector<Op> ops; };
+struct UdGraph { hipGraphExec_t exec = nullptr; int device = -1; int runs = 0; };
+struct UdProgram {
+  std::vector<Op> ops;
+  std::map<std::pair<int, int>, UdGraph> graphs;      // (first, last) -> instantiated graph of that range
+};
 
 extern "C" {
 UdProgram* ud_program_create(void) { return new (std::nothrow) UdProgram(); }
-void ud_program_destroy(UdProgram* p) { delete p; }
+static void drop_graphs(UdProgram* p) {
+  for (auto& kv : p->graphs)
+    if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+  p->graphs.clear();
+}
+void ud_program_destroy(UdProgram* p) {
+  if (p) drop_graphs(p);
+  delete p;
+}
 int ud_program_size(const UdProgram* p) { return p ? (int)p->ops.size() : 0; }
 
+// (a recorded graph holds the descriptors BY VALUE: appending ops does not change it, but a range that grew is a different key)
 #define ADD(KIND, FIELD, SRC)       \
   if (!p) return UD_ERR_BAD_ARG;    \
   Op op; op.kind = KIND; op.FIELD = SRC; p->ops.push_back(op); return (int)p->ops.size() - 1;
@@ -135,4 +154,51 @@ int ud_program_run(const UdProgram* p, int first, int last, void* stream) {
   }
   return UD_OK;
 }
+
+// Replay ops [first, last) through a hipGraph.  Replay 1 of a range runs eagerly (module loads, one-time hipFuncSetAttribute calls and the
+// LDS-size opt-ins happen there, outside any capture); replay 2 is recorded on a private non-blocking stream in RELAXED capture mode
+// (other threads may keep calling HIP: pipeline slots) and instantiated; the recording itself executes nothing, so the graph is launched
+// for replay 2 as well.  Every later replay is one hipGraphLaunch on the caller's stream.  The graph bakes in the descriptors' device
+// pointers: the buffers of a plan live as long as its program does (unidepth_amd _Plan), which is the contract of ud_program_run too.
+int ud_program_run_graph(UdProgram* p, int first, int last, void* stream) {
+  if (!p || first < 0 || last > (int)p->ops.size() || first > last) { ud_set_error("ud_program_run_graph: bad range"); return UD_ERR_BAD_ARG; }
+  if (first == last) return UD_OK;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) { ud_set_error("ud_program_run_graph: hipGetDevice failed"); return UD_ERR_LAUNCH; }
+  UdGraph& g = p->graphs[std::make_pair(first, last)];
+  if (g.exec && g.device != dev) { (void)hipGraphExecDestroy(g.exec); g = UdGraph(); }
+  if (!g.exec) {
+    if (g.runs++ == 0) return ud_program_run(p, first, last, stream);
+    hipStream_t cs = nullptr;
+    if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { ud_set_error("ud_program_run_graph: cannot create the capture stream"); return UD_ERR_LAUNCH; }
+    hipGraph_t graph = nullptr;
+    int rc = UD_OK;
+    if (hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed) != hipSuccess) {
+      ud_set_error("ud_program_run_graph: hipStreamBeginCapture failed");
+      rc = UD_ERR_LAUNCH;
+    } else {
+      rc = ud_program_run(p, first, last, cs);
+      const hipError_t e = hipStreamEndCapture(cs, &graph);          // always end the capture, also after a failed op
+      if (rc == UD_OK && (e != hipSuccess || !graph)) { ud_set_error("ud_program_run_graph: hipStreamEndCapture failed"); rc = UD_ERR_LAUNCH; }
+    }
+    if (rc == UD_OK && hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+      g.exec = nullptr;
+      ud_set_error("ud_program_run_graph: hipGraphInstantiate failed");
+      rc = UD_ERR_LAUNCH;
+    }
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipStreamDestroy(cs);
+    (void)hipGetLastError();
+    if (rc != UD_OK) { g.runs = 0; return rc; }
+    g.device = dev;
+  }
+  if (hipGraphLaunch(g.exec, (hipStream_t)stream) != hipSuccess) { ud_set_error("ud_program_run_graph: hipGraphLaunch failed"); return UD_ERR_LAUNCH; }
+  return UD_OK;
+}
+int ud_program_graph_count(const UdProgram* p) {
+  int n = 0;
+  if (p) for (const auto& kv : p->graphs) n += kv.second.exec != nullptr;
+  return n;
+}
+void ud_program_drop_graphs(UdProgram* p) { if (p) drop_graphs(p); }
 }

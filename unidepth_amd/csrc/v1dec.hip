@@ -545,8 +545,50 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(void* dst, const float* 
     const long long r = idx / D;
     const int t = (int)(r % T), img = (int)(r / T);
     const size_t o = ((size_t)img * rows_per_img + row_off + t) * ld + d;
-    if (to_f16) ((half_t*)dst)[o] = (half_t)src[idx];
+    if (to_f16 == 2) {              // two fp16 terms side by side (ld >= 2 D): hi at column d, lo = fp16(x - hi) at column D + d
+      const float x = src[idx];
+      const half_t hi = (half_t)x;
+      ((half_t*)dst)[o] = hi;
+      ((half_t*)dst)[o + D] = (half_t)(x - (float)hi);
+    } else if (to_f16) ((half_t*)dst)[o] = (half_t)src[idx];
     else ((float*)dst)[o] = src[idx];
+  }
+}
+// nn.UpsamplingBilinear2d (align_corners=True; layers/upsample.py:34) of an fp32 NHWC map, written as the TWO-TERM fp16 A operand of the 3x3
+// convolution behind it: out[pix][0 .. C) = hi = fp16(v), out[pix][C .. 2C) = lo = fp16(v - hi) -- with weights [W_hi | W_hi | W_lo] per tap and
+// the channel index wrapping after 2 C (UdGemm.a_wrap) the product is A_hi W_hi + A_lo W_hi + A_hi W_lo: the activation's fp16 rounding
+// (2^-11 relative, the largest single error source of the V1 depth stack: DESIGN 10.3) is gone, interpolation stays fp32 throughout.
+// Same source-coordinate arithmetic as resize_ac_kernel (pointwise.hip).  4 channels per thread.
+__global__ __launch_bounds__(256) void resize_ac_split_kernel(const float* in, half_t* out, int B, int Hin, int Win, int Hout, int Wout, int C) {
+  const int CG = C >> 2;
+  const float sy = Hout > 1 ? (float)(Hin - 1) / (float)(Hout - 1) : 0.f;
+  const float sx = Wout > 1 ? (float)(Win - 1) / (float)(Wout - 1) : 0.f;
+  const long long total = (long long)B * Hout * Wout * CG;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int cg = (int)(idx % CG);
+    const long long pix = idx / CG;
+    const int ox = (int)(pix % Wout);
+    const long long r = pix / Wout;
+    const int oy = (int)(r % Hout), b = (int)(r / Hout);
+    const float fy = sy * (float)oy, fx = sx * (float)ox;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hin - 1), x1 = x0 + (x0 < Win - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float* ip = in + (size_t)b * Hin * Win * C + cg * 4;
+    const f32x4 v00 = *(const f32x4*)(ip + ((size_t)y0 * Win + x0) * C), v01 = *(const f32x4*)(ip + ((size_t)y0 * Win + x1) * C);
+    const f32x4 v10 = *(const f32x4*)(ip + ((size_t)y1 * Win + x0) * C), v11 = *(const f32x4*)(ip + ((size_t)y1 * Win + x1) * C);
+    half4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float top = (1.0f - lx) * v00[e] + lx * v01[e];
+      const float bot = (1.0f - lx) * v10[e] + lx * v11[e];
+      const float v = (1.0f - ly) * top + ly * bot;
+      hi[e] = (half_t)v;
+      lo[e] = (half_t)(v - (float)hi[e]);
+    }
+    half_t* op = out + (size_t)pix * 2 * C + cg * 4;
+    *(half4*)op = hi;
+    *(half4*)(op + C) = lo;
   }
 }
 // out fp16 [G, N, ldo] = transpose of in fp32 [G, M, N] (M <= ldo; pad columns zero): pinv @ kernel_3 as the W operand of the last Nystrom GEMM
@@ -768,8 +810,15 @@ extern "C" int ud_v1_op(const UdV1Op* desc, void* stream) {
       UD_CHECK_LAUNCH("ud_v1_op(vit_tap) launch");
       return UD_OK;
     }
+    case UD_V1_RESIZE_AC_SPLIT: {   // a = fp32 NHWC [B, Hin, Win, C]; out = fp16 [B, Hout, Wout, 2 C] (hi | lo); i = B, Hin, Win, Hout, Wout, C
+      if (!d.a || !d.out || i[0] <= 0 || i[1] <= 0 || i[2] <= 0 || i[3] <= 0 || i[4] <= 0 || i[5] <= 0 || (i[5] & 3)) break;
+      hipLaunchKernelGGL(resize_ac_split_kernel, dim3(grid1((long long)i[0] * i[3] * i[4] * (i[5] >> 2))), dim3(256), 0, s, (const float*)d.a, (half_t*)d.out, i[0], i[1], i[2],
+                         i[3], i[4], i[5]);
+      UD_CHECK_LAUNCH("ud_v1_op(resize_ac_split) launch");
+      return UD_OK;
+    }
     case UD_V1_COPY_ROWS: {      // a = src fp32 [n_img*T, D]; out rows (img*rows_per_img + row_off + t), stride ld; i = n_img, T, rows_per_img, row_off, D, ld, to_f16
-      if (!d.a || !d.out || i[0] <= 0 || i[1] <= 0 || i[4] <= 0) break;
+      if (!d.a || !d.out || i[0] <= 0 || i[1] <= 0 || i[4] <= 0 || (i[6] == 2 && i[5] < 2 * i[4])) break;
       hipLaunchKernelGGL(copy_rows_kernel, dim3(grid1((long long)i[0] * i[1] * i[4])), dim3(256), 0, s, d.out, (const float*)d.a, i[0], i[1], i[2], i[3], i[4], i[5], i[6]);
       UD_CHECK_LAUNCH("ud_v1_op(copy_rows) launch");
       return UD_OK;

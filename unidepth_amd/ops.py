@@ -240,6 +240,15 @@ class Program:
         self.meta.append(("v1." + tag, tag, 0.0, 0.0))
         return check(lib.ud_program_add_v1_op(self.h, C.byref(v1_desc(kind, a, b, c, out, out2, i, f))))
 
-    def run(self, first=0, last=None, stream=None):
+    def run(self, first=0, last=None, stream=None, graph=False):
+        """Replay ops [first, last) on the current (or given) stream; graph=True: through ud_program_run_graph (eager the first time the
+        range is seen, recorded into a hipGraph the second, one hipGraphLaunch from then on; same kernels, same order, same bits)."""
         last = len(self) if last is None else last
-        check(lib.ud_program_run(self.h, first, last, cur_stream() if stream is None else stream), "ud_program_run")
+        fn = lib.ud_program_run_graph if graph else lib.ud_program_run
+        check(fn(self.h, first, last, cur_stream() if stream is None else stream), "ud_program_run_graph" if graph else "ud_program_run")
+
+    def graph_count(self):
+        return int(lib.ud_program_graph_count(self.h))
+
+    def drop_graphs(self):
+        lib.ud_program_drop_graphs(self.h)

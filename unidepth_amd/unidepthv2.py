@@ -172,6 +172,7 @@ class _Plan:
         env = os.environ.get("UNIDEPTH_LN_FOLD", "")
         fold = big and env != "0" and (prod_tiles <= 320 or env == "1")
         self.ln_fold = fold
+        self.row_tickets = rticket          # tests: every completed launch leaves its ticket set at zero
         lnc = dict(row_stats_in=rstats, ln_slabs=slabs, ln_D=D, ln_eps=1e-6)
         for i in range(a["depth"]):
             if fold and i > 0:
@@ -416,7 +417,9 @@ class UniDepthV2(EngineModule):
         self._plans: "collections.OrderedDict" = collections.OrderedDict()
         self.max_plans = int(os.environ.get("UNIDEPTH_MAX_PLANS", "6"))   # LRU bound on cached (batch, shape, camera, slot) plans
         self._pos_cache: dict = {}
-        self.use_graph = False
+        # True: a plan's launch program is replayed as ONE hipGraph launch (recorded on the second call of a signature).  For the launch-bound
+        # small-batch calls (bs = 1: ~280 kernels of 2-10 us each); at bs = 8 the stream is never idle and eager replay is as fast.
+        self.use_graph = os.environ.get("UNIDEPTH_GRAPH", "0") == "1"
 
     # ---- checkpoint I/O (HF mixin layout: config.json + model.safetensors / pytorch_model.bin) ----
     @classmethod
@@ -589,14 +592,15 @@ class UniDepthV2(EngineModule):
                 Kn[:, 1, 2] += pt
                 Kn[:, :2, :] *= plan.rf
                 plan.kinv_gt.copy_(torch.inverse(Kn).reshape(-1, 9))
-            self._run(plan, 0, len(plan.prog), taps)
+            self._run(plan, 0, len(plan.prog), taps, graph=self.use_graph)
             return self._collect(plan, B)
 
     @staticmethod
-    def _run(plan: _Plan, first: int, last: int, taps=None):
-        """Replay ops [first, last) of the plan; with `taps` = (dict, names or None) the replay stops at every tap point in range."""
+    def _run(plan: _Plan, first: int, last: int, taps=None, graph: bool = False):
+        """Replay ops [first, last) of the plan; with `taps` = (dict, names or None) the replay stops at every tap point in range.
+        graph (model.use_graph): the whole range as one hipGraph launch from its third replay on (csrc/program.cpp ud_program_run_graph)."""
         if taps is None:
-            plan.prog.run(first, last)
+            plan.prog.run(first, last, graph=graph)
             return
         store, names = taps
         pos = first
