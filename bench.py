@@ -505,8 +505,10 @@ def extra_configs(torch, model_v2, dev, cpu=True):
         rec = {"metric": "images/sec, UniDepthV1 ConvNeXt-L 640x480 bs=16 (BASELINE configs[3])", "value": round(B1 / dt, 2), "unit": "images/s",
                "ms_per_step": round(dt * 1e3, 3), "steps": 10, "launches": len(plan.prog),
                "dtype": "f16 MFMA operands, fp32 accumulate" + ("; weights as TWO fp16 terms (W_hi + W_lo, ~22-bit weights: UdGemm.a_wrap)" + ("" if v1mod.WSPLIT_CONVNEXT_FC1 else " except the ConvNeXt blocks' fc1") if v1mod.WSPLIT else "")
+                        + ("; the ConvUpsample tails and the output convs as THREE-term products ([A_hi | A_lo] x [W_hi | W_hi | W_lo])" if getattr(v1mod, "ASPLIT", False) else "")
                         + "; depth-wise convolutions, LayerNorm / softmax statistics, the camera transformer, the Nystrom pseudo-inverse and all residual streams in fp32",
-               "parity": "depth ARel <= 1e-3 per image vs the fp32 oracle at this batch (tests/test_v1_gpu.py::test_v1_infer_config4_bs16_vs_oracle); "
+               "parity": "depth ARel <= 1e-3 per image vs the fp32 oracle at this batch (tests/test_v1_gpu.py::test_v1_infer_config4_bs16_vs_oracle); over 8 checkpoint "
+                         "seeds x 2 sizes (tests/test_parity_sweep_gpu.py): median 5.6e-4, max 7.9e-4, 16 of 16 within 1e-3 (profiles/r04_v1_sweep_three_term_all_split.txt); "
                          "Nystrom stages: parity unpinned (oracle header)",
                "model_tflops_per_s": round(fl_total / dt / 1e12, 1),
                "roofline": {"bound": "mfma", "kernel": dom + " (v_mfma_f32_16x16x32_f16)", "achieved": round(dv[1] / (dv[0] * 1e-3) / 1e12, 2),

@@ -204,20 +204,21 @@ def test_interrupted_replay_leaves_no_state_behind(engine_cls):
     tile, the last arriver reduces) to the consumer launch after it (qkv / fc1).  A replay that stops BETWEEN the two -- an exception in
     a tap replay, a caller abandoning a call -- must not poison later replays of the same plan: every completed launch leaves its
     tickets at zero (atomicInc with the arrival count as bound) and every statistic a consumer reads is rewritten by the producer in
-    front of it.  Here the plan of a folded ViT-L bs=4 call is (1) replayed in full, (2) replayed up to just after a producer, in the
+    front of it.  Here the plan of a folded ViT-L bs=8 call is (1) replayed in full, (2) replayed up to just after a producer, in the
     middle of the encoder, (3) replayed from the middle of the encoder to just after a later producer (consumers fed with stale
-    statistics, result discarded), and then replayed in full again: the outputs must be the SAME BITS as (1)."""
+    statistics, result discarded), and then replayed in full again: the outputs must be the SAME BITS as (1).  (bs = 8: the fold needs all
+    four block GEMMs on the large-tile kernel, which the picker grants from M = 11008 rows on for ViT-L, not at bs = 4.)"""
     case = cases.CASES["vitl_518x518_b1"]
     cfg = synth.load_config(case["arch"])
     sd = synth.make_synthetic_checkpoint(cfg, case["ckpt_seed"])
     model = engine_cls(cfg).load_state_dict(sd).to("cuda").eval()
-    rgb = torch.randint(0, 256, (4, 3, 518, 518), dtype=torch.uint8, generator=torch.Generator().manual_seed(5)).cuda()
+    rgb = torch.randint(0, 256, (8, 3, 518, 518), dtype=torch.uint8, generator=torch.Generator().manual_seed(5)).cuda()
     out0 = model.infer(rgb)
     torch.cuda.synchronize()
     plan = next(reversed(model._plans.values()))
     tags = [m[1] for m in plan.prog.meta]
     # the fold must be on for this plan (large-tile kernel, bs >= 4 for ViT-L), else the test tests nothing
-    assert plan.ln_fold and tags.count("enc.ln") <= 2, "the LayerNorm fold is expected to be active at bs=4 ViT-L (only block 0's norm1 stays a launch)"
+    assert plan.ln_fold and tags.count("enc.ln") <= 2, "the LayerNorm fold is expected to be active at bs=8 ViT-L (only block 0's norm1 stays a launch)"
     prods = [i for i, t in enumerate(tags) if t in ("enc.proj", "enc.fc2")]
     assert len(prods) == 48
     stop_a = prods[7] + 1          # just after the proj of block 3: its consumer (fc1) never runs

@@ -154,10 +154,16 @@ def test_v1_depth_error_distribution(arch):
     _hist(f"UniDepthV1 {arch} intrinsics max-rel", kk, 1e-3)
     over = sum(d > 1e-3 for d in dep)
     print(f"UniDepthV1 {arch}: {len(dep) - over} of {len(dep)} cases within 1e-3; worst {max(dep):.2e}")
-    # MEASURED, round 4: ConvNeXt-L median 9.2e-4, max 1.54e-3, 10 of 16 within 1e-3; ViT-L/14 median 1.03e-3, max 1.93e-3,
-    # 8 of 16.  The camera is NOT the cause here (K <= 4.2e-4 everywhere): it is the depth stack's fp16 ACTIVATION rounding (weights are two
-    # fp16 terms already), spread over every layer (tools/v1_precision_study.py), against a reference that runs fp32 without autocast
-    # (unidepthv1.py:288-373).  The 1e-3 bar of the four seeded cases in tests/test_v1_gpu.py therefore holds for THOSE checkpoints, not
-    # for the checkpoint distribution; what IS asserted here is the level the distribution supports with margin, so that a precision
-    # regression (e.g. a weight term dropped) still fails: median <= 1.2e-3, worst <= 2.5e-3, camera <= 1e-3.
-    assert float(np.median(dep)) <= 1.2e-3 and max(dep) <= 2.5e-3 and max(kk) <= 1e-3, (float(np.median(dep)), max(dep), max(kk))
+    # MEASURED, round 4 (profiles/r04_v1_sweep_*.txt, r04_parity_sweep.txt):
+    #   ConvNeXt-L  round-3 build        median 9.2e-4  max 1.54e-3  10 of 16 within 1e-3
+    #               + three-term tail     median 7.0e-4  max 1.09e-3  15 of 16   (activation rounding of the ConvUpsample tails / output convs removed)
+    #               + fc1 weights split   median 5.6e-4  max 7.9e-4   16 of 16   (the default build: the north-star bar, with 21 % of margin on the worst case)
+    #   ViT-L/14    round-3 build        median 1.03e-3 max 1.93e-3   8 of 16
+    #               + three-term tail     median 8.1e-4  max 1.48e-3  11 of 16   (the rest is the fp16-operand ENCODER against an fp32 reference: a global
+    #                                                                             shift through the class tokens, tools/r4_v1_seed_study.py; bar NOT met)
+    # The camera is not the cause in either (K <= 4.2e-4 everywhere).  Asserted: ConvNeXt-L (SURVEY 8f / BASELINE configs[3]) at the bar itself;
+    # the ViT-L/14 variant at the level its distribution supports with margin, so that a precision regression still fails.
+    if arch == "cnvnxtl":
+        assert max(dep) <= 1e-3 and max(kk) <= 1e-3, (float(np.median(dep)), max(dep), max(kk))
+    else:
+        assert float(np.median(dep)) <= 1.0e-3 and max(dep) <= 2.0e-3 and max(kk) <= 1e-3, (float(np.median(dep)), max(dep), max(kk))

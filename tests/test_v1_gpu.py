@@ -135,6 +135,63 @@ def test_v1_resize_aa(ops):
     assert rel(y, ref) < 2e-6
 
 
+def test_v1_three_term_tail_ops_and_products(ops):
+    """Round 4: COPY_ROWS to_f16 = 2 ([hi | lo] of an fp32 stream), RESIZE_AC_SPLIT (nn.UpsamplingBilinear2d of an fp32 map written as
+    [hi | lo]), and the three-term products they feed -- dense (UdGemm.a_wrap = 2 K against [W_hi | W_hi | W_lo]) and 3x3 implicit GEMM
+    (channel index wrapping after 2 Cin) -- against plain fp32 torch on the SAME fp32 operands: <= 3e-6 where the one- / two-term forms
+    sit at the fp16 rounding of A (a few 1e-4)."""
+    from unidepth_amd import _lib as L
+    from unidepth_amd import unidepthv1 as U
+    g = torch.Generator().manual_seed(9)
+    M, K, N = 1064, 512, 256
+    x = (torch.randn(M, K, generator=g) * (1.0 + 2.0 * torch.rand(1, K, generator=g)) + 1.5).cuda()
+    a2 = torch.zeros(M, 2 * K, dtype=torch.half, device="cuda")
+    ops.v1_op(L.UD_V1_COPY_ROWS, a=x, out=a2, i=(1, M, M, 0, K, 2 * K, 2))
+    torch.cuda.synchronize()
+    hi = x.half()
+    assert torch.equal(a2[:, :K], hi) and torch.equal(a2[:, K:], (x - hi.float()).half())
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    bias = torch.randn(N, generator=g).cuda()
+    w3 = U._padk16_3(w).cuda()
+    out = torch.zeros(M, N, device="cuda")
+    ops.gemm(A=a2, W=w3, bias=bias, out=out, M=M, N=N, lda=2 * K, ldc=N, epi=ops.UD_EPI_F32, **U._wk(w3, K))
+    ref = x.double() @ w.double().cuda().t() + bias.double()
+    torch.cuda.synchronize()
+    e3 = rel(out, ref)
+    w2 = U._padk16(w, split=True).cuda()
+    out2 = torch.zeros(M, N, device="cuda")
+    ops.gemm(A=hi, W=w2, bias=bias, out=out2, M=M, N=N, lda=K, ldc=N, epi=ops.UD_EPI_F32, **U._wk(w2, K))
+    torch.cuda.synchronize()
+    e2 = rel(out2, ref)
+    print(f"dense: three-term {e3:.2e}, two-term {e2:.2e}")
+    assert e3 < 3e-6 and e2 > 10 * e3, (e3, e2)
+    # align_corners x2 of an fp32 NHWC map -> [hi | lo], then the 3x3 conv (zero padding) with per-tap [W_hi | W_hi | W_lo]
+    B, Hs, Ws, Cc, Co = 2, 15, 20, 64, 64
+    u0 = (torch.randn(B, Hs, Ws, Cc, generator=g) * 3.0 + 1.0).cuda()
+    u1 = torch.zeros(B, 2 * Hs, 2 * Ws, 2 * Cc, dtype=torch.half, device="cuda")
+    ops.v1_op(L.UD_V1_RESIZE_AC_SPLIT, a=u0, out=u1, i=(B, Hs, Ws, 2 * Hs, 2 * Ws, Cc))
+    up = F.interpolate(u0.permute(0, 3, 1, 2).double(), scale_factor=2, mode="bilinear", align_corners=True)        # = nn.UpsamplingBilinear2d
+    torch.cuda.synchronize()
+    got = (u1[..., :Cc].double() + u1[..., Cc:].double()).permute(0, 3, 1, 2)
+    assert rel(got, up) < 2e-6, rel(got, up)
+    hi_err = (u1[..., :Cc].double().permute(0, 3, 1, 2) - up).abs()
+    assert (hi_err <= up.abs() * 2.0 ** -11 + 2e-5).all()                  # the hi term alone is the fp16 rounding of the value (+ fp32 cancellation near zero crossings)
+    assert (u1[..., Cc:].float().abs() <= u1[..., :Cc].float().abs() * 2.0 ** -10 + 1e-7).all()      # and the lo term is what that rounding dropped
+    wc = torch.randn(Co, Cc, 3, 3, generator=g) * (9 * Cc) ** -0.5
+    bc = torch.randn(Co, generator=g).cuda()
+    wk = U._padk16(U._conv3_rows_3(wc), split=False).cuda()
+    Mo = B * 4 * Hs * Ws
+    o = torch.zeros(Mo, Co, device="cuda")
+    zeros = torch.zeros(4096, dtype=torch.half, device="cuda")
+    ops.gemm(A=u1, W=wk, bias=bc, out=o, zeros=zeros, M=Mo, N=Co, ldc=Co, amode=ops.UD_A_CONV3_ZERO, epi=ops.UD_EPI_F32, Himg=2 * Hs, Wimg=2 * Ws,
+             cstride=2 * Cc, coff=0, rows_img=4 * Hs * Ws, img_stride=4 * Hs * Ws * 2 * Cc, **U._wk(wk, 0, Cc))
+    refc = F.conv2d(up, wc.double().cuda(), bc.double(), padding=1).permute(0, 2, 3, 1).reshape(Mo, Co)
+    torch.cuda.synchronize()
+    ec = rel(o, refc)
+    print(f"3x3 on the interpolated map: three-term {ec:.2e}")
+    assert ec < 3e-6, ec
+
+
 def test_v1_sh_embed(ops):
     from unidepth_amd import _lib as L
     from oracle import restate_v1

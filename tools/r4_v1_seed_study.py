@@ -77,10 +77,16 @@ def main():
     else:
         FC1 = {}
     ENG = {**W_ALL, **FC1}
+    if os.environ.get("BASEFIX") == "1":           # the round-4 three-term tail (up*.up.0 / up*.up.2 / out* exact in A) as the starting point
+        ENG.update({f"depth_layer.up{s_}.up.{j}": "x" for s_ in (8, 4, 2) for j in (0, 2)})
+        ENG.update({f"depth_layer.out{s_}": "x" for s_ in (8, 4, 2)})
     run("engine as built (split weights, ConvNeXt fc1 single)", ENG)
     run("weights split everywhere", W_ALL)
     run("encoder exact, decoder as built", {**ENG, "pixel_encoder": "x"})
     run("decoder exact, encoder as built", {**{"": "x"}, **{k: v for k, v in ENG.items() if k.startswith("pixel_encoder")}, "pixel_encoder": "w", **FC1})
+    if arch == "vitl14":
+        for grp in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2", "attn"):
+            run(f"as built, encoder {grp} exact", {**ENG, **{f"pixel_encoder.blocks.{i}.{grp}": "x" for i in range(24)}})
     for grp in ("depth_layer.aggregate_16", "depth_layer.prompt_camera", "depth_layer.layers_16", "depth_layer.layers_8", "depth_layer.layers_4",
                 "depth_layer.up", "depth_layer.out", "depth_layer.project_rays", "input_adapter", "features_channel_cat", "to_latents", "token_adapter"):
         run(f"as built, {grp} exact", {**ENG, grp: "x"})

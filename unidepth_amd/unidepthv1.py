@@ -45,7 +45,10 @@ def _rup(x, m):
 # k_chunk + ud_attention_merge_f32) and softmax(q k_l^T) (pinv(kernel_2) kernel_3 v) as plain flash attention over the 128 landmarks.
 # UNIDEPTH_V1_NYS_FLASH=0: the first form (GEMM -> row softmax -> GEMM through fp32 score matrices in HBM), kept for A/B runs.
 NYS_FLASH = os.environ.get("UNIDEPTH_V1_NYS_FLASH", "1") != "0"
-_WSPLIT_ENV = os.environ.get("UNIDEPTH_V1_WSPLIT", "1")
+# UNIDEPTH_V1_WSPLIT: "all" (default since round 4) = every GEMM weight as two fp16 terms; "1" = the round-3 placement (the ConvNeXt blocks'
+# fc1 weights single fp16: -6.9 % time, but over 8 checkpoint seeds a global depth shift of up to 8.6e-4 and the one case of the sweep
+# left above 1e-3; measured 16 of 16 within the bar, worst 7.9e-4, with them split: DESIGN 10.3b); "0" = single fp16 weights everywhere.
+_WSPLIT_ENV = os.environ.get("UNIDEPTH_V1_WSPLIT", "all")
 WSPLIT = _WSPLIT_ENV != "0"
 WSPLIT_CONVNEXT_FC1 = _WSPLIT_ENV == "all"
 # Third product term (round 4): the A operand of the ConvUpsample tails (conv1x1 -> bilinear x2 -> conv3x3, layers/upsample.py:
