@@ -48,6 +48,9 @@
 #ifndef UD_ATTN_MFMASUM
 #define UD_ATTN_MFMASUM 0          // NOMAX only: row sums by v_mfma_f32_4x4x4_16b_f16 (A = ones) instead of 32 v_add_f32 per tile
 #endif
+#ifndef UD_ATTN_QB
+#define UD_ATTN_QB 1            // 32-row query blocks per WAVE (product path, MODE 1): 2 = every K / V^T fragment read from LDS feeds two MFMAs, and a staged
+#endif                          // tile serves 256 query rows -- half the ds_reads, DMA instructions and barriers per FLOP at ~2x the registers (2 waves per SIMD)
 #ifndef UD_ATTN_MINW
 #define UD_ATTN_MINW 1          // minimum waves per SIMD promised to the register allocator (4 = cap the kernel at 128 VGPRs)
 #endif
@@ -95,8 +98,9 @@ constexpr int STAGE = KS_BYTES + VS_BYTES;
 // SPLIT: split-key mode (UdAttention.k_chunk / part): the workgroup covers ONE chunk of the keys and leaves its un-normalised accumulators,
 // running maximum and row sum in `part`; attention_merge_kernel combines the chunks.  For few queries against many keys (the Nystrom
 // kernel_3 product: 128 landmark queries x up to 19200 keys per (image, head) -- one workgroup per pair would walk 300 key tiles alone).
-template <int ABL, int MODE, int NW = 4, bool SPLIT = false>
+template <int ABL, int MODE, int NW = 4, bool SPLIT = false, int QB = 1>
 __global__ __launch_bounds__(NW * 64, UD_ATTN_MINW) void attention_kernel(const UdAttention p, const float defer_thr) {
+  static_assert(QB == 1 || (MODE == 1 && !SPLIT && !UD_ATTN_NOMAX && !UD_ATTN_SPLIT_SM && !UD_ATTN_OAGPR && ABL == 0), "QB > 1: the product MODE 1 path only");
   constexpr int NST = UD_ATTN_NSTAGE;
   __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
   const int tid = threadIdx.x;
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(NW * 64, UD_ATTN_MINW) void attention_kernel(const 
   // (2 x 175 KB at N = 1370), so all of them go to ONE XCD, in consecutive dispatch slots -- with the natural 3-D grid they
   // were spread over all 8 private L2s and every XCD pulled nearly every K/V through the fabric (rocprofv3 FETCH_SIZE
   // 403 MB per launch against 67 MB of unique Q/K/V: the kernel ran at the fabric read rate, 4.1 TB/s, not at MFMA rate).
-  const int qt = (p.Nq + NW * 32 - 1) / (NW * 32);
+  const int qt = (p.Nq + NW * 32 * QB - 1) / (NW * 32 * QB);
   const int pairs = p.B * p.H;
   const int nt = (p.Nk + KT - 1) / KT;
   const int tpc = SPLIT ? p.k_chunk / KT : nt;            // key tiles per chunk
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(NW * 64, UD_ATTN_MINW) void attention_kernel(const 
   const int kimg = p.kv_broadcast ? (p.kv_group > 0 ? img / p.kv_group : 0) : img;
   const int rem = slot % (qt * nc);
   const int chunk = rem / qt;
-  const int q0 = (rem % qt) * (NW * 32) + wv * 32;
+  const int q0 = (rem % qt) * (NW * 32 * QB) + wv * (32 * QB);
   const int kt0 = chunk * tpc;
   const int kt1 = SPLIT ? (kt0 + tpc < nt ? kt0 + tpc : nt) : nt;
 
@@ -130,13 +134,14 @@ __global__ __launch_bounds__(NW * 64, UD_ATTN_MINW) void attention_kernel(const 
   const half_t* Vt = (const half_t*)p.Vt + ((size_t)kimg * p.H + head) * 64 * (size_t)p.kv_ld;
 
   // ---- Q fragments (B operand): q = ql, d = ks*16 + hh*8 .. +8
-  half8 qf[4];
-  {
-    int qr = q0 + ql;
+  half8 qf[QB][4];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    int qr = q0 + qb * 32 + ql;
     qr = qr < p.Nq ? qr : p.Nq - 1;
     const half_t* qp = Q + ((size_t)img * p.q_rows_per_img + qr) * p.ldq + head * 64 + hh * 8;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const half8*)(qp + ks * 16);
+    for (int ks = 0; ks < 4; ++ks) qf[qb][ks] = *(const half8*)(qp + ks * 16);
   }
 
   // ---- tile loader: 512 16-byte chunks per operand tile = 8 wave-instructions of 8 rows x 128 B; wave w issues pieces 2w, 2w+1.
@@ -165,13 +170,21 @@ __global__ __launch_bounds__(NW * 64, UD_ATTN_MINW) void attention_kernel(const 
     }
   };
 
-  f32x16 o[2];
+  f32x16 oq[QB][2];
+  float m_q[QB], l_q[QB];
 #pragma unroll
-  for (int db = 0; db < 2; ++db)
+  for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[db][r] = 0.0f;
-  float m_i = MODE ? 0.0f : -1.0e30f;
-  float l_i = 0.0f;
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oq[qb][db][r] = 0.0f;
+    m_q[qb] = MODE ? 0.0f : -1.0e30f;
+    l_q[qb] = 0.0f;
+  }
+  // the one-block forms below (variants, ablations, split-key mode) keep their names: block 0
+  f32x16 (&o)[2] = oq[0];
+  float& m_i = m_q[0];
+  float& l_i = l_q[0];
   const float c = p.scale * 1.4426950408889634f;
 
   // ring prologue: tiles kt0 .. kt0 + NST - 2 go out, all of them awaited once (a few hundred ns per workgroup, off the per-tile path)
@@ -198,6 +211,107 @@ __global__ __launch_bounds__(NW * 64, UD_ATTN_MINW) void attention_kernel(const 
     const char* sb = smem + ((ABL & 8) ? 0 : (CS >= 0 ? CS : st_cur)) * STAGE;
     UD_ATT_STAMP(1);                                       // [0] DMA issue
 
+    if constexpr (QB > 1) {
+      // ================= QB query blocks per wave (MODE 1): every K / V^T fragment read from LDS feeds QB MFMAs =================
+      f32x16 sq[QB][2];
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sq[qb][kb][r] = -m_q[qb];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const char* kp = sb + (kb * 32 + ql) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const half8 kf = *(const half8*)(kp + (((ks * 2 + hh) ^ kswz) << 4));
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) sq[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[qb][ks], sq[qb][kb], 0, 0, 0);
+        }
+      }
+      if (kt == nt - 1 && (p.Nk & (KT - 1))) {           // key tail (last tile only)
+        const int kbase = kt * KT + 4 * hh;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kbase + kb * 32 + (r & 3) + 8 * (r >> 2);
+            if (key >= p.Nk) {
+#pragma unroll
+              for (int qb = 0; qb < QB; ++qb) sq[qb][kb][r] = -1.0e30f;
+            }
+          }
+      }
+      // per block: how far the tile's row maximum exceeds the running offset (scores are S - m already); deferred like the one-block form
+      float mtq[QB];
+      float mmax = -1.0e30f;
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        float mt = sq[qb][0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) mt = fmaxf(fmaxf(mt, sq[qb][kb][r]), sq[qb][kb][r + 1]);
+        mtq[qb] = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        mmax = fmaxf(mmax, mtq[qb]);
+      }
+      if (kt == kt0 || __any(mmax > defer_thr)) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          const float d = kt == kt0 ? mtq[qb] : fmaxf(mtq[qb], 0.0f);
+          m_q[qb] += d;
+          if (kt != kt0) {                                 // first tile: O and l are still zero (and exp2(-d) may overflow)
+            const float alpha = __builtin_amdgcn_exp2f(-d);
+            l_q[qb] *= alpha;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) oq[qb][db][r] *= alpha;
+          }
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sq[qb][kb][r] -= d;
+        }
+      }
+      half8 pfq[QB][2][2];
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        float ls = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+              f32x2 pv;
+              pv[0] = __builtin_amdgcn_exp2f(sq[qb][kb][t * 8 + e]);
+              pv[1] = __builtin_amdgcn_exp2f(sq[qb][kb][t * 8 + e + 1]);
+              ls += pv[0] + pv[1];
+              const half2v ph = __builtin_convertvector(pv, half2v);
+              pfq[qb][kb][t][e] = ph[0];
+              pfq[qb][kb][t][e + 1] = ph[1];
+            }
+        l_q[qb] += ls;
+      }
+      // ---- O^T += V^T P^T, every V^T fragment for all blocks
+      const char* vs = sb + KS_BYTES;
+      if constexpr (!UD_ATTN_NOPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const char* vrow = vs + (db * 32 + ql) * 128;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const half8 vf = *(const half8*)(vrow + ((((kb * 2 + t) * 2 + hh) ^ kswz) << 4));
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) oq[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pfq[qb][kb][t], oq[qb][db], 0, 0, 0);
+          }
+      }
+      if constexpr (!UD_ATTN_NOPRIO) __builtin_amdgcn_s_setprio(0);
+    } else {
     // ---- S^T = K Q^T  (two 32-key blocks), MODE >= 1: minus the running offset m_i
     f32x16 s[2];
     auto scores = [&]() {
@@ -213,7 +327,7 @@ __global__ __launch_bounds__(NW * 64, UD_ATTN_MINW) void attention_kernel(const 
             asm volatile("" ::"v"(kf));
             s[kb][ks] += (float)kf[0];
           } else {
-            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kb], 0, 0, 0);
+            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[0][ks], s[kb], 0, 0, 0);
           }
         }
       }
@@ -465,6 +579,8 @@ __global__ __launch_bounds__(NW * 64, UD_ATTN_MINW) void attention_kernel(const 
     if constexpr (!UD_ATTN_NOPRIO) __builtin_amdgcn_s_setprio(0);
     }
 
+    }   // QB == 1
+
 #if UD_ATTN_TRACE
     UD_ATT_STAMP(4);                                       // [3] V^T fragment reads + P V MFMAs issued (the last MFMAs may still run)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -504,6 +620,27 @@ __global__ __launch_bounds__(NW * 64, UD_ATTN_MINW) void attention_kernel(const 
     atomicAdd(ud_attn_trace_ptr + 6, (unsigned long long)(kt1 - kt0));
   }
 #endif
+  if constexpr (QB > 1) {
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      const float lt = l_q[qb] + __shfl_xor(l_q[qb], 32, 64);
+      const float inv = 1.0f / lt;
+      const int qr = q0 + qb * 32 + ql;
+      if (qr < p.Nq) {
+        half_t* op = (half_t*)p.O + ((size_t)img * p.q_rows_per_img + qr) * p.ldo + head * 64 + 4 * hh;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            half4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = (half_t)(oq[qb][db][g * 4 + e] * inv);
+            *(half4*)(op + db * 32 + g * 8) = h;
+          }
+      }
+    }
+    return;
+  }
   const float l_tot = l_i + __shfl_xor(l_i, 32, 64);
   const int qr = q0 + ql;
   if constexpr (SPLIT) {
@@ -594,7 +731,9 @@ extern "C" int ud_attention_f16(const UdAttention* desc, void* stream) {
   // K / V staging traffic buys nothing (105 instead of 124 VGPRs, same 16 waves per CU), and 6 tiles of 256 rows waste 5 of 48 wave slots
   // per (image, head) where 11 tiles of 128 rows waste 1 of 44.  The product builds the 4-wave form.
   const bool wide = UD_ATTN_NW == 8 && d.Nq >= 512 && !split;
-  const int rows_wg = wide ? 256 : 128;
+  // UD_ATTN_QB query blocks per wave on the pre-scaled (encoder / decoder MODE 1) path when the query sequence is long enough to fill the chip
+  const bool multi = UD_ATTN_QB > 1 && d.q_prescaled && !split && !wide && d.Nq >= 512;
+  const int rows_wg = (wide ? 256 : 128) * (multi ? UD_ATTN_QB : 1);
   const int qt = (d.Nq + rows_wg - 1) / rows_wg, pairs = d.B * d.H;
   const int ntile = (d.Nk + 63) / 64;
   const int nc = split ? (ntile + d.k_chunk / 64 - 1) / (d.k_chunk / 64) : 1;
@@ -619,6 +758,10 @@ extern "C" int ud_attention_f16(const UdAttention* desc, void* stream) {
   if (wide) {
     if (d.q_prescaled) hipLaunchKernelGGL((attention_kernel<0, UD_ATTN_PRE_MODE, 8>), grid, dim3(512), extra_lds, (hipStream_t)stream, d, thr);
     else hipLaunchKernelGGL((attention_kernel<0, 0, 8>), grid, dim3(512), extra_lds, (hipStream_t)stream, d, thr);
+  } else if (multi) {
+#if UD_ATTN_QB > 1
+    hipLaunchKernelGGL((attention_kernel<0, 1, 4, false, UD_ATTN_QB>), grid, dim3(256), extra_lds, (hipStream_t)stream, d, thr);
+#endif
   } else if (d.q_prescaled) hipLaunchKernelGGL((attention_kernel<0, UD_ATTN_PRE_MODE>), grid, dim3(256), extra_lds, (hipStream_t)stream, d, thr);
   else hipLaunchKernelGGL((attention_kernel<0, 0>), grid, dim3(256), extra_lds, (hipStream_t)stream, d, thr);
 #endif
