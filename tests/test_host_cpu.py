@@ -485,3 +485,41 @@ def test_v1_plan_builder_dry_run_validates_every_gemm_descriptor(monkeypatch):
     assert not bad, bad[:3]                                    # UD_ERR_BAD_ARG would mean a descriptor the kernels refuse
     three = [r for r in seen if r[5] and (3 * r[5] == 2 * r[4] or (r[6] and 3 * r[5] == 2 * r[6]))]
     assert len(three) == 9, three                              # up{8,4,2}.up.0, up{8,4,2}.up.2, out{8,4,2}
+
+
+def test_v2_plan_builder_dry_run_side_branch_and_descriptors(monkeypatch):
+    """The UniDepthV2 launch program recorded on the host (nothing runs): every GEMM descriptor passes the C side's argument validation, and
+    the decoder starts with the two branches the program's side stream separates -- camera head + rays + ray embedding between
+    side.begin / side.end, the feature adapters / LayerNorm / q projection between side.end / side.join, the K / V projection of the
+    ray embedding right behind the join (ud_program_add_side)."""
+    import contextlib
+    from oracle import synth
+    from unidepth_amd import UniDepthV2, _lib, ops
+    from unidepth_amd.weights import pack
+    if torch.cuda.is_available():
+        pytest.skip("host-only dry run")
+    cfg = synth.load_config("vits14")
+    m = UniDepthV2(cfg).load_state_dict(synth.make_synthetic_checkpoint(cfg, 3))
+    dev = torch.device("cpu")
+    m._w = pack(cfg, m._sd, dev)
+    m._device = dev
+    m.resolution_level = 2
+    monkeypatch.setenv("UNIDEPTH_SIDE", "1")                   # the branch form (off by default: measured neutral, DESIGN 10.5)
+    monkeypatch.setattr(torch.cuda, "device", lambda d: contextlib.nullcontext())
+    monkeypatch.setattr(ops, "ptr", lambda t: None if t is None else (t if isinstance(t, int) else t.data_ptr()))
+    real_add, seen = _lib.lib.ud_program_add_gemm, []
+
+    def add(h, dref):
+        rc = _lib.lib.ud_gemm_f16(dref, None)
+        seen.append((rc, _lib.lib.ud_last_error().decode() if rc else ""))
+        return real_add(h, dref)
+    monkeypatch.setattr(ops.lib, "ud_program_add_gemm", add)
+    plan = m._plan(1, 462, 616, 0, True, True)
+    assert len(seen) > 60 and not [r for r in seen if r[0] != -2], [r for r in seen if r[0] != -2][:3]     # -2 = UD_ERR_LAUNCH: arguments accepted
+    tags = [t[1] for t in plan.prog.meta]
+    i0, i1, i2 = tags.index("side.begin"), tags.index("side.end"), tags.index("side.join")
+    assert plan.dec_first == plan.enc_last == i0 and tags.count("side.begin") == 1
+    cam = tags[i0 + 1:i1]
+    assert cam.count("cam.adapter") == 4 and cam[-2:] == ["rays", "ray_embed"] and "camera_intrinsics" in cam and not any(t.startswith("dec.") or t.startswith("dh.") for t in cam)
+    assert tags[i1 + 1:i2] == ["dec.adapters(x4)", "layernorm", "dh.q(x4)"] and tags[i2 + 1] == "dh.kv(x4)"
+    assert ops.lib.ud_program_add_side(plan.prog.h, 3) < 0                                                # unknown mode: refused

@@ -166,6 +166,7 @@ def _load():
         "ud_knn_points": [P(UdKnn), vp],
         "ud_knn_split": [P(UdKnn)],
         "ud_extract_patches": [P(UdExtractPatches), vp],
+        "ud_program_add_side": [vp, i32],
         "ud_program_run": [vp, i32, i32, vp],
         "ud_program_run_graph": [vp, i32, i32, vp],
         "ud_program_graph_count": [vp],

@@ -15,7 +15,7 @@
 void ud_set_error(const char* msg);
 
 namespace {
-enum Kind { K_LIN32, K_ATTS, K_GEMM, K_LN, K_ATTN, K_PRE, K_FILL, K_CAM, K_RAYS, K_RAYS_CAM, K_EMBED, K_UP2, K_RESIZE, K_FINAL, K_T, K_DW7, K_LNP2, K_PATCH4, K_MAX, K_MEAN, K_V1, K_RSF };
+enum Kind { K_LIN32, K_ATTS, K_GEMM, K_LN, K_ATTN, K_PRE, K_FILL, K_CAM, K_RAYS, K_RAYS_CAM, K_EMBED, K_UP2, K_RESIZE, K_FINAL, K_T, K_DW7, K_LNP2, K_PATCH4, K_MAX, K_MEAN, K_V1, K_RSF, K_SIDE };
 struct FillArgs { float* dst; const float* src; int n_img, rows_per_img, row_off, D, ld; };
 struct CamArgs { const float* raw; int raw_stride; float* intr4; float* K33; float* Kinv33; float* Kpost33; int B, Hn, Wn; float rf; int pad_l, pad_t; };
 struct RaysArgs { const float* Kinv33; float* rays; int nb, Hn, Wn, gt_mode; };
@@ -32,7 +32,7 @@ struct Op {
   union {
     UdGemm gemm; UdLayerNorm ln; UdAttention attn; UdPreprocess pre; FillArgs fill; CamArgs cam; RaysArgs rays; RaysCamArgs rays_cam;
     UdRayEmbed embed; UdUpsample2x up2; UdResizeAC resize; UdFinalize fin; TArgs t; UdLinearF32 lin32; AttSArgs atts;
-    UdDwConv7 dw7; UdV1Op v1; LnP2Args lnp2; Patch4Args patch4; MaxArgs mx; MeanArgs mean; RsfArgs rsf;
+    UdDwConv7 dw7; UdV1Op v1; LnP2Args lnp2; Patch4Args patch4; MaxArgs mx; MeanArgs mean; RsfArgs rsf; int side;
   };
   Op() {}
 };
@@ -42,6 +42,10 @@ struct UdGraph { hipGraphExec_t exec = nullptr; int device = -1; int runs = 0; }
 struct UdProgram {
   std::vector<Op> ops;
   std::map<std::pair<int, int>, UdGraph> graphs;      // (first, last) -> instantiated graph of that range
+  // side branch (ud_program_add_side): a second stream of this program and the two events that fork it from / join it to the caller's
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int side_device = -1;
 };
 
 extern "C" {
@@ -51,8 +55,14 @@ static void drop_graphs(UdProgram* p) {
     if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
   p->graphs.clear();
 }
+static void drop_side(UdProgram* p) {
+  if (p->side) (void)hipStreamDestroy(p->side);
+  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+  if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+  p->side = nullptr; p->ev_fork = p->ev_join = nullptr; p->side_device = -1;
+}
 void ud_program_destroy(UdProgram* p) {
-  if (p) drop_graphs(p);
+  if (p) { drop_graphs(p); drop_side(p); }
   delete p;
 }
 int ud_program_size(const UdProgram* p) { return p ? (int)p->ops.size() : 0; }
@@ -120,39 +130,96 @@ int ud_program_add_row_stats_finalize(UdProgram* p, const float* partials, float
   RsfArgs a = {partials, stats, M, slabs, D, eps};
   ADD(K_RSF, rsf, a)
 }
+// Side branch of a program: independent launch chains of one forward pass on two HIP streams (the V2 camera head -- ~25 dependent launches
+// of a few workgroups each -- beside the decoder's adapter GEMMs, which do not depend on the camera).
+//   mode 0  BEGIN  the ops that follow run on the program's side stream, ordered behind everything recorded so far (event fork)
+//   mode 1  END    the ops that follow run on the caller's stream again; the side branch keeps running
+//   mode 2  JOIN   the caller's stream waits for the side branch (event join); a no-op when nothing is outstanding
+// A replayed RANGE that starts inside a branch runs those ops on the caller's stream (correct, just serial); a range that ends before the
+// JOIN is joined at its end, so a caller that synchronises its stream sees all the work of the range.  The two branches must write
+// disjoint buffers: results are then bit-identical to the one-stream replay.
+int ud_program_add_side(UdProgram* p, int mode) {
+  if (mode < 0 || mode > 2) return UD_ERR_BAD_ARG;
+  ADD(K_SIDE, side, mode)
+}
 
-int ud_program_run(const UdProgram* p, int first, int last, void* stream) {
+static int side_setup(UdProgram* p) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return UD_ERR_LAUNCH;
+  if (p->side && p->side_device == dev) return UD_OK;
+  drop_side(p);
+  if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess) {
+    drop_side(p);
+    ud_set_error("ud_program_run: cannot create the side stream / events of a program");
+    return UD_ERR_LAUNCH;
+  }
+  p->side_device = dev;
+  return UD_OK;
+}
+
+int ud_program_run(const UdProgram* cp, int first, int last, void* stream) {
+  UdProgram* p = const_cast<UdProgram*>(cp);           // the side stream and its events are created on first use
   if (!p || first < 0 || last > (int)p->ops.size() || first > last) { ud_set_error("ud_program_run: bad range"); return UD_ERR_BAD_ARG; }
+  hipStream_t main_s = (hipStream_t)stream;
+  void* cur = stream;
+  bool outstanding = false;                             // side work issued in this range and not yet joined
+  auto join = [&]() -> int {
+    if (!outstanding) return UD_OK;
+    if (hipEventRecord(p->ev_join, p->side) != hipSuccess || hipStreamWaitEvent(main_s, p->ev_join, 0) != hipSuccess) {
+      ud_set_error("ud_program_run: joining the side branch failed");
+      return UD_ERR_LAUNCH;
+    }
+    outstanding = false;
+    return UD_OK;
+  };
   for (int i = first; i < last; ++i) {
     const Op& op = p->ops[i];
     int rc = UD_OK;
     switch (op.kind) {
-      case K_GEMM: rc = ud_gemm_f16(&op.gemm, stream); break;
-      case K_LIN32: rc = ud_linear_f32(&op.lin32, stream); break;
-      case K_ATTS: rc = ud_attention_small_f32(op.atts.q, op.atts.kv, op.atts.out, op.atts.B, op.atts.T, op.atts.H, op.atts.C, op.atts.scale, stream); break;
-      case K_LN: rc = ud_layernorm_f32_f16(&op.ln, stream); break;
-      case K_ATTN: rc = ud_attention_f16(&op.attn, stream); break;
-      case K_PRE: rc = ud_preprocess_patches(&op.pre, stream); break;
-      case K_FILL: rc = ud_fill_rows_f32(op.fill.dst, op.fill.src, op.fill.n_img, op.fill.rows_per_img, op.fill.row_off, op.fill.D, op.fill.ld, stream); break;
-      case K_CAM: rc = ud_camera_intrinsics(op.cam.raw, op.cam.raw_stride, op.cam.intr4, op.cam.K33, op.cam.Kinv33, op.cam.Kpost33, op.cam.B, op.cam.Hn, op.cam.Wn, op.cam.rf, op.cam.pad_l, op.cam.pad_t, stream); break;
-      case K_RAYS: rc = ud_rays_from_kinv(op.rays.Kinv33, op.rays.rays, op.rays.nb, op.rays.Hn, op.rays.Wn, op.rays.gt_mode, stream); break;
-      case K_RAYS_CAM: rc = ud_rays_from_camera(op.rays_cam.params, op.rays_cam.rays, op.rays_cam.scratch, op.rays_cam.Hn, op.rays_cam.Wn, op.rays_cam.model, stream); break;
-      case K_EMBED: rc = ud_ray_embed(&op.embed, stream); break;
-      case K_UP2: rc = ud_upsample2x_nhwc(&op.up2, stream); break;
-      case K_RESIZE: rc = ud_resize_ac_nhwc_f16(&op.resize, stream); break;
-      case K_FINAL: rc = ud_finalize_outputs(&op.fin, stream); break;
-      case K_DW7: rc = ud_dwconv7_nhwc_f32(&op.dw7, stream); break;
-      case K_V1: rc = ud_v1_op(&op.v1, stream); break;
-      case K_LNP2: rc = ud_layernorm_patchify2(op.lnp2.x, op.lnp2.out, op.lnp2.B, op.lnp2.H, op.lnp2.W, op.lnp2.C, op.lnp2.ldo, op.lnp2.eps, stream); break;
-      case K_PATCH4: rc = ud_patchify4_nchw(op.patch4.img, op.patch4.out, op.patch4.B, op.patch4.H, op.patch4.W, op.patch4.ldo, stream); break;
-      case K_MAX: rc = ud_max_f32(op.mx.dst, op.mx.src, op.mx.n, op.mx.init, stream); break;
-      case K_MEAN: rc = ud_spatial_mean_f32(op.mean.x, op.mean.out, op.mean.B, op.mean.HW, op.mean.C, op.mean.ldo, stream); break;
-      case K_RSF: rc = ud_row_stats_finalize(op.rsf.part, op.rsf.stats, op.rsf.M, op.rsf.slabs, op.rsf.D, op.rsf.eps, stream); break;
-      case K_T: rc = ud_nhwc_to_nchw_f32(op.t.in, op.t.out, op.t.B, op.t.hw, op.t.C, op.t.ld, op.t.rows_per_img, stream); break;
+      case K_SIDE:
+        if (op.side == 0) {
+          if ((rc = side_setup(p)) != UD_OK) break;
+          if (hipEventRecord(p->ev_fork, main_s) != hipSuccess || hipStreamWaitEvent(p->side, p->ev_fork, 0) != hipSuccess) {
+            ud_set_error("ud_program_run: forking the side branch failed");
+            rc = UD_ERR_LAUNCH;
+            break;
+          }
+          cur = (void*)p->side;
+          outstanding = true;
+        } else if (op.side == 1) {
+          cur = stream;
+        } else {
+          cur = stream;
+          rc = join();
+        }
+        break;
+      case K_GEMM: rc = ud_gemm_f16(&op.gemm, cur); break;
+      case K_LIN32: rc = ud_linear_f32(&op.lin32, cur); break;
+      case K_ATTS: rc = ud_attention_small_f32(op.atts.q, op.atts.kv, op.atts.out, op.atts.B, op.atts.T, op.atts.H, op.atts.C, op.atts.scale, cur); break;
+      case K_LN: rc = ud_layernorm_f32_f16(&op.ln, cur); break;
+      case K_ATTN: rc = ud_attention_f16(&op.attn, cur); break;
+      case K_PRE: rc = ud_preprocess_patches(&op.pre, cur); break;
+      case K_FILL: rc = ud_fill_rows_f32(op.fill.dst, op.fill.src, op.fill.n_img, op.fill.rows_per_img, op.fill.row_off, op.fill.D, op.fill.ld, cur); break;
+      case K_CAM: rc = ud_camera_intrinsics(op.cam.raw, op.cam.raw_stride, op.cam.intr4, op.cam.K33, op.cam.Kinv33, op.cam.Kpost33, op.cam.B, op.cam.Hn, op.cam.Wn, op.cam.rf, op.cam.pad_l, op.cam.pad_t, cur); break;
+      case K_RAYS: rc = ud_rays_from_kinv(op.rays.Kinv33, op.rays.rays, op.rays.nb, op.rays.Hn, op.rays.Wn, op.rays.gt_mode, cur); break;
+      case K_RAYS_CAM: rc = ud_rays_from_camera(op.rays_cam.params, op.rays_cam.rays, op.rays_cam.scratch, op.rays_cam.Hn, op.rays_cam.Wn, op.rays_cam.model, cur); break;
+      case K_EMBED: rc = ud_ray_embed(&op.embed, cur); break;
+      case K_UP2: rc = ud_upsample2x_nhwc(&op.up2, cur); break;
+      case K_RESIZE: rc = ud_resize_ac_nhwc_f16(&op.resize, cur); break;
+      case K_FINAL: rc = ud_finalize_outputs(&op.fin, cur); break;
+      case K_DW7: rc = ud_dwconv7_nhwc_f32(&op.dw7, cur); break;
+      case K_V1: rc = ud_v1_op(&op.v1, cur); break;
+      case K_LNP2: rc = ud_layernorm_patchify2(op.lnp2.x, op.lnp2.out, op.lnp2.B, op.lnp2.H, op.lnp2.W, op.lnp2.C, op.lnp2.ldo, op.lnp2.eps, cur); break;
+      case K_PATCH4: rc = ud_patchify4_nchw(op.patch4.img, op.patch4.out, op.patch4.B, op.patch4.H, op.patch4.W, op.patch4.ldo, cur); break;
+      case K_MAX: rc = ud_max_f32(op.mx.dst, op.mx.src, op.mx.n, op.mx.init, cur); break;
+      case K_MEAN: rc = ud_spatial_mean_f32(op.mean.x, op.mean.out, op.mean.B, op.mean.HW, op.mean.C, op.mean.ldo, cur); break;
+      case K_RSF: rc = ud_row_stats_finalize(op.rsf.part, op.rsf.stats, op.rsf.M, op.rsf.slabs, op.rsf.D, op.rsf.eps, cur); break;
+      case K_T: rc = ud_nhwc_to_nchw_f32(op.t.in, op.t.out, op.t.B, op.t.hw, op.t.C, op.t.ld, op.t.rows_per_img, cur); break;
     }
-    if (rc != UD_OK) return rc;
+    if (rc != UD_OK) { (void)join(); return rc; }
   }
-  return UD_OK;
+  return join();
 }
 
 // Replay ops [first, last) through a hipGraph.  Replay 1 of a range runs eagerly (module loads, one-time hipFuncSetAttribute calls and the

@@ -114,11 +114,16 @@ class Program:
         tiles = -(-kw["M"] // 128) * -(-n // 128)
         if (g == 1 and kw.get("amode", 0) == UD_A_DENSE and kw.get("epi", 0) in (UD_EPI_F16, UD_EPI_F32) and tiles <= 128
                 and kw["K"] >= 1024 and kw["K"] % 128 == 0 and "splitk_ws" not in kw):
-            if self._splitk is None:           # small problems (small batches): see UdGemm.splitk_ws in include/unidepth_hip.h
+            # small problems (small batches): see UdGemm.splitk_ws in include/unidepth_hip.h.  One workspace per BRANCH of the program: launches
+            # of the side branch (Program.side) run concurrently with the caller's stream and must not share partial-sum storage with it
+            key = 1 if getattr(self, "_in_side", False) else 0
+            if not isinstance(self._splitk, dict):
+                self._splitk = {}
+            if key not in self._splitk:
                 dev = kw["A"].device
-                self._splitk = (torch.empty(256 * 16384, dtype=torch.float32, device=dev), torch.zeros(128, dtype=torch.int32, device=dev))
-                self.keep += list(self._splitk)
-            kw["splitk_ws"], kw["splitk_cnt"] = self._splitk
+                self._splitk[key] = (torch.empty(256 * 16384, dtype=torch.float32, device=dev), torch.zeros(128, dtype=torch.int32, device=dev))
+                self.keep += list(self._splitk[key])
+            kw["splitk_ws"], kw["splitk_cnt"] = self._splitk[key]
         d = mk(UdGemm, **kw)
         pick, epi, amode = lib.ud_gemm_pick(C.byref(d)), kw.get("epi", 0), kw.get("amode", 0)
         lnc, grp = "true" if pick & 16 else "false", "true" if pick & 32 else "false"
@@ -239,6 +244,12 @@ class Program:
         self.keep += [t for t in (a, b, c, out, out2) if isinstance(t, torch.Tensor)]
         self.meta.append(("v1." + tag, tag, 0.0, 0.0))
         return check(lib.ud_program_add_v1_op(self.h, C.byref(v1_desc(kind, a, b, c, out, out2, i, f))))
+
+    def side(self, mode):
+        """Side branch marker (include/unidepth_hip.h ud_program_add_side): 0 begin, 1 end, 2 join."""
+        self.meta.append(("side", ("side.begin", "side.end", "side.join")[mode], 0.0, 0.0))
+        self._in_side = mode == 0
+        return check(lib.ud_program_add_side(self.h, int(mode)))
 
     def run(self, first=0, last=None, stream=None, graph=False):
         """Replay ops [first, last) on the current (or given) stream; graph=True: through ud_program_run_graph (eager the first time the

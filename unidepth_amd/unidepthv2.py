@@ -224,12 +224,28 @@ class _Plan:
         Md = B * hwp
         feat_all = z(4, Md, C, dtype=f32)
         ct = z(B * 4, C, dtype=f32)
-        P.gemm(A=featn_all, W=w["dec.adapterg.w"], bias=w["dec.adapterg.b"], out=feat_all, M=Md, N=C, K=D, lda=D, ldw=D, ldc=C,
-               epi=UD_EPI_F32, groups=4, gA=Md * D, gW=C * D, gBias=C, gOut=Md * C, tag="dec.adapters(x4)",
-               **({"tile_hint": 1} if os.environ.get("UNIDEPTH_GRP_BIG", "1") == "0" else {}))
+        # Two independent launch chains start here: the CAMERA branch (4 token adapters, the fp32 camera head, intrinsics, rays, ray embedding:
+        # ~30 dependent launches of a few workgroups each, 0.35-0.45 ms when run alone) and the FEATURE branch (the grouped adapter GEMM, its
+        # LayerNorm, the q projection of the four cross-attention blocks: 0.16 ms of full-chip launches) -- they meet at the K / V projection
+        # of the ray embedding.  The camera branch is recorded as the program's side branch (ud_program_add_side: a second HIP stream, fork /
+        # join by events) with UNIDEPTH_SIDE=1.  Disjoint buffers: same bits (test_side_branch_bit_identical).  MEASURED (profiles/
+        # r04_side_branch_ab.txt, three interleaved rounds on one box): one-call p50 14.22 / 14.20 / 14.22 ms on one stream against 14.25 / 14.24 /
+        # 14.25 ms with the branch, 604.6-605.5 against 604.2-604.8 images/s two calls in flight -- nothing: the 0.16 ms of feature-branch launches
+        # fill every CU's LDS (144 KB per workgroup), the camera kernels wait for them to drain instead of running beside them, and the fork /
+        # join events cost what little overlap is left.  Off by default; the mechanism stays in the ABI.
+        side = os.environ.get("UNIDEPTH_SIDE", "0") == "1"
         self.dec_first = self.enc_last
-        for j in range(4):
-            tap(f"input_adapter.{j}", lambda j=j: feat_all[j].view(B, hwp, C)[:, :hw].clone())
+
+        def feature_branch_head():
+            P.gemm(A=featn_all, W=w["dec.adapterg.w"], bias=w["dec.adapterg.b"], out=feat_all, M=Md, N=C, K=D, lda=D, ldw=D, ldc=C,
+                   epi=UD_EPI_F32, groups=4, gA=Md * D, gW=C * D, gBias=C, gOut=Md * C, tag="dec.adapters(x4)",
+                   **({"tile_hint": 1} if os.environ.get("UNIDEPTH_GRP_BIG", "1") == "0" else {}))
+            for j in range(4):
+                tap(f"input_adapter.{j}", lambda j=j: feat_all[j].view(B, hwp, C)[:, :hw].clone())
+        if side:
+            P.side(0)
+        else:
+            feature_branch_head()
         for j in range(4):
             P.linear_f32(x=clsn[j], W=w[f"dec.camadapter.{j}.w"], bias=w[f"dec.camadapter.{j}.b"], out=ct.data_ptr() + j * C * 4,
                          M=B, N=C, K=D, ldx=D, ldw=D, ldc=4 * C, tag="cam.adapter")
@@ -305,9 +321,14 @@ class _Plan:
         c16_all = z(4, Md, C)
         c16 = [c16_all[j] for j in range(4)]
         G4 = dict(groups=4, **({"tile_hint": 1} if os.environ.get("UNIDEPTH_GRP_BIG", "1") == "0" else {}))      # A/B switch: 128-row blockIdx.z form
+        if side:
+            P.side(1)                                    # camera branch recorded; what follows runs beside it on the caller's stream
+            feature_branch_head()
         ln(feat_all, fn, 4 * Md)
         P.gemm(A=fn, W=w["dhg.q.w"], bias=w["dhg.q.b"], out=qd, M=Md, N=HC, K=C, lda=C, ldw=C, ldc=HC, epi=UD_EPI_F16,
                gA=Md * C, gW=HC * C, gBias=HC, gOut=Md * HC, tag="dh.q(x4)", **G4)
+        if side:
+            P.side(2)                                    # the K / V projection below reads the ray embedding of the camera branch
         P.gemm(A=emb, W=w["dhg.kv.w"], bias=w["dhg.kv.b"], out=kd, out2=vtd, M=Mk, N=2 * HC, K=C, lda=C, ldw=C, ldc=HC, epi=UD_EPI_QKV,
                vsplit=HC, tok_per_img=hwp, kv_ld=hwkp, heads_v=Hd, gA=0, gW=2 * HC * C, gBias=2 * HC, gOut=Mk * HC,
                gOut2=nb * Hd * 64 * hwkp, tag="dh.kv(x4)", **G4)
