@@ -1788,6 +1788,168 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const UdGemm p) {
   }
 }
 
+
+// ================================================================================================================
+// Head convolution with its weights in REGISTERS (round 4): the ViT-L head (N = 32, Cin = 64, 3x3 reflect over the fused align_corners
+// up-sampling, LeakyReLU + 1x1 + clip / exp epilogue) has 36 KB of weights per branch -- 9 taps x [32][64] fp16 -- and the kernel above
+// streams them through LDS per tile and tap: 9 x (wait for the slab's DMA, barrier, 16 MFMAs per wave), ~12 us per 16 x 16 tile against
+// ~1.2 us of MFMA work.  Here a PERSISTENT workgroup loads the branch's weights once into registers as MFMA fragments (36 x half8 per lane,
+// 144 VGPRs; two workgroups per CU = two waves per SIMD, 256 registers each) and walks its tiles: source patch by LDS-DMA (issued one tile
+// ahead, behind the barrier that frees the patch buffer), interpolation into the halo, then 144 MFMAs per wave with NO barrier and no DMA
+// wait between taps, epilogue.  Two barriers per tile instead of eleven; LDS 63 KB (halo + patch).
+// ================================================================================================================
+__global__ __launch_bounds__(256, 2) void conv_head_regw_kernel(const UdGemm p, const int tiles_x, const int tiles_img, const int tiles_g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;
+  char* patch = smem + HALO_BYTES;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = blockIdx.y;
+  const int px = lane & 15, fq = lane >> 4;
+  const half_t* W = (const half_t*)p.W + (long long)g * p.gW;
+  const float* bias = p.bias + (long long)g * p.gBias;
+  const float* w2 = p.w2 + (long long)g * p.gW2;
+  const float ups_sy = p.Himg > 1 ? (float)(p.Hsrc - 1) / (float)(p.Himg - 1) : 0.f;
+  const float ups_sx = p.Wimg > 1 ? (float)(p.Wsrc - 1) / (float)(p.Wimg - 1) : 0.f;
+
+  // ---- the branch's weights as B fragments: lane (px, fq) holds W[n = 16 j + px][tap * 64 + (4 ks + fq) * 8 .. + 8]
+  half8 bfr[9][2][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bfr[tap][ks][j] = *(const half8*)(W + (size_t)(j * 16 + px) * p.ldw + tap * 64 + (ks * 4 + fq) * 8);
+  // tile geometry is workgroup-uniform: kept in SGPRs (readfirstlane), the register file belongs to the weight fragments
+  struct Geo { int b, x0, y0, ylo, yhi, xlo, xhi, syA, sxA, PR, PC; };
+  auto geo = [&](int t) {
+    Geo q;
+    q.b = __builtin_amdgcn_readfirstlane(t / tiles_img);
+    const int r = t - q.b * tiles_img;
+    const int ty = __builtin_amdgcn_readfirstlane(r / tiles_x), tx = r - ty * tiles_x;
+    q.x0 = tx << 4; q.y0 = ty << 4;
+    q.ylo = q.y0 == 0 ? 0 : q.y0 - 1; q.yhi = q.y0 + 16 < p.Himg ? q.y0 + 16 : p.Himg - 1;
+    q.xlo = q.x0 == 0 ? 0 : q.x0 - 1; q.xhi = q.x0 + 16 < p.Wimg ? q.x0 + 16 : p.Wimg - 1;
+    q.syA = (int)(ups_sy * (float)q.ylo); q.sxA = (int)(ups_sx * (float)q.xlo);
+    int syB = (int)(ups_sy * (float)q.yhi) + 1, sxB = (int)(ups_sx * (float)q.xhi) + 1;
+    syB = syB < p.Hsrc ? syB : p.Hsrc - 1;
+    sxB = sxB < p.Wsrc ? sxB : p.Wsrc - 1;
+    q.syA = __builtin_amdgcn_readfirstlane(q.syA); q.sxA = __builtin_amdgcn_readfirstlane(q.sxA);
+    q.PR = __builtin_amdgcn_readfirstlane(syB - q.syA + 1); q.PC = __builtin_amdgcn_readfirstlane(sxB - q.sxA + 1);
+    return q;
+  };
+  auto issue_patch = [&](const Geo& q) {
+    const half_t* in = (const half_t*)p.A + (long long)g * p.gA + (long long)q.b * p.img_stride + p.coff;
+    const int npiece = (q.PR * q.PC * 8 + 63) >> 6;
+    for (int i = wv; i < npiece; i += 4) {
+      const int idx = i * 64 + lane;
+      int pp = idx >> 3;
+      pp = pp < q.PR * q.PC ? pp : q.PR * q.PC - 1;
+      const int pr = pp / q.PC, pc = pp - pr * q.PC;
+      ud_glds16(in + ((long long)(q.syA + pr) * p.Wsrc + q.sxA + pc) * p.cstride + ((idx & 7) << 3), patch + i * 1024);
+    }
+  };
+
+  int t = __builtin_amdgcn_readfirstlane(blockIdx.x);
+  if (t >= tiles_g) return;
+  Geo cur = geo(t);
+  issue_patch(cur);
+  for (; t < tiles_g; t += gridDim.x) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the patch landed (and its stores of the previous tile left)
+    __syncthreads();                                       // ... everybody's; and every wave is past the halo reads of the previous tile
+    // ---- interpolate the 18 x 18 halo from the staged patch (same arithmetic as conv_tile_kernel<.., UPS>: same bits)
+#pragma unroll 1
+    for (int jj = 0; jj < 11; ++jj) {
+      const int i = wv + 4 * jj;
+      if (i < 41) {
+        const int idx = i * 64 + lane;
+        const int hp = idx >> 3, cpos = idx & 7;
+        const int hy = hp / 18, hx = hp - hy * 18;
+        int iy = cur.y0 - 1 + hy, ix = cur.x0 - 1 + hx;
+        iy = iy < 0 ? -iy : (iy >= p.Himg ? 2 * p.Himg - 2 - iy : iy);
+        ix = ix < 0 ? -ix : (ix >= p.Wimg ? 2 * p.Wimg - 2 - ix : ix);
+        const bool ok = hp < 324 && iy >= cur.ylo && iy <= cur.yhi && ix >= cur.xlo && ix <= cur.xhi;
+        half8 o8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] = (half_t)0.f;
+        if (ok) {
+          const float fy = ups_sy * (float)iy, fx = ups_sx * (float)ix;
+          const int sy0 = (int)fy, sx0 = (int)fx;
+          const int sy1 = sy0 + (sy0 < p.Hsrc - 1), sx1 = sx0 + (sx0 < p.Wsrc - 1);
+          const half_t ly = (half_t)(fy - (float)sy0), lx = (half_t)(fx - (float)sx0);
+          const int cs = (cpos ^ ((hp >> 1) & 7)) << 4;
+          const half8 h00 = *(const half8*)(patch + ((sy0 - cur.syA) * cur.PC + (sx0 - cur.sxA)) * 128 + cs);
+          const half8 h01 = *(const half8*)(patch + ((sy0 - cur.syA) * cur.PC + (sx1 - cur.sxA)) * 128 + cs);
+          const half8 h10 = *(const half8*)(patch + ((sy1 - cur.syA) * cur.PC + (sx0 - cur.sxA)) * 128 + cs);
+          const half8 h11 = *(const half8*)(patch + ((sy1 - cur.syA) * cur.PC + (sx1 - cur.sxA)) * 128 + cs);
+          const half8 top = h00 + lx * (h01 - h00);
+          const half8 bot = h10 + lx * (h11 - h10);
+          o8 = top + ly * (bot - top);
+        }
+        *(half8*)(halo + i * 1024 + lane * 16) = o8;
+      }
+    }
+    __syncthreads();                                       // halo complete; the patch buffer is free
+    const int tn = t + (int)gridDim.x;
+    Geo nxt = cur;
+    if (tn < tiles_g) {
+      nxt = geo(tn);
+      issue_patch(nxt);                                    // lands under the MFMAs below
+    }
+    // ---- 9 taps x 2 k-steps x (4 rows x 2 column tiles) MFMAs, fragments of A straight from the halo, weights from registers
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        half8 af[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int hp = (wv * 4 + i + dy) * 18 + px + dx;
+          af[i] = *(const half8*)(halo + hp * 128 + (((ks * 4 + fq) ^ ((hp >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[tap][ks][j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);                 // fragment reads stay one k-step ahead at most: 144 registers hold weights
+      }
+    }
+    // ---- epilogue (UD_EPI_HEAD): lane owns pixel (y0 + 4 wv + i, x0 + px), channels 16 j + 4 fq .. + 3
+    f32x4 bv[2], wv2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bv[j] = *(const f32x4*)(bias + j * 16 + 4 * fq);
+      wv2[j] = *(const f32x4*)(w2 + j * 16 + 4 * fq);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int y = cur.y0 + wv * 4 + i, x = cur.x0 + px;
+      const bool ok = y < p.Himg && x < p.Wimg;
+      const size_t row = ((size_t)cur.b * p.Himg + y) * p.Wimg + x;
+      float part = 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part += ud_lrelu(acc[i][j][r] + bv[j][r]) * wv2[j][r];
+      part += __shfl_xor(part, 16, 64);
+      part += __shfl_xor(part, 32, 64);
+      if (ok && fq == 0) {
+        float yv = part + (g == 0 ? p.b2 : p.b2_g1);
+        yv = fminf(fmaxf(yv, -8.0f), 8.0f);
+        ((float*)p.out)[(long long)g * p.gOut + row] = __expf(yv + (g == 0 ? p.post_add : p.post_add_g1));
+      }
+    }
+    cur = nxt;
+  }
+}
+
 constexpr int UPS_PATCH = 13;                  // source patch side of the fused up-sampling loader (halo of 18 at a scale <= 0.6, + 2)
 template <int NT, int EPI, bool REFLECT, bool UPS = false>
 int launch_conv_tile(const UdGemm& d, hipStream_t s) {
@@ -1801,6 +1963,11 @@ int launch_conv_tile(const UdGemm& d, hipStream_t s) {
   hipLaunchKernelGGL((conv_tile_kernel<NT, EPI, REFLECT, UPS>), grid, dim3(256), lds, s, d);
   UD_CHECK_LAUNCH("ud_gemm_f16 (halo-tile conv) launch");
   return UD_OK;
+}
+
+inline bool head_regw_enabled() {
+  static const int on = [] { const char* e = getenv("UD_HEAD_REGW"); return (e && e[0] == '0') ? 0 : 1; }();
+  return on != 0;
 }
 
 // eligibility: dense images (rows_img == H*W), N in {32, 64}, Cin multiple of 64, weights laid out [N][tap*Cin + ci]
@@ -1991,6 +2158,20 @@ extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
       if (!conv_tile_ok(d) || d.Hsrc < 1 || d.Wsrc < 1 || (d.cstride & 7) || !fits) {
         ud_set_error("ud_gemm_f16: CONV3_REFLECT_UP needs Cin % 64 == 0, dense images, Hsrc / Wsrc >= 1 and an up-sampling factor >= ~1.7");
         return UD_ERR_BAD_ARG;
+      }
+      if (d.Cin == 64 && head_regw_enabled()) {
+        // weights in registers, persistent workgroups (conv_head_regw_kernel); UD_HEAD_REGW=0 keeps the LDS-streamed form (A/B)
+        const int lds = HALO_BYTES + (UPS_PATCH * UPS_PATCH * 128 + 1023) / 1024 * 1024;
+        static bool attr_set[UD_MAX_DEVICES];
+        if (!ud_attr_once(attr_set)) (void)hipFuncSetAttribute((const void*)conv_head_regw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        const int B = d.M / d.rows_img;
+        const int tiles_x = (d.Wimg + 15) >> 4, tiles_img = tiles_x * ((d.Himg + 15) >> 4), tiles_g = tiles_img * B;
+        const int G = d.groups > 0 ? d.groups : 1;
+        int wgs = (512 + G - 1) / G;                             // two workgroups per CU over all branches
+        wgs = wgs < tiles_g ? wgs : tiles_g;
+        hipLaunchKernelGGL(conv_head_regw_kernel, dim3(wgs, G), dim3(256), lds, s, d, tiles_x, tiles_img, tiles_g);
+        UD_CHECK_LAUNCH("ud_gemm_f16 (head conv, register-resident weights) launch");
+        return UD_OK;
       }
       return launch_conv_tile<2, UD_EPI_HEAD, true, true>(d, s);
     }
