@@ -3,6 +3,7 @@ PyTorch-ROCm's; all arithmetic is in libunidepth_hip.so) and record / replay lau
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -133,9 +134,14 @@ class Program:
         elif pick in (6, 7):     # 128x128 tiles, 4-stage pipelined ring (7: + two-way K split)
             cls = "gemm_kernel<Cfg<128, 64, 64>, %d, %d, 4, %s>" % (epi, amode, "true" if pick == 7 else "false")
         elif pick <= 4:
-            cls = "gemm256_kernel<%d, %d, %d, false, %s, %s>" % (pick, epi, amode, lnc, grp)
+            # 7th template argument: the 3-deep weight ring of the 192-row tile list (csrc/gemm.hip launch256: dense A, not grouped, K >= 128)
+            w3 = (pick == 3 and amode == UD_A_DENSE and grp == "false" and kw["K"] >= 128 and kw.get("tile_hint", 0) != 9
+                  and os.environ.get("UD_GEMM_W3", "1")[:1] != "0")
+            cls = "gemm256_kernel<%d, %d, %d, false, %s, %s, %s>" % (pick, epi, amode, lnc, grp, "true" if w3 else "false")
         elif pick == 8:     # row-balanced schedule of the 256-column kernel
-            cls = "gemm256_kernel<4, %d, %d, true, %s, false>" % (epi, amode, lnc)
+            cls = "gemm256_kernel<4, %d, %d, true, %s, false, false>" % (epi, amode, lnc)
+        elif amode == 3 and kw.get("Cin", 0) == 64 and epi == UD_EPI_HEAD and os.environ.get("UD_HEAD_REGW", "1")[:1] != "0":
+            cls = "conv_head_regw_kernel"                       # head conv with its weights in registers
         else:
             cls = "conv_tile_kernel<%d, %d, %s, %s>" % (n // 16, epi, "true" if amode >= 2 else "false", "true" if amode == 3 else "false")
         self.keep.extend(v for v in kw.values() if isinstance(v, torch.Tensor))
