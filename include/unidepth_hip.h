@@ -132,6 +132,12 @@ typedef struct UdGemm {
   const float* wsum;
   int ln_slabs, ln_D;
   float ln_eps;
+  /* UD_EPI_D2S, optional (round 4): the value the transposed convolution accumulates INTO is not read from `out` but interpolated on the fly
+   * from up_src -- fp32 NHWC [*, up_img_rows, up_ld] holding a (up_H x up_W) map per image -- as its bilinear x2 up-sampling
+   * (align_corners=False: exactly ud_upsample2x_nhwc mode 0, upsample.py:184-186 nn.Upsample behind the 1x1 conv), so the up-sampled map is
+   * never written and read back: out = up2(up_src) + ConvT(A) (+ bias), out2 = act2(out).  Needs d2s_Hin * d2s_k == 2 * up_H (same for W). */
+  const float* up_src;
+  int up_H, up_W, up_ld, up_img_rows;
 } UdGemm;
 
 int ud_gemm_f16(const UdGemm* desc, void* stream);

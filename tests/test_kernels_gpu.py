@@ -701,6 +701,43 @@ def test_gemm_d2s_convtranspose(ops, k):
     assert rel(lat16.view(B, Hout, Wout, Co).float(), F.leaky_relu(ref, 0.01)) < 1e-3
 
 
+@pytest.mark.parametrize("k,B,Hin,Win,Cin,Co,pad_rows", [(2, 2, 5, 7, 64, 64, 5), (4, 1, 6, 6, 128, 128, 0), (2, 3, 37, 37, 512, 256, 7)])
+def test_gemm_d2s_fused_upsampling(ops, k, B, Hin, Win, Cin, Co, pad_rows):
+    """UdGemm.up_src (round 4): the transposed convolution's accumulate interpolates the x2 up-sampling of a half-resolution fp32 map itself
+    instead of reading the materialised up-sampled map == ud_upsample2x_nhwc (mode 0) followed by the plain read-modify-write, on
+    straight-line and edge tiles (the last case is the ViT-L stage-1 shape: large-tile kernel, 192-row tiles with a partial last tile)."""
+    import ctypes
+    rows_in = Hin * Win + pad_rows
+    x = rnd(B, rows_in, Cin, seed=1).half()
+    wt = rnd(Cin, Co, k, k, scale=Cin ** -0.5, seed=2)
+    bias = rnd(Co, seed=3)
+    Wg = wt.permute(2, 3, 1, 0).reshape(k * k * Co, Cin).contiguous().half()
+    Hout, Wout = Hin * k, Win * k
+    uh, uw = Hout // 2, Wout // 2
+    urows = uh * uw + 3                                                     # rows per image of the source map (padded, like the engine's token rows)
+    u = rnd(B, urows, Co, seed=4)
+    common = dict(A=x, W=Wg, bias=bias, M=B * rows_in, N=k * k * Co, K=Cin, lda=Cin, ldw=Cin, ldc=Co, ldc2=Co, epi=ops.UD_EPI_D2S, act2=ops.UD_ACT_LRELU,
+                  d2s_k=k, d2s_Co=Co, d2s_Hin=Hin, d2s_Win=Win, d2s_rows_in_img=rows_in, d2s_out_img_pix=Hout * Wout)
+    # reference: materialise, then accumulate
+    lat_m = torch.zeros(B, Hout * Wout, Co, device="cuda")
+    d = ops.mk(ops.UdUpsample2x, in_=u, out=lat_m, B=B, H=uh, W=uw, C=Co, ldin=Co, ldy=Co, mode=0, in_img_rows=urows)
+    ops.check(ops.lib.ud_upsample2x_nhwc(ctypes.byref(d), ops.cur_stream()))
+    up = lat_m.clone()
+    l16_m = torch.zeros(B, Hout * Wout, Co, dtype=torch.half, device="cuda")
+    ops.gemm(out=lat_m, out2=l16_m, **common)
+    # fused: `out` starts as garbage -- it must never be read
+    lat_f = torch.full((B, Hout * Wout, Co), 1.0e9, device="cuda")
+    l16_f = torch.zeros_like(l16_m)
+    ops.gemm(out=lat_f, out2=l16_f, up_src=u, up_H=uh, up_W=uw, up_ld=Co, up_img_rows=urows, **common)
+    torch.cuda.synchronize()
+    ref_up = F.interpolate(u[:, :uh * uw].view(B, uh, uw, Co).permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    assert rel(up.view(B, Hout, Wout, Co), ref_up) < 1e-6
+    assert rel(lat_f, lat_m) < 1e-6, rel(lat_f, lat_m)                      # same expression, contraction may differ by an ulp
+    assert rel(l16_f.float(), l16_m.float()) < 1e-4
+    with pytest.raises(RuntimeError):                                       # geometry that does not match the transposed convolution's output grid
+        ops.gemm(out=lat_f, out2=l16_f, up_src=u, up_H=uh + 1, up_W=uw, up_ld=Co, up_img_rows=urows, **common)
+
+
 def test_gemm_head_epilogue(ops):
     G, B, H, W, Cin = 2, 1, 20, 13, 64
     x = rnd(G, B, H * W, Cin, seed=1).half()

@@ -33,6 +33,7 @@ class UdGemm(C.Structure):
         ("b2_g1", f32), ("post_add_g1", f32), ("tile_hint", i32),
         ("splitk_ws", vp), ("splitk_cnt", vp), ("Hsrc", i32), ("Wsrc", i32), ("a_wrap", i32), ("w_wrap", i32), ("max_out", fp), ("max_init", i32), ("grp_rows", i32),
         ("row_stats_out", fp), ("row_stats_final", fp), ("row_stats_ticket", vp), ("row_stats_in", fp), ("wsum", fp), ("ln_slabs", i32), ("ln_D", i32), ("ln_eps", f32),
+        ("up_src", fp), ("up_H", i32), ("up_W", i32), ("up_ld", i32), ("up_img_rows", i32),
     ]
 
 

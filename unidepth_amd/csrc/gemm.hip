@@ -98,6 +98,22 @@ __device__ __forceinline__ f32x4 ud_ln_apply4(f32x4 acc, float rs, float nmr, f3
   return o;
 }
 
+// UdGemm.up_src (UD_EPI_D2S): the old value of output pixel (img, Y, X), channels o .. o + 3, as the bilinear x2 up-sampling of the source map
+// (align_corners=False; the same expression as upsample2x_kernel<0> in pointwise.hip, evaluated where the transposed convolution adds to it)
+__device__ __forceinline__ f32x4 ud_up2_fetch(const UdGemm& p, int img, int Y, int X, int o) {
+  float fy = 0.5f * ((float)Y + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+  float fx = 0.5f * ((float)X + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < p.up_H - 1), x1 = x0 + (x0 < p.up_W - 1);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float* in = p.up_src + (size_t)img * p.up_img_rows * p.up_ld + o;
+  const f32x4 v00 = *(const f32x4*)(in + ((size_t)y0 * p.up_W + x0) * p.up_ld);
+  const f32x4 v01 = *(const f32x4*)(in + ((size_t)y0 * p.up_W + x1) * p.up_ld);
+  const f32x4 v10 = *(const f32x4*)(in + ((size_t)y1 * p.up_W + x0) * p.up_ld);
+  const f32x4 v11 = *(const f32x4*)(in + ((size_t)y1 * p.up_W + x1) * p.up_ld);
+  return (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
+}
+
 template <int TM, int TN, int TMA>      // TM row tiles used of an accumulator array of TMA (deduced)
 __device__ __forceinline__ void gemm_preload_acc(const UdGemm& p, f32x4 (&acc)[TMA][TN], int mbase, int nbase, int lane, const char* out) {
 #pragma unroll
@@ -276,7 +292,7 @@ __device__ __forceinline__ void gemm_epilogue_impl(const UdGemm& p, f32x4 (&acc)
           const int a = ac / k, c = ac - a * k;
           const long long pix = (long long)img * p.d2s_out_img_pix + (long long)(y * k + a) * Wout + (x * k + c);
           float* dst = (float*)out + pix * p.ldc + o;
-          f32x4 v = *(f32x4*)dst;
+          f32x4 v = p.up_src ? ud_up2_fetch(p, img, y * k + a, x * k + c, o) : *(f32x4*)dst;
           const f32x4 bv = *(const f32x4*)(bias + o);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += acc[i][j][r] + bv[r];
@@ -1333,7 +1349,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
           float* dst = (float*)p.out + pix * p.ldc + o0 + 4 * fq;
           f32x4 v[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = ok ? *(const f32x4*)(dst + j * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int j = 0; j < 4; ++j) v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (ok) {
+            if (p.up_src) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = ud_up2_fetch(p, img, y * k + sa, x * k + sc, o0 + j * 16 + 4 * fq);
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = *(const f32x4*)(dst + j * 16);
+            }
+          }
           unsigned w[4][2];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -2139,9 +2164,19 @@ extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
     if (const int bt = pick_tiles(d)) return launch_big<UD_EPI_QKV>(d, s, bt);
     return launch<Cfg<128, 64, 64>, UD_EPI_QKV, UD_A_DENSE>(d, s);
   }
+  if (d.up_src && d.epi != UD_EPI_D2S) {
+    ud_set_error("ud_gemm_f16: up_src belongs to the D2S epilogue");
+    return UD_ERR_BAD_ARG;
+  }
   if (d.epi == UD_EPI_D2S) {
     if (d.amode != UD_A_DENSE || (d.d2s_Co & 3)) {
       ud_set_error("ud_gemm_f16: bad D2S epilogue geometry");
+      return UD_ERR_BAD_ARG;
+    }
+    if (d.up_src && (d.up_H < 1 || d.up_W < 1 || 2 * d.up_H != d.d2s_Hin * d.d2s_k || 2 * d.up_W != d.d2s_Win * d.d2s_k || (d.up_ld & 3) || d.up_ld < d.d2s_Co ||
+                     d.up_img_rows < d.up_H * d.up_W || d.groups > 1)) {
+      ud_set_error("ud_gemm_f16: up_src (fused x2 up-sampling under the D2S accumulate) needs 2 * up_H == d2s_Hin * d2s_k (same for W), up_ld % 4 == 0, "
+                   "up_ld >= d2s_Co, up_img_rows >= up_H * up_W");
       return UD_ERR_BAD_ARG;
     }
     if (const int bt = pick_tiles(d)) return launch_big<UD_EPI_D2S>(d, s, bt);

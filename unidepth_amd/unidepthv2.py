@@ -352,6 +352,11 @@ class _Plan:
         P.nhwc_to_nchw(lat, self.depth_features, B, hw, C, C, hwp)
         gh, gw, rows_img = h, wg, hwp
         xh = None
+        # The x2 up-sampling behind a stage's 1x1 conv feeds only the next stage's ConvTranspose accumulate: with UNIDEPTH_UPFUSE (default on) that
+        # accumulate interpolates the 1x1 conv's output itself (UdGemm.up_src) -- the up-sampled fp32 map is never written and read back
+        # (45 + 90 MB at bs = 8, two launches).  =0: ud_upsample2x_nhwc + plain read-modify-write as before (A/B).
+        upfuse = os.environ.get("UNIDEPTH_UPFUSE", "1") != "0"
+        pending_up = {}
         for i in range(3):
             cur, outd = meta["chans"][i]
             k = max(1, 2 * i)
@@ -359,7 +364,8 @@ class _Plan:
             l16 = z(Ms, cur); t16 = z(Ms, cur)
             P.gemm(A=c16[i + 1], W=w[f"dh.convt.{i}.w"], bias=w[f"dh.convt.{i}.b"], out=lat, out2=l16, M=Md, N=k * k * cur, K=C, lda=C,
                    ldw=C, ldc=cur, ldc2=cur, epi=UD_EPI_D2S, act2=UD_ACT_LRELU, d2s_k=k, d2s_Co=cur, d2s_Hin=h, d2s_Win=wg,
-                   d2s_rows_in_img=hwp, d2s_out_img_pix=rows_img)
+                   d2s_rows_in_img=hwp, d2s_out_img_pix=rows_img, **pending_up)
+            pending_up = {}
             kp = w[f"dh.ups.{i}.0.conv1.w"].shape[1]
             conv = dict(zeros=zeros, M=Ms, N=cur, K=kp, ldw=kp, amode=UD_A_CONV3_ZERO, Himg=gh, Wimg=gw, Cin=cur, cstride=cur, coff=0,
                         rows_img=rows_img, img_stride=rows_img * cur)
@@ -373,9 +379,15 @@ class _Plan:
                    ldw=_rup(cur, 64), ldc=outd, epi=UD_EPI_F32)
             if i < 2:
                 nlat = z(B * 4 * gh * gw, outd, dtype=f32)
-                P.upsample2x(in_=u, out=nlat, B=B, H=gh, W=gw, C=outd, ldin=outd, ldy=outd, mode=0, in_img_rows=rows_img)
+                if upfuse:
+                    pending_up = dict(up_src=u, up_H=gh, up_W=gw, up_ld=outd, up_img_rows=rows_img)      # consumed by the next stage's ConvT
+                    # the tap (the stage's output = the up-sampled map BEFORE the next injection) is formed from u on demand
+                    tap(f"ups.{i}", lambda u=u, gh=gh, gw=gw, outd=outd, ri=rows_img: torch.nn.functional.interpolate(
+                        u.view(B, ri, outd)[:, :gh * gw].reshape(B, gh, gw, outd).permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False))
+                else:
+                    P.upsample2x(in_=u, out=nlat, B=B, H=gh, W=gw, C=outd, ldin=outd, ldy=outd, mode=0, in_img_rows=rows_img)
+                    tap(f"ups.{i}", lambda t=nlat, gh=gh, gw=gw, outd=outd: t.view(B, 2 * gh, 2 * gw, outd).permute(0, 3, 1, 2).clone())
                 lat = nlat
-                tap(f"ups.{i}", lambda t=nlat, gh=gh, gw=gw, outd=outd: t.view(B, 2 * gh, 2 * gw, outd).permute(0, 3, 1, 2).clone())
             else:
                 ldx = _rup(outd, 64)
                 xh = z(B * 4 * gh * gw, ldx)
