@@ -3,8 +3,10 @@
 // per-launch host cost is a C++ switch instead of a ctypes round trip (the recorded range can also be captured
 // into a hipGraph by the caller: every launch goes to the stream passed to ud_program_run).
 // ud_program_run_graph does that capture itself: the second replay of a range records it on a private capture stream (the caller's stream
-// may be the legacy default stream, which cannot capture), instantiates the graph once and from then on a replay is ONE hipGraphLaunch --
-// the launch-bound small-batch programs (ViT-S bs=1: ~280 kernels of 2-10 us) no longer pay one host launch per kernel.
+// may be the legacy default stream, which cannot capture), instantiates the graph once and from then on a replay is ONE hipGraphLaunch.
+// Measured on MI355X: bit-identical to the eager replay and NOT faster, at bs = 8 or at bs = 1 -- the small-batch programs
+// are paced by dependent, under-filled kernels on the GPU, not by this file's launch loop.  Kept as an option, off by default.
+// ud_program_add_side: a second stream per program with fork / join events for independent launch chains.
 #include <hip/hip_runtime.h>
 #include <map>
 #include <utility>
