@@ -523,3 +523,23 @@ def test_v2_plan_builder_dry_run_side_branch_and_descriptors(monkeypatch):
     assert cam.count("cam.adapter") == 4 and cam[-2:] == ["rays", "ray_embed"] and "camera_intrinsics" in cam and not any(t.startswith("dec.") or t.startswith("dh.") for t in cam)
     assert tags[i1 + 1:i2] == ["dec.adapters(x4)", "layernorm", "dh.q(x4)"] and tags[i2 + 1] == "dh.kv(x4)"
     assert ops.lib.ud_program_add_side(plan.prog.h, 3) < 0                                                # unknown mode: refused
+
+
+def test_program_graph_and_side_api_argument_checks_without_gpu():
+    """ud_program_run_graph / ud_program_add_side / ud_program_graph_count on the host: ranges and modes are validated before anything
+    touches the device, an empty range is a no-op, a program without recorded graphs reports none, destroy releases everything."""
+    from unidepth_amd import _lib
+    lib = _lib.lib
+    p = lib.ud_program_create()
+    assert p and lib.ud_program_size(p) == 0 and lib.ud_program_graph_count(p) == 0
+    assert lib.ud_program_add_side(p, 0) == 0 and lib.ud_program_add_side(p, 1) == 1 and lib.ud_program_add_side(p, 2) == 2
+    assert lib.ud_program_add_side(p, 7) == -1 and lib.ud_program_add_side(None, 0) == -1          # UD_ERR_BAD_ARG
+    assert lib.ud_program_size(p) == 3
+    assert lib.ud_program_run_graph(p, 2, 1, None) == -1 and b"bad range" in lib.ud_last_error()
+    assert lib.ud_program_run_graph(p, 0, 9, None) == -1
+    assert lib.ud_program_run(p, -1, 2, None) == -1
+    assert lib.ud_program_run_graph(p, 1, 1, None) == 0                                              # empty range: nothing to do
+    assert lib.ud_program_run(p, 1, 2, None) == 0                                                    # a bare END marker touches no device state
+    lib.ud_program_drop_graphs(p)
+    assert lib.ud_program_graph_count(p) == 0
+    lib.ud_program_destroy(p)
