@@ -13,12 +13,14 @@ statistic covers weight-rounding noise (a fixed perturbation per checkpoint) as 
   (2) depth GIVEN THE CAMERA: the engine's depth against the oracle evaluated with the engine's own predicted pinhole parameters
       substituted for the oracle's camera head output: ARel <= 1e-3.  infer() is depth = f(image, K(image)); (1) bounds the K error and
       (2) bounds the error of f at equal K, which is the part the MFMA path computes;
-  (3) end to end (each side with its own camera): reported, and asserted at 1e-3 on the MEDIAN case and at
-      1e-3 + S * (K error) on every case, S = the oracle's OWN measured sensitivity d(depth ARel) / d(K max-rel) for that checkpoint and
-      image (finite difference between the oracle's two runs above).  On most checkpoints S ~ 1 (depth scales with the focal length);
-      the sensitised random decoders include checkpoints with S ~ 10 at 644x966, where the ray embedding's top band sin(angle 2^5 pi)
-      turns a 9e-4 focal difference into 9e-3 of depth in the ORACLE ITSELF -- no fp16-operand encoder (the reference's own CUDA path
-      included) can hold 1e-3 end to end there; round 4 found this with this very test (seed 301).
+  (3) end to end (each side with its own camera), against the REFERENCE AS SHIPPED as the comparator (SURVEY 8c's
+      secondary comparator): the same oracle code (oracle/restate.py -- the reference's own torch ops) run on the GPU under
+      torch.autocast("cuda", dtype=torch.float16), i.e. under the decorator the reference's infer() carries (unidepthv2.py:239-240).  Three
+      columns per case are printed -- engine, autocast reference, both against the fp32 CPU oracle -- and asserted per case:
+          engine end-to-end ARel  <= max(1e-3, autocast-reference end-to-end ARel)
+          engine K max-rel        <= max(1e-3, autocast-reference K max-rel)
+      No sensitivity allowance: on checkpoints whose depth responds to the focal length with a factor of 2-10 (the ray embedding's top band
+      sin(angle 2^5 pi)) the engine may miss 1e-3 end to end only where the reference's own CUDA path misses it by at least as much.
 Oracle = test infrastructure; the engine never sees it."""
 import numpy as np
 import pytest
@@ -49,19 +51,42 @@ def _errors(out, ref):
 
 
 def _report_and_assert(tag, rows, kbar):
-    """rows: (end-to-end ARel, K max-rel, ARel at the engine's camera, oracle sensitivity ARel(oracle @ K_engine vs oracle @ K_oracle))"""
-    e2e = [r[0] for r in rows]; kk = [r[1] for r in rows]; atk = [r[2] for r in rows]; sens = [r[3] for r in rows]
+    """rows: (end-to-end ARel, K max-rel, ARel at the engine's camera, oracle sensitivity ARel(oracle @ K_engine vs oracle @ K_oracle),
+    autocast-reference end-to-end ARel, autocast-reference K max-rel) -- every error against the fp32 CPU oracle"""
+    e2e = [r[0] for r in rows]; kk = [r[1] for r in rows]; atk = [r[2] for r in rows]
+    ref_e2e = [r[4] for r in rows]; ref_k = [r[5] for r in rows]
     _hist(f"{tag}: depth ARel GIVEN THE CAMERA (engine vs oracle at the engine's K)", atk, 1e-3)
-    _hist(f"{tag}: intrinsics max-rel", kk, kbar)
-    _hist(f"{tag}: depth ARel end to end (each side its own camera)", e2e, 1e-3)
-    print("   per case: end-to-end / K error / at-equal-K / oracle's own depth change for that K error")
+    _hist(f"{tag}: intrinsics max-rel, engine", kk, kbar)
+    _hist(f"{tag}: intrinsics max-rel, reference under fp16 autocast (as shipped)", ref_k, kbar)
+    _hist(f"{tag}: depth ARel end to end, engine", e2e, 1e-3)
+    _hist(f"{tag}: depth ARel end to end, reference under fp16 autocast (as shipped)", ref_e2e, 1e-3)
+    print("   per case, all against the fp32 oracle:")
+    print("     engine e2e | autocast-ref e2e || engine K | autocast-ref K || engine at-equal-K | oracle's own depth change for the engine's K error")
     for r in rows:
-        print(f"     {r[0]:.2e}  {r[1]:.2e}  {r[2]:.2e}  {r[3]:.2e}")
+        print(f"     {r[0]:.2e}   {r[4]:.2e}   ||  {r[1]:.2e}   {r[5]:.2e}  ||  {r[2]:.2e}   {r[3]:.2e}")
+    print(f"   engine within 1e-3 end to end: {sum(v <= 1e-3 for v in e2e)} of {len(e2e)}; autocast reference: {sum(v <= 1e-3 for v in ref_e2e)} of {len(ref_e2e)}")
+    print(f"   median end to end: engine {np.median(e2e):.2e}, autocast reference {np.median(ref_e2e):.2e}; "
+          f"median K: engine {np.median(kk):.2e}, autocast reference {np.median(ref_k):.2e}")
     assert max(kk) <= kbar, ("camera", max(kk))
     assert max(atk) <= 1e-3, ("depth at equal camera", max(atk))
     assert float(np.median(e2e)) <= 1e-3, ("median end-to-end", float(np.median(e2e)))
     for r in rows:
-        assert r[0] <= 1e-3 + r[3] + 1e-4, ("end-to-end beyond the oracle's own response to the camera difference", r)
+        assert r[0] <= max(1e-3, r[4]), ("end-to-end: engine worse than the bar AND than the reference as shipped (fp16 autocast)", r)
+        assert r[1] <= max(1e-3, r[5]), ("camera: engine worse than the bar AND than the reference as shipped (fp16 autocast)", r)
+
+
+def _reference_as_shipped(orc, rgb):
+    """The reference's CUDA path: the oracle's own ops on the GPU under the autocast decorator of the reference's infer()
+    (unidepthv2.py:239-240: @torch.autocast(device_type="cuda", dtype=torch.float16)).  Test infrastructure only."""
+    w_cpu = orc.w
+    orc.w = {k: v.cuda() for k, v in w_cpu.items()}
+    try:
+        with torch.no_grad(), torch.device("cuda"), torch.autocast(device_type="cuda", enabled=True, dtype=torch.float16):
+            out = orc.infer(rgb.cuda())
+        torch.cuda.synchronize()
+        return {k: v.float().cpu() for k, v in out.items() if torch.is_tensor(v)}
+    finally:
+        orc.w = w_cpu
 
 
 class _OracleAtK:
@@ -124,7 +149,9 @@ def test_v2_vitl_depth_error_distribution():
             d, k = _errors(out, ref)
             dk, _ = _errors(out, ref_k)
             s_, _ = _errors({"depth": ref_k["depth"], "intrinsics": ref_k["intrinsics"]}, ref)
-            rows.append((d[0], k[0], dk[0], s_[0]))
+            shipped = _reference_as_shipped(orc, rgb)
+            sd_, sk_ = _errors(shipped, ref)
+            rows.append((d[0], k[0], dk[0], s_[0], sd_[0], sk_[0]))
         model.clear_plans()
         del model, orc, sd
     _report_and_assert("UniDepthV2 ViT-L/14 (8 seeds x {518x518, 644x966})", rows, 2e-3)
