@@ -1,9 +1,9 @@
 #!/usr/bin/env python
-"""A/B of attention-kernel variant libraries (tools/r4_attn_variants.sh -> ab/libattn_<name>.so) on the encoder shape
+"""A/B of attention-kernel variant libraries (tools/attn_variants.sh -> ab/libattn_<name>.so) on the encoder shape
 (B=8, H=16, N=1370, q pre-scaled, MODE 1).  One subprocess per (library, round), rounds interleaved so that box drift hits every
 variant alike; the child also checks the result against an fp32 torch softmax(QK^T)V on two (image, head) pairs, one of them with
 a SPIKED key row placed in a late tile (forces the rare rescale path: cdna guide rule 26).  GPU box only.
-usage: python tools/r4_attn_ab.py [--rounds 3] name1 name2 ...      (names of ab/libattn_<name>.so; 'product' = the in-tree library)"""
+usage: python tools/attn_ab.py [--rounds 3] name1 name2 ...      (names of ab/libattn_<name>.so; 'product' = the in-tree library)"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Build one library per attention-kernel variant (compile-time switches of csrc/attention.hip) into ab/libattn_<name>.so.
-# Usage: tools/r4_attn_variants.sh name1="flags" name2="flags" ...     (run in the authoring container; the .so files travel with gpurun)
+# Usage: tools/attn_variants.sh name1="flags" name2="flags" ...     (run in the authoring container; the .so files travel with gpurun)
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p ab

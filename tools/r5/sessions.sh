@@ -1,0 +1,33 @@
+#!/bin/bash
+# The batched GPU-box sessions of round 5, one function per gpurun call (tests + interleaved A/B + profiles in one call each); every
+# profiles/r05_* file names the session that produced it.  usage (on the GPU box, through gpurun):  bash tools/r5/sessions.sh <name>
+# (function bodies are not indented: they contain here-documents)
+cd "$(dirname "$0")/../.." && R=$PWD
+export PYTHONWARNINGS=ignore
+line() { python -c "
+import json,sys
+try:
+    d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['value'], d['ms_per_step'], d.get('p50_latency_ms'), d.get('value_one_call'))
+except Exception as e: print('$1 FAILED', e)"; }
+
+# round 5, GPU call 1: the software-pipelined attention kernel (correctness incl. the spiked-key rescale path, interleaved A/B of its
+# compile-time variants against the round-4 kernel, the attention kernel tests on the product library), the V2 parity sweep with the
+# reference-as-shipped (fp16 autocast) comparator, the bench line with the new and the round-4 attention kernel interleaved
+call1() {
+O=gpurun_out/r5c1 && mkdir -p $O
+t0=$(date +%s)
+timeout 600 python tools/attn_ab.py --rounds 2 classic pipe o2fd4 o1 o0fd4 nw8 2>&1 | grep -v amdgpu.ids > $O/attn_ab.txt
+echo "[ab done $(( $(date +%s) - t0 )) s]" >> $O/attn_ab.txt
+timeout 400 python -m pytest tests/test_kernels_gpu.py -q -m gpu -k "attention" 2>&1 | grep -v "^$\|amdgpu.ids" | tail -8 > $O/attn_tests.txt
+echo "[attention tests done $(( $(date +%s) - t0 )) s]" >> $O/attn_tests.txt
+for r in 1 2; do
+  timeout 300 python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-extra-configs --no-kernel-timing 2>$O/err.txt | line "pipe" >> $O/bench_ab.txt
+  UNIDEPTH_HIP_LIB=$R/ab/libattn_classic.so timeout 300 python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-extra-configs --no-kernel-timing 2>$O/err.txt | line "classic" >> $O/bench_ab.txt
+done
+echo "[bench ab done $(( $(date +%s) - t0 )) s]" >> $O/bench_ab.txt
+timeout 900 python -m pytest tests/test_parity_sweep_gpu.py -q -s -m gpu -k "v2" 2>&1 | grep -v "^$\|amdgpu.ids" | tail -110 > $O/sweep_v2.txt
+echo "[v2 sweep done $(( $(date +%s) - t0 )) s]" >> $O/sweep_v2.txt
+cat $O/attn_ab.txt $O/attn_tests.txt $O/bench_ab.txt; tail -70 $O/sweep_v2.txt
+}
+
+"$@"
