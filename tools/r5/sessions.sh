@@ -30,4 +30,12 @@ echo "[v2 sweep done $(( $(date +%s) - t0 )) s]" >> $O/sweep_v2.txt
 cat $O/attn_ab.txt $O/attn_tests.txt $O/bench_ab.txt; tail -70 $O/sweep_v2.txt
 }
 
+# round 5, GPU call 2: where does the pipelined attention kernel's tile time go?  Parts compiled out (results wrong by construction), plus two
+# structural variants (fragment ring 4 deep; 2-wave workgroups = half the barrier group)
+call2() {
+O=gpurun_out/r5c2 && mkdir -p $O
+timeout 900 python tools/attn_ab.py --rounds 2 classic pipe fd4 nw2 abl1 abl3 abl4 abl8 abl16 abl24 abl32 abl35 abl64 abl127 2>&1 | grep -v amdgpu.ids > $O/attn_abl.txt
+cat $O/attn_abl.txt
+}
+
 "$@"

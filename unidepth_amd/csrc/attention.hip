@@ -40,6 +40,9 @@
 #ifndef UD_ATTN_PIPE_NW
 #define UD_ATTN_PIPE_NW 4       // waves per workgroup of the pipelined kernel (4 or 8)
 #endif
+#ifndef UD_ATTN_PIPE_ABL
+#define UD_ATTN_PIPE_ABL 0      // tools builds only (tools/r5/sessions.sh): parts compiled OUT of the tile loop, results are wrong by construction --
+#endif                          // 1 barrier, 2 K / V^T DMA, 4 exp2 + pack, 8 Q K^T MFMAs, 16 P V MFMAs, 32 fragment reads from LDS, 64 row maximum
 #ifndef UD_ATTN_PIPE_FD
 #define UD_ATTN_PIPE_FD 3       // fragment register ring: a K / V^T fragment is read from LDS FD - 1 MFMAs ahead of its use
 #endif
@@ -447,6 +450,10 @@ __global__ __launch_bounds__(NW * 64, UD_ATTN_PIPE_MINW) void attention_pipe_ker
   auto ex = [&](auto A_) {
     constexpr int a = decltype(A_)::value;
     f32x2 pv;
+    if constexpr (UD_ATTN_PIPE_ABL & 4) {
+      pw[a] = __float_as_uint(sc[a >> 3][(a & 7) * 2]) ^ __float_as_uint(sc[a >> 3][(a & 7) * 2 + 1]);
+      return;
+    }
     pv[0] = __builtin_amdgcn_exp2f(sc[a >> 3][(a & 7) * 2]);
     pv[1] = __builtin_amdgcn_exp2f(sc[a >> 3][(a & 7) * 2 + 1]);
     if constexpr (!MSUM) ls += pv[0] + pv[1];
@@ -530,8 +537,11 @@ __global__ __launch_bounds__(NW * 64, UD_ATTN_PIPE_MINW) void attention_pipe_ker
     // (2) the first fragments (their LDS latency runs under the exponentials below), then the DMA of the tiles the NEXT iteration reads
     constexpr int F0 = LAST ? 8 : 0;                       // the last tile has no Q K^T half
 #pragma unroll
-    for (int i = F0; i < F0 + FD - 1; ++i) fr[i % FD] = *(const half8*)frag_ptr(i, STG ^ 1, STG);
-    if constexpr (!LAST) {
+    for (int i = F0; i < F0 + FD - 1; ++i) {
+      if constexpr (UD_ATTN_PIPE_ABL & 32) fr[i % FD] = qf[i & 3];
+      else fr[i % FD] = *(const half8*)frag_ptr(i, STG ^ 1, STG);
+    }
+    if constexpr (!LAST && !(UD_ATTN_PIPE_ABL & 2)) {
       issue_k(t + 2, STG);
       issue_v(t + 1, STG ^ 1);
     }
@@ -548,17 +558,28 @@ __global__ __launch_bounds__(NW * 64, UD_ATTN_PIPE_MINW) void attention_pipe_ker
     __builtin_amdgcn_sched_barrier(0);
     auto slot = [&](auto I_) {
       constexpr int i = decltype(I_)::value;
-      if constexpr (i + FD - 1 < 16 && i + FD - 1 >= F0 + FD - 1) fr[(i + FD - 1) % FD] = *(const half8*)frag_ptr(i + FD - 1, STG ^ 1, STG);
+      if constexpr (i + FD - 1 < 16 && i + FD - 1 >= F0 + FD - 1) {
+        if constexpr (UD_ATTN_PIPE_ABL & 32) fr[(i + FD - 1) % FD] = qf[i & 3];
+        else fr[(i + FD - 1) % FD] = *(const half8*)frag_ptr(i + FD - 1, STG ^ 1, STG);
+      }
       if constexpr (i < 8) {
-        if constexpr (!LAST) mm_qk(I_, sn);
+        if constexpr (!LAST) {
+          if constexpr (UD_ATTN_PIPE_ABL & 8) {
+            asm volatile("" ::"v"(fr[i % FD]));
+            if constexpr (i < 2) sn[i & 1] = negm;
+          } else {
+            mm_qk(I_, sn);
+          }
+        }
       } else {
-        mm_pv(integral_constant<int, i - 8>{});
+        if constexpr (UD_ATTN_PIPE_ABL & 16) asm volatile("" ::"v"(fr[i % FD]), "v"(pw[4 * ((i - 8) >> 1)]), "v"(pw[4 * ((i - 8) >> 1) + 3]));
+        else mm_pv(integral_constant<int, i - 8>{});
       }
       // row-sum MFMA k over pairs 2k, 2k+1 (packed in slots 2k-2, 2k-1): issued in slot 2k+1, well behind the v_cvt that wrote its operand
       if constexpr (i & 1) sm(integral_constant<int, (i / 2)>{});
       if constexpr (i < 14) ex(integral_constant<int, i + 2>{});
       // row maximum of S(t+1): complete after slot 7; block kb = 0 was finished by slot 6, so its half starts in slot 8
-      if constexpr (!LAST && KIND == 0 && i >= 8) {
+      if constexpr (!LAST && KIND == 0 && i >= 8 && !(UD_ATTN_PIPE_ABL & 64)) {
         constexpr int kb = (i - 8) >> 2, r0 = ((i - 8) & 3) * 4;
         if constexpr (i == 8) mx = sn[0][0];
         mx = fmaxf(fmaxf(mx, sn[kb][r0]), sn[kb][r0 + 1]);
@@ -581,7 +602,7 @@ __global__ __launch_bounds__(NW * 64, UD_ATTN_PIPE_MINW) void attention_pipe_ker
       }
       // (4) tiles of the next iteration landed (this wave's pieces; the barrier covers the others')
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if constexpr (!(UD_ATTN_PIPE_ABL & 1)) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) sc[kb] = sn[kb];
