@@ -494,7 +494,6 @@ def extra_configs(torch, model_v2, dev, cpu=True):
         cfg1 = synth_v1.load_config_v1()
         sd1 = synth_v1.make_synthetic_checkpoint_v1(cfg1, 211)
         m1 = UniDepthV1(cfg1).load_state_dict(sd1).to(dev).eval()
-        m1.nystrom_caveat_acknowledged = True
         B1 = 16
         rgb1 = torch.randint(0, 256, (B1, 3, 480, 640), dtype=torch.uint8, generator=torch.Generator().manual_seed(1)).to(dev)
         dt = _timed_calls(torch, lambda: m1.infer(rgb1), 10, warm=3)

@@ -202,18 +202,8 @@ typedef struct UdAttention {
   int kv_group;           /* with kv_broadcast: image i uses the K/V of image i / kv_group (0 -> all share image 0) */
   int q_prescaled;        /* != 0: Q already holds q * scale * log2(e) (folded into the q projection by the caller): `scale` is ignored and the
                            * kernel skips the per-score multiply (softmax(q k^T scale) is unchanged) */
-  int k_chunk;            /* > 0 (multiple of 64, with `part`, q_prescaled == 0): SPLIT-KEY mode for few queries against many keys (the Nystrom
-                           * kernel_3 product softmax(q_landmarks K^T) V, layers/nystrom_attention.py:59-62 -> xformers NystromAttention): the
-                           * keys are cut into NC = ceil(ceil(Nk / 64) * 64 / k_chunk) chunks, one workgroup per (image, head, 128 queries, chunk);
-                           * O is not written (may be NULL); ud_attention_merge_f32 combines the chunks */
-  float* part;            /* split-key mode: fp32 [B][NC][H * Nq][UD_ATTN_PART_LD]: 64 un-normalised outputs sum_k exp(s_k - m) v_k, then
-                           * m (running maximum of scale * q.k, natural-log units) and sum_k exp(s_k - m); written completely */
 } UdAttention;
-#define UD_ATTN_PART_LD 68
 int ud_attention_f16(const UdAttention* desc, void* stream);
-/* split-key mode, second step: out fp32 [H][B][Nq][64] (head-major: the (head, image) order of the Nystrom pseudo-inverse batch) =
- * sum_c part_c exp(m_c - M) / sum_c l_c exp(m_c - M) (+ bias[h * 64 + d] if bias != NULL), M = max_c m_c. */
-int ud_attention_merge_f32(const float* part, const float* bias, float* out, int B, int NC, int H, int Nq, void* stream);
 
 /* ---- pre-processing + im2col for the 14x14 patch embedding ---------------------------------------------
  * Replaces unidepthv2.py:288-297 (/255, ImageNet mean/std, zero pad, bilinear align_corners=False resize) and
@@ -337,20 +327,16 @@ int ud_spatial_mean_f32(const float* x, float* out, int B, int HW, int C, int ld
  *                a = q fp32 [B*T, D], b = kv fp16 [B*Nk, 2D] = [K | V], out fp32 [B*T, D].  i = B, T, Nk, D; f[0] = scale
  *                c (optional) = fp32 scratch of B * ceil(Nk / 64) * T * (D + 2) floats: the keys are then processed in chunks of 64 by
  *                separate workgroups and merged in a second launch (deterministic order)
- *  SEGMENT_MEAN  Nystrom landmark pooling (xformers AvgPool): fp16 [G, N, ldi] -> n segment means, fp16 out and optional fp32 out2.  i = G, N, C, n, ldi, ldo
- *  BMM           out[g] = f[1] * I + f[0] * a[g] b[g], small fp32 matrices (Newton-Schulz pseudo-inverse of xformers iterative_pinv).  i = G, M, N, K;
- *                out2 != NULL: also out2[g] = f[3] * I + f[2] * a[g] b[g] (KZ and 7 I - KZ from one product)
- *  PINV_INIT     Z0 = K^T / max column sum (iterative_pinv initialisation).  i = G, n
+ *  HEAD_MIX      the attention of layers_8 / layers_4 AS THE REFERENCE COMPUTES IT (layers/nystrom_attention.py:59-62,81: q, k, v go to xformers
+ *                NystromAttention as [b, n, h, d]; its `seq_len = k.size(-2)` is then h <= num_landmarks, so it takes its plain-softmax branch
+ *                over the last two axes): per token, softmax((q_i / sqrt d) . k_j over the h heads j) v_j.  a = q fp32 [M, ldq], b = [K | V] fp32
+ *                [M, ldkv], out fp16 [M, ldo]; head width 64.  i = M, h (2 / 4 / 8), ldq, ldkv, ldo; f[0] = 1 / sqrt(d)
  *  ADD           out = a + b (fp32; latents + ray embedding, decoder.py:263,283,303).  i = n & 0x7fffffff, n >> 31
  *  COPY_ROWS     out[(img*rows_per_img + row_off + t)*ld + d] = a[(img*T + t)*D + d] (torch.cat of token groups).  i = n_img, T, rows_per_img, row_off, D, ld, to_f16
  *                to_f16 == 2 (ld >= 2 D): the value as TWO fp16 terms, hi at column d and lo = fp16(x - hi) at column D + d -- the A operand
  *                [A_hi | A_lo] of a three-term product against [W_hi | W_hi | W_lo] (UdGemm.a_wrap = 2 K)
  *  RESIZE_AC_SPLIT  nn.UpsamplingBilinear2d (align_corners=True, layers/upsample.py:34) of an fp32 NHWC map, written as [hi | lo] fp16
  *                (2 C channels per pixel) for the 3x3 convolution behind it.  i = B, Hin, Win, Hout, Wout, C (C % 4 == 0)
- *  TRANSPOSE16   fp32 [G, M, N] -> fp16 [G, N, ldo] transposed, zero padded.  i = G, M, N, ldo, nh, vt.  nh > 0: input groups (head, image)-major
- *                (g = head * G / nh + image), output groups (image, head)-major; vt != 0 (ldo % 16 == 0): output columns in the V^T block
- *                order of ud_attention_f16 -- together: T = pinv(kernel_2) kernel_3 v as the V^T operand of the Nystrom output attention
- *  ATTN_MERGE    ud_attention_merge_f32 as a program op: a = part, b = bias or NULL, out; i = B, NC, H, Nq
  *  CAMERA        raw [B*4] -> K33 (out), its inverse (out2), post-processed K (c) (decoder.py:85-99,347-353; unidepthv1.py:88-92).
  *                i = B, Hn, Wn, pad_l, pad_t; f[0] = ratio
  *  POINTS        z map + K33 -> points [B,3,H,W] (out), depth [B,1,H,W] (out2) (unidepthv1.py:353-371; utils/geometric.py:45-73).  i = B, H, W, ldz, nK
@@ -360,9 +346,8 @@ int ud_spatial_mean_f32(const float* x, float* out, int B, int HW, int C, int ld
  *                (optional) = the raw class tokens [B, D].  i = B, Np, hw, D, init
  *  PREPROCESS    V1 network image (unidepthv1.py:305-321,50-56): [/255], ImageNet normalise, antialiased resize to (h, w), zero pad to (Hn, Wn).
  *                i = B, H, W, h, w, Hn, Wn, pad_l, pad_t, is_u8, div255, normalize */
-enum { UD_V1_RESIZE_AA = 1, UD_V1_SH_EMBED, UD_V1_SOFTMAX, UD_V1_ATTN_FEWQ, UD_V1_SEGMENT_MEAN, UD_V1_BMM, UD_V1_PINV_INIT, UD_V1_ADD,
-       UD_V1_COPY_ROWS, UD_V1_TRANSPOSE16, UD_V1_CAMERA, UD_V1_POINTS, UD_V1_MEAN3, UD_V1_PREPROCESS, UD_V1_VIT_TAP, UD_V1_ATTN_MERGE,
-       UD_V1_RESIZE_AC_SPLIT };
+enum { UD_V1_RESIZE_AA = 1, UD_V1_SH_EMBED = 2, UD_V1_SOFTMAX = 3, UD_V1_ATTN_FEWQ = 4, UD_V1_HEAD_MIX = 5, UD_V1_ADD = 8, UD_V1_COPY_ROWS = 9,
+       UD_V1_CAMERA = 11, UD_V1_POINTS = 12, UD_V1_MEAN3 = 13, UD_V1_PREPROCESS = 14, UD_V1_VIT_TAP = 15, UD_V1_RESIZE_AC_SPLIT = 17 };
 typedef struct UdV1Op {
   int kind;
   const void* a; const void* b; void* c; void* out; void* out2;

@@ -38,7 +38,7 @@ def main():
     d["cls_last4"] = torch.cat([cls[-i - 1] for i in range(4)], dim=-1).numpy()
     np.savez_compressed(os.path.join(OUT, "v1_convnext_128x160.npz"), **d)
     print({k: v.shape for k, v in d.items()})
-    # whole infer(): the reference's own decoder / pre- / post-processing with the restated NystromAttention stub (PARITY UNPINNED there)
+    # whole infer(): the reference's own decoder / pre- / post-processing on the statement-by-statement restatement of xformers NystromAttention (oracle/stubs/xformers)
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(OUT)))
     from test_oracle_v1_pins import V1_CASES, v1_case_inputs, v1_digest

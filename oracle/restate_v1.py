@@ -87,27 +87,18 @@ class OracleConvNeXt:
 # utils/geometric.py:12-73,227-252 (generate_rays, spherical_zbuffer_to_euclidean, flat_interpolate), utils/sht.py:833 (rsh_cart_8),
 # unidepthv1.py:28-98,288-373 (pre / post-processing, infer).
 #
-# PARITY UNPINNED for layers_8 / layers_4 (NystromBlock, layers/nystrom_attention.py:22-84): their attention is
-# xformers.components.attention.NystromAttention(num_landmarks=128) -- requirements.txt:24 `xformers>=0.0.26`, un-vendored, absent here,
-# and the reference cannot execute without it.  `nystrom_attention()` below restates the PUBLISHED algorithm of that class
-# (Xiong et al. 2021 as implemented by xformers: segment-mean landmarks, three softmax kernels, 6 Newton-Schulz iterations for the
-# pseudo-inverse with the exact 1/||K||_1 initialisation, no skip connection, no dropout at inference) applied per head over the
-# token axis.  Everything else of the decoder is pinned by running the reference's own decoder with this function plugged in as
-# xformers' NystromAttention (oracle/stubs/xformers).
-#
-# What exactly is ASSUMED about the un-reproducible call (layers/nystrom_attention.py:59-62,81):
-#   * the reference passes q, k, v as 4-D [b, n, h, d] (einops "b n (h d) -> b n h d") and reads the result back as "b n h d";
-#   * this restatement takes that to MEAN: for every (image b, head h) independently, Nystrom attention of the n tokens' d-wide
-#     q / k / v rows -- landmarks = means over 128 consecutive token segments (xformers AvgPool rule for n % 128 != 0: the first
-#     128 - n % 128 segments hold floor(n / 128) tokens, the others one more), kernels softmax(q kl^T / sqrt d), softmax(ql kl^T / sqrt d),
-#     softmax(ql k^T / sqrt d) v, pseudo-inverse by 6 Newton-Schulz steps from Z0 = K^T / max column sum (per matrix);
-#   * xformers' module is written for 3-D [N, S, hs] inputs (heads folded into the batch by its MultiHeadDispatch); with a 4-D input
-#     its `seq_len = k.size(-2)` reads the HEAD count and its AvgPool reads x.shape[2] (= h) as the head width, so what the deployed
-#     build really computes for the reference's layout may be something else (e.g. a shape error, or a degenerate attention across the
-#     h heads of each token).  Without the package this cannot be decided here.
-# Single-source risk on the ALGORITHM is removed by tests/test_oracle_nystrom_cpu.py: nystrom_attention / iterative_pinv /
-# segment_means agree to fp32 round-off with Hugging Face's independent NystromformerSelfAttention (installed: transformers).  The LAYOUT
-# question stays open, so parity of layers_8 / layers_4 with released weights is UNPINNED and the engine warns (unidepth_amd/hub.py).
+# layers_8 / layers_4 (NystromBlock, layers/nystrom_attention.py:22-84): their attention is xformers.components.attention.NystromAttention(
+# num_landmarks=128) -- requirements.txt:24 `xformers>=0.0.26`, un-vendored and absent here.  oracle/stubs/xformers/components/attention is a
+# statement-by-statement restatement of that module (nystrom.py forward + AvgPool, core.py scaled_query_key_softmax / scaled_dot_product_attention,
+# utils.py iterative_pinv of xformers v0.0.26) and the live reference runs on it (tests/test_oracle_v1_pins.py).  The finding (round 5): the
+# reference hands it 4-D [b, n, h, d] tensors (einops "b n (h d) -> b n h d"); the module reads `seq_len = k.size(-2)` = h (4 / 2 heads), finds
+# `num_landmarks (128) >= seq_len` and takes its small-sequence branch, plain softmax attention over the last two axes: every token's h
+# head-vectors attend to EACH OTHER, att = softmax(q k^T / sqrt d) in [b, n, h, h], out = att v.  No landmarks, no pseudo-inverse, no mixing
+# between tokens.  `nystrom_block_attention()` below states that; rounds 2-4 had restated the PAPER's algorithm per head over the token axis
+# (`nystrom_attention()`, kept because tests/test_oracle_nystrom_cpu.py triangulates it against Hugging Face's Nystromformer and the engine's
+# split-key flash kernel is tested against it), which is NOT what the reference's module computes for this layout.
+# The pin is as strong as the restatement of the two load-bearing lines (`seq_len = k.size(-2)`, `if self.num_landmarks >= seq_len:`): the
+# package cannot be executed here.
 # =====================================================================================================================
 def real_sh_deg8(xyz: torch.Tensor) -> torch.Tensor:
     """Real spherical harmonics up to degree 8 at unit vectors xyz [..., 3] -> [..., 81], Y_n^m at index n(n+1)+m, Condon-Shortley
@@ -174,8 +165,16 @@ def segment_means(x: torch.Tensor, n: int) -> torch.Tensor:
     return torch.cat([a, b], dim=1)
 
 
+def nystrom_block_attention(q, k, v):
+    """What xformers' NystromAttention computes for the reference's 4-D call (see the note above): q, k, v [B, N, h, d] ->
+    softmax(q k^T / sqrt d over the h heads of each token) v, [B, N, h, d].  xformers core.py scaled_dot_product_attention: q / sqrt(d) first."""
+    att = torch.softmax((q / math.sqrt(k.shape[-1])) @ k.transpose(-2, -1), dim=-1)
+    return att @ v
+
+
 def nystrom_attention(q, k, v, num_landmarks: int = 128):
-    """q, k, v [BH, N, d] -> [BH, N, d] (see the PARITY UNPINNED note above)."""
+    """The PUBLISHED Nystrom algorithm per (image, head) over the token axis: q, k, v [BH, N, d] -> [BH, N, d].  Not what the reference's
+    layers_8 / layers_4 compute (note above); kept for the kernel tests of the split-key flash attention and the HF triangulation."""
     N, d = k.shape[-2], k.shape[-1]
     if num_landmarks == N:
         return F.scaled_dot_product_attention(q, k, v)
@@ -323,12 +322,13 @@ class OracleV1(OracleConvNeXt):
 
         def split(t):
             return t.reshape(t.shape[0], t.shape[1], heads, d).permute(0, 2, 1, 3)
-        q, k, v = split(q), split(k), split(v)
         if nystrom:
-            o = nystrom_attention(q.reshape(B * heads, N, d), k.reshape(B * heads, -1, d), v.reshape(B * heads, -1, d)).reshape(B, heads, N, d)
+            # layers/nystrom_attention.py:59-62,81: "b n (h d) -> b n h d" into xformers NystromAttention, read back as "b n h d"
+            o = nystrom_block_attention(q.reshape(B, N, heads, d), k.reshape(B, -1, heads, d), v.reshape(B, -1, heads, d)).reshape(B, N, C)
         else:
-            o = F.scaled_dot_product_attention(q, k, v)
-        o = self._lin(o.permute(0, 2, 1, 3).reshape(B, N, C), p + "out")
+            q, k, v = split(q), split(k), split(v)
+            o = F.scaled_dot_product_attention(q, k, v).permute(0, 2, 1, 3).reshape(B, N, C)
+        o = self._lin(o, p + "out")
         x = o * self.w[p + "ls1.gamma"] + x
         return self._mlp(x, p + "mlp.") * self.w[p + "ls2.gamma"] + x
 

@@ -370,19 +370,11 @@ def test_v1_every_gemm_weight_is_two_terms_by_default():
     assert U._wk(U._padk16(torch.zeros(8, dims[0]), split=False), dims[0]) == dict(K=dims[0], ldw=dims[0])
 
 
-def test_v1_nystrom_plan_and_fused_kv_packing():
-    """Host side of the Nystrom stages as flash attention: the split-key plan covers every 64-key tile exactly once with no empty chunk and
-    lands near the workgroup target; the decoder packer stores ONE [K | V] weight per Nystrom block (K rows first, as the reference's
-    `kv` Linear + 'b n (kv h d)' rearrange orders them, layers/nystrom_attention.py:59-62) with the context LayerNorm folded in."""
+def test_v1_nystrom_block_fused_kv_packing():
+    """The decoder packer stores ONE [K | V] weight per NystromBlock (K rows first, as the reference's `kv` Linear + 'b n (kv h d)' rearrange
+    orders them, layers/nystrom_attention.py:59-62) with the context LayerNorm folded in."""
     from unidepth_amd import unidepthv1 as U
     from oracle import synth_v1
-    for nt in (1, 2, 18, 75, 76, 300, 301, 1200):
-        for pairs in (1, 2, 8, 32, 64, 256, 4096):
-            tpc, nc = U.nystrom_key_chunks(nt, pairs)
-            assert tpc >= 1 and nc >= 1 and (nc - 1) * tpc < nt <= nc * tpc, (nt, pairs, tpc, nc)
-            assert nc == 1 or pairs * nc <= 2 * 1024 or tpc == 1, (nt, pairs, tpc, nc)
-    assert U.nystrom_key_chunks(300, 32) == (10, 30) and U.nystrom_key_chunks(75, 64) == (5, 15)      # bs 16 at 640x480: 1/4 and 1/8 levels
-    assert U.NYS_FLASH
     cfg = synth_v1.load_config_v1()
     sd = synth_v1.make_synthetic_checkpoint_v1(cfg, 211)
     w = U.pack_v1_decoder(cfg, sd, torch.device("cpu"))
@@ -480,7 +472,7 @@ def test_v1_plan_builder_dry_run_validates_every_gemm_descriptor(monkeypatch):
         return real_add(h, dref)
     monkeypatch.setattr(ops.lib, "ud_program_add_gemm", add)
     plan = m._full_plan(1, 240, 320, True, False, True, 0, False)
-    assert len(plan.prog) > 400 and len(seen) > 150
+    assert len(plan.prog) > 300 and len(seen) > 150      # (round 5: the NystromBlocks lost their ~90 landmark / pseudo-inverse launches)
     bad = [r for r in seen if r[0] != -2]                     # -2 = UD_ERR_LAUNCH (include/unidepth_hip.h)
     assert not bad, bad[:3]                                    # UD_ERR_BAD_ARG would mean a descriptor the kernels refuse
     three = [r for r in seen if r[5] and (3 * r[5] == 2 * r[4] or (r[6] and 3 * r[5] == 2 * r[6]))]

@@ -801,84 +801,6 @@ def test_attention(ops, B, H, Nq, Nk, bc):
     assert qr == Nq or o[:, Nq:].abs().max() == 0
 
 
-@pytest.mark.parametrize("B,H,Nq,Nk,chunk", [(2, 2, 128, 4800, 320), (1, 2, 128, 4524, 64), (3, 4, 128, 1131, 448), (2, 1, 100, 700, 128), (1, 2, 128, 19200, 640),
-                                             (1, 1, 128, 64, 64), (2, 3, 300, 1000, 256), (9, 1, 129, 200, 64)])
-def test_attention_split_keys(ops, B, H, Nq, Nk, chunk):
-    """Split-key mode of ud_attention_f16 (UdAttention.k_chunk / part) + ud_attention_merge_f32: softmax(q k^T scale) v for few queries over many
-    keys -- the Nystrom kernel_3 product.  Chunked partials (un-normalised o, running max in natural-log units, row sum) merged into the
-    (head, image)-major fp32 batch with the value bias added; ragged last chunks and key tails; a spiked key far from chunk 0 so that the
-    chunks' maxima differ by orders of magnitude."""
-    from unidepth_amd import _lib as L
-    D = H * 64
-    qr, kr = ((Nq + 7) // 8) * 8, ((Nk + 7) // 8) * 8
-    kv_ld = ((Nk + 63) // 64) * 64
-    q = rnd(B, qr, D, seed=1).half()
-    kk = rnd(B, kr, D, seed=2).half()
-    if Nk > 600:
-        kk[0, 555, :64] = q[0, 3, :64] * 3.0
-    v = rnd(B, kr, D, seed=3).half()
-    vt = torch.zeros(B, H, 64, kv_ld, dtype=torch.half, device="cuda")
-    vt[..., vt_cols(Nk)] = v[:, :Nk].view(B, Nk, H, 64).permute(0, 2, 3, 1)
-    nt = kv_ld // 64
-    nc = -(-nt // (chunk // 64))
-    part = torch.full((B * nc * H * Nq, L.UD_ATTN_PART_LD), float("nan"), device="cuda")
-    bias = rnd(D, seed=4)
-    out = torch.zeros(H, B, Nq, 64, device="cuda")
-    scale = 0.125
-    ops.attention(Q=q, K=kk, Vt=vt, O=None, B=B, H=H, Nq=Nq, Nk=Nk, ldq=D, ldk=D, ldo=D, kv_ld=kv_ld, q_rows_per_img=qr, k_rows_per_img=kr, scale=scale,
-                  k_chunk=chunk, part=part)
-    ops.attention_merge(part, bias, out, B, nc, H, Nq)
-    qf = q[:, :Nq].float().view(B, Nq, H, 64).permute(0, 2, 1, 3)
-    kf = kk[:, :Nk].float().view(B, Nk, H, 64).permute(0, 2, 1, 3)
-    vf = v[:, :Nk].float().view(B, Nk, H, 64).permute(0, 2, 1, 3)
-    ref = torch.softmax(qf @ kf.transpose(-1, -2) * scale, dim=-1) @ vf + bias.view(1, H, 1, 64)          # [B, H, Nq, 64]
-    torch.cuda.synchronize()
-    assert not torch.isnan(part[:, :66]).any()                                       # every partial row written
-    assert rel(out.permute(1, 0, 2, 3), ref) < 2e-3
-    # one chunk holding all keys == the chunked result up to fp32 reassociation
-    part1 = torch.zeros(B * H * Nq, L.UD_ATTN_PART_LD, device="cuda"); out1 = torch.zeros_like(out)
-    ops.attention(Q=q, K=kk, Vt=vt, O=None, B=B, H=H, Nq=Nq, Nk=Nk, ldq=D, ldk=D, ldo=D, kv_ld=kv_ld, q_rows_per_img=qr, k_rows_per_img=kr, scale=scale,
-                  k_chunk=kv_ld, part=part1)
-    ops.attention_merge(part1, bias, out1, B, 1, H, Nq)
-    torch.cuda.synchronize()
-    assert rel(out1, out) < 2e-3                                                     # per-chunk fp16 P with different maxima: same class as above
-
-
-def test_attention_split_keys_rejects(ops):
-    from unidepth_amd import _lib as L
-    q = rnd(1, 128, 64).half(); vt = torch.zeros(1, 1, 64, 128, dtype=torch.half, device="cuda"); part = torch.zeros(128, L.UD_ATTN_PART_LD, device="cuda")
-    base = dict(Q=q, K=q, Vt=vt, O=None, B=1, H=1, Nq=128, Nk=128, ldq=64, ldk=64, ldo=64, kv_ld=128, q_rows_per_img=128, k_rows_per_img=128, scale=1.0)
-    for bad in (dict(k_chunk=96, part=part), dict(k_chunk=64, part=None), dict(k_chunk=64, part=part, q_prescaled=1), dict(k_chunk=64, part=part, kv_broadcast=1)):
-        with pytest.raises(RuntimeError):
-            ops.attention(**{**base, **bad})
-    with pytest.raises(RuntimeError):                                                # O may be NULL in split mode only
-        ops.attention(**base)
-
-
-def test_v1_transpose_to_attention_vt(ops):
-    """UD_V1_TRANSPOSE16 with (nh, vt): the (head, image)-major fp32 batch T [G, 128, 64] becomes the V^T operand [image][head][64][128] of
-    ud_attention_f16 (V^T block order) -- checked by running the attention on it against torch."""
-    from unidepth_amd import _lib as L
-    B, nh, Lm, n = 3, 2, 128, 300
-    G = nh * B
-    T = rnd(G * Lm, 64, seed=5)
-    Tt = torch.zeros(B, nh, 64, Lm, dtype=torch.half, device="cuda")
-    ops.v1_op(L.UD_V1_TRANSPOSE16, a=T, out=Tt, i=(G, Lm, 64, Lm, nh, 1))
-    torch.cuda.synchronize()
-    want = T.view(nh, B, Lm, 64).permute(1, 0, 3, 2).half()                           # [B, nh, 64, Lm] natural column order
-    got = torch.zeros_like(Tt); got[..., :] = Tt[..., vt_cols(Lm)]
-    assert torch.equal(got, want)
-    D = nh * 64
-    q = rnd(B, 304, D, seed=6).half(); kl = rnd(B, Lm, D, seed=7).half()
-    o = torch.zeros(B, 304, D, dtype=torch.half, device="cuda")
-    ops.attention(Q=q, K=kl, Vt=Tt, O=o, B=B, H=nh, Nq=n, Nk=Lm, ldq=D, ldk=D, ldo=D, kv_ld=Lm, q_rows_per_img=304, k_rows_per_img=Lm, scale=0.125)
-    qf = q[:, :n].float().view(B, n, nh, 64).permute(0, 2, 1, 3); kf = kl.float().view(B, Lm, nh, 64).permute(0, 2, 1, 3)
-    vf = T.view(nh, B, Lm, 64).permute(1, 0, 2, 3).half().float()
-    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * 0.125, dim=-1) @ vf).permute(0, 2, 1, 3).reshape(B, n, D)
-    torch.cuda.synchronize()
-    assert rel(o[:, :n].float(), ref) < 2e-3
-
-
 def test_attention_spiked_rows(ops):
     """online-softmax rescale path: one key row dominates late in the sequence (max jumps at a late tile)."""
     B, H, N = 1, 1, 300

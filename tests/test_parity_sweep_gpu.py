@@ -177,7 +177,6 @@ def test_v1_depth_error_distribution(arch):
         sd = synth_v1.make_synthetic_checkpoint_v1(cfg, seed)
         orc = restate_v1.OracleV1(cfg, sd)
         model = UniDepthV1(cfg).load_state_dict(sd).to("cuda").eval()
-        model.nystrom_caveat_acknowledged = True
         for (H, W) in ((240, 320), (480, 640)):
             rgb = torch.randint(0, 256, (1, 3, H, W), dtype=torch.uint8, generator=torch.Generator().manual_seed(seed + H))
             out = model.infer(rgb.cuda())

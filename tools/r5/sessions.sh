@@ -38,4 +38,27 @@ timeout 900 python tools/attn_ab.py --rounds 2 classic pipe fd4 nw2 abl1 abl3 ab
 cat $O/attn_abl.txt
 }
 
+# round 5, GPU call 3: the one-tile-at-a-time kernel with the cheap VALU savings of the pipelined one (c1 permlane exchange, c2 matrix-pipe row
+# sums, c3 both), and the pipelined kernel ROLLED (one tile per trip: 149-173 registers instead of 252 -> three waves per SIMD)
+call3() {
+O=gpurun_out/r5c3 && mkdir -p $O
+timeout 900 python tools/attn_ab.py --rounds 2 classic pipe c1 c2 c3 roll r3o2 r3o3 r3o0 2>&1 | grep -v amdgpu.ids > $O/attn_ab.txt
+cat $O/attn_ab.txt
+}
+
+# round 5, GPU call 4: UniDepthV1 with the NystromBlocks as the reference executes them (UD_V1_HEAD_MIX): kernel + model tests, the V1 parity sweeps,
+# the V1 bench at BASELINE configs[3]; the attention kernel tests again (split-key mode removed)
+call4() {
+O=gpurun_out/r5c4 && mkdir -p $O
+t0=$(date +%s)
+timeout 900 python -m pytest tests/test_v1_gpu.py -q -m gpu -x 2>&1 | grep -v "^$\|amdgpu.ids" | tail -15 > $O/v1_tests.txt
+echo "[v1 tests done $(( $(date +%s) - t0 )) s]" >> $O/v1_tests.txt
+timeout 300 python -m pytest tests/test_kernels_gpu.py -q -m gpu -k "attention" 2>&1 | grep -v "^$\|amdgpu.ids" | tail -5 > $O/attn_tests.txt
+timeout 900 python -m pytest tests/test_parity_sweep_gpu.py -q -s -m gpu -k "v1" 2>&1 | grep -v "^$\|amdgpu.ids" | tail -80 > $O/sweep_v1.txt
+echo "[v1 sweeps done $(( $(date +%s) - t0 )) s]" >> $O/sweep_v1.txt
+timeout 400 python tools/bench_v1.py > $O/bench_v1.txt 2>&1
+timeout 400 python tools/bench_v1.py --by-tag > $O/bench_v1_tags.txt 2>&1
+cat $O/v1_tests.txt $O/attn_tests.txt; tail -60 $O/sweep_v1.txt; tail -12 $O/bench_v1.txt; tail -45 $O/bench_v1_tags.txt
+}
+
 "$@"

@@ -14,7 +14,7 @@ def __getattr__(name):
     if name == "UniDepthV2":
         from .unidepthv2 import UniDepthV2
         return UniDepthV2
-    if name in ("UniDepthV1", "UniDepth"):            # hubconf-style entry point / the V1 family (ConvNeXt-L; see hub.py for the Nystrom caveat)
+    if name in ("UniDepthV1", "UniDepth"):            # hubconf-style entry point / the V1 family (ConvNeXt-L / ViT-L)
         from . import hub
         return getattr(hub, name)
     raise AttributeError(name)

@@ -66,19 +66,17 @@ class UdExtractPatches(C.Structure):
                 ("h", i32), ("w", i32), ("pad_h", i32), ("pad_w", i32)]
 
 
-(UD_V1_RESIZE_AA, UD_V1_SH_EMBED, UD_V1_SOFTMAX, UD_V1_ATTN_FEWQ, UD_V1_SEGMENT_MEAN, UD_V1_BMM, UD_V1_PINV_INIT, UD_V1_ADD, UD_V1_COPY_ROWS,
- UD_V1_TRANSPOSE16, UD_V1_CAMERA, UD_V1_POINTS, UD_V1_MEAN3, UD_V1_PREPROCESS, UD_V1_VIT_TAP, UD_V1_ATTN_MERGE, UD_V1_RESIZE_AC_SPLIT) = range(1, 18)
+(UD_V1_RESIZE_AA, UD_V1_SH_EMBED, UD_V1_SOFTMAX, UD_V1_ATTN_FEWQ, UD_V1_HEAD_MIX) = range(1, 6)
+(UD_V1_ADD, UD_V1_COPY_ROWS) = (8, 9)
+(UD_V1_CAMERA, UD_V1_POINTS, UD_V1_MEAN3, UD_V1_PREPROCESS, UD_V1_VIT_TAP) = range(11, 16)
+UD_V1_RESIZE_AC_SPLIT = 17
 UD_ACT_CLAMPEXP = 3
-
-
-UD_ATTN_PART_LD = 68          # floats per row of UdAttention.part (include/unidepth_hip.h)
 
 
 class UdAttention(C.Structure):
     _fields_ = [("Q", vp), ("K", vp), ("Vt", vp), ("O", vp), ("B", i32), ("H", i32), ("Nq", i32), ("Nk", i32),
                 ("ldq", i32), ("ldk", i32), ("ldo", i32), ("kv_ld", i32), ("q_rows_per_img", i32),
-                ("k_rows_per_img", i32), ("scale", f32), ("kv_broadcast", i32), ("kv_group", i32), ("q_prescaled", i32),
-                ("k_chunk", i32), ("part", vp)]
+                ("k_rows_per_img", i32), ("scale", f32), ("kv_broadcast", i32), ("kv_group", i32), ("q_prescaled", i32)]
 
 
 class UdPreprocess(C.Structure):
@@ -120,7 +118,6 @@ def _load():
         "ud_gemm_pick": [P(UdGemm)],
         "ud_layernorm_f32_f16": [P(UdLayerNorm), vp],
         "ud_attention_f16": [P(UdAttention), vp],
-        "ud_attention_merge_f32": [vp, vp, vp, i32, i32, i32, i32, vp],
         "ud_row_stats_finalize": [vp, vp, i32, i32, i32, f32, vp],
         "ud_program_add_row_stats_finalize": [vp, vp, vp, i32, i32, i32, f32],
         "ud_linear_f32": [P(UdLinearF32), vp],
@@ -186,7 +183,7 @@ def _load():
     lib.ud_last_error.restype = C.c_char_p
     for i, st in enumerate([UdGemm, UdLayerNorm, UdAttention, UdPreprocess, UdRayEmbed, UdUpsample2x, UdResizeAC, UdFinalize, UdLinearF32, UdDwConv7, UdV1Op, UdKnn, UdExtractPatches]):
         # a library whose descriptors differ from this mirror in ANY way is a hard error (A/B runs rebuild both arms from one tree:
-        # an older .so would read the appended fields -- a_wrap, row_stats_*, k_chunk -- as garbage or not at all)
+        # an older .so would read the appended fields -- a_wrap, row_stats_* -- as garbage or not at all)
         if lib.ud_struct_size(i) != C.sizeof(st):
             raise ImportError(f"ctypes mirror of {st.__name__} is out of sync with include/unidepth_hip.h "
                               f"({C.sizeof(st)} vs {lib.ud_struct_size(i)} bytes)")

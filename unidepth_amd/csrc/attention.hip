@@ -23,29 +23,24 @@
 //       VALU turns the scores of tile t into probabilities and reduces the row maximum of tile t+1, so MFMA and VALU instructions of
 //       INDEPENDENT data alternate in one instruction stream (the round-4 counters showed the one-tile-at-a-time form running the two
 //       pipes one after the other: MFMA busy 37 % + VALU busy 59 % = 96 % of the SIMD cycles, with four waves per SIMD).
-//   attention_kernel       the one-tile-at-a-time form (rounds 1-4): raw Q (MODE 0: one fma per score), split-key mode for the Nystrom
-//       kernel_3 product, and the tested fallback of the pipelined kernel (-DUD_ATTN_PIPE=0).
+//   attention_kernel       the one-tile-at-a-time form (rounds 1-4): raw Q (MODE 0: one fma per score), and the tested fallback of the
+//       pipelined kernel (-DUD_ATTN_PIPE=0).
 #include "ud_common.h"
 #include <type_traits>
 
 #ifndef UD_ATTN_PIPE
 #define UD_ATTN_PIPE 1          // 0: pre-scaled Q takes the one-tile-at-a-time kernel (MODE 1) like rounds 2-4
 #endif
-#ifndef UD_ATTN_PIPE_OPT
-#define UD_ATTN_PIPE_OPT 3      // bit 0: the running offset enters Q K^T as the first MFMA's C operand from a persistent 16-register splat
-#endif                          //        (no 16 v_mov per tile); bit 1: row sums on the matrix pipe (v_mfma_f32_4x4x4_16b_f16 against ones)
-#ifndef UD_ATTN_PIPE_MINW
-#define UD_ATTN_PIPE_MINW 2     // waves per SIMD promised to the register allocator (2 -> 256 VGPRs, 3 -> 168)
-#endif
-#ifndef UD_ATTN_PIPE_NW
-#define UD_ATTN_PIPE_NW 4       // waves per workgroup of the pipelined kernel (4 or 8)
-#endif
-#ifndef UD_ATTN_PIPE_ABL
-#define UD_ATTN_PIPE_ABL 0      // tools builds only (tools/r5/sessions.sh): parts compiled OUT of the tile loop, results are wrong by construction --
-#endif                          // 1 barrier, 2 K / V^T DMA, 4 exp2 + pack, 8 Q K^T MFMAs, 16 P V MFMAs, 32 fragment reads from LDS, 64 row maximum
-#ifndef UD_ATTN_PIPE_FD
-#define UD_ATTN_PIPE_FD 3       // fragment register ring: a K / V^T fragment is read from LDS FD - 1 MFMAs ahead of its use
-#endif
+// Fixed choices of the pipelined kernel, each measured on the encoder shape (B = 8, H = 16, N = 1370; profiles/r05_attn_*.txt) -- the alternatives
+// were built as compile-time variants for the A/B runs and removed afterwards:
+//   OPT 3 (offset as MFMA C operand + matrix-pipe row sums) 91.1 us | without the C operand 93.2 | without the row-sum MFMAs 91.0 | neither 92.5
+//   4 waves per workgroup 91.1 | 8 waves 96.6 | 2 waves 95.3;  fragment ring 3 deep 89.5 | 4 deep 90.5 (5 spilled registers outside the loop)
+//   two tiles per loop trip (every LDS address = base + immediate, 252 registers, 2 waves per SIMD) 93.5 | one tile per trip (149-173 registers:
+//   3 waves per SIMD, but 33 more VALU moves per tile) 92.6-98.0
+#define UD_ATTN_PIPE_OPT 3
+#define UD_ATTN_PIPE_MINW 2
+#define UD_ATTN_PIPE_NW 4
+#define UD_ATTN_PIPE_FD 3
 
 namespace {
 
@@ -64,10 +59,7 @@ constexpr int STAGE = KS_BYTES + VS_BYTES;
 //   the running maximum is subtracted by the MFMA itself -- the score accumulators start at -m instead of 0 -- so P = exp2(S'') with
 //   no VALU in between.  A growing maximum (deferred, threshold 2^8) is handled on the rare path by shifting S''.
 // NW = waves per workgroup, 32 query rows each.
-// SPLIT: split-key mode (UdAttention.k_chunk / part): the workgroup covers ONE chunk of the keys and leaves its un-normalised accumulators,
-// running maximum and row sum in `part`; attention_merge_kernel combines the chunks.  For few queries against many keys (the Nystrom
-// kernel_3 product: 128 landmark queries x up to 19200 keys per (image, head) -- one workgroup per pair would walk 300 key tiles alone).
-template <int MODE, int NW = 4, bool SPLIT = false>
+template <int MODE, int NW = 4>
 __global__ __launch_bounds__(NW * 64) void attention_kernel(const UdAttention p, const float defer_thr) {
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   const int tid = threadIdx.x;
@@ -78,19 +70,14 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const UdAttention p,
   const int qt = (p.Nq + NW * 32 - 1) / (NW * 32);
   const int pairs = p.B * p.H;
   const int nt = (p.Nk + KT - 1) / KT;
-  const int tpc = SPLIT ? p.k_chunk / KT : nt;            // key tiles per chunk
-  const int nc = SPLIT ? (nt + tpc - 1) / tpc : 1;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int pr = xcd + 8 * (slot / (qt * nc));            // all q-tiles and chunks of a pair on one XCD, consecutive slots
+  const int pr = xcd + 8 * (slot / qt);                   // all q-tiles of a pair on one XCD, consecutive slots
   if (pr >= pairs) return;
   const int head = pr % p.H;
   const int img = pr / p.H;
   const int kimg = p.kv_broadcast ? (p.kv_group > 0 ? img / p.kv_group : 0) : img;
-  const int rem = slot % (qt * nc);
-  const int chunk = rem / qt;
-  const int q0 = (rem % qt) * (NW * 32) + wv * 32;
-  const int kt0 = chunk * tpc;
-  const int kt1 = SPLIT ? (kt0 + tpc < nt ? kt0 + tpc : nt) : nt;
+  const int q0 = (slot % qt) * (NW * 32) + wv * 32;
+  const int kt0 = 0, kt1 = nt;
 
   const half_t* Q = (const half_t*)p.Q;
   const half_t* K = (const half_t*)p.K;
@@ -266,27 +253,6 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const UdAttention p,
 
   const float l_tot = l_i + __shfl_xor(l_i, 32, 64);
   const int qr = q0 + ql;
-  if constexpr (SPLIT) {
-    // ---- split-key mode: un-normalised O^T, the running maximum in natural-log units (MODE 0: m_i is a raw score, P = exp(scale (s - m)))
-    //      and the row sum go to part[img][chunk][head * Nq + q][0..65]
-    if (qr < p.Nq) {
-      float* pp = p.part + ((((size_t)img * nc + chunk) * p.H + head) * p.Nq + qr) * UD_ATTN_PART_LD;
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = o[db][g * 4 + e];
-          *(f32x4*)(pp + db * 32 + g * 8 + 4 * hh) = v;
-        }
-      if (hh == 0) {
-        pp[64] = MODE ? m_i * 0.6931471805599453f : m_i * p.scale;
-        pp[65] = l_tot;
-      }
-    }
-    return;
-  }
   // ---- normalise and store O[q][head*64 + d]
   const float inv = 1.0f / l_tot;
   if (qr < p.Nq) {
@@ -450,10 +416,6 @@ __global__ __launch_bounds__(NW * 64, UD_ATTN_PIPE_MINW) void attention_pipe_ker
   auto ex = [&](auto A_) {
     constexpr int a = decltype(A_)::value;
     f32x2 pv;
-    if constexpr (UD_ATTN_PIPE_ABL & 4) {
-      pw[a] = __float_as_uint(sc[a >> 3][(a & 7) * 2]) ^ __float_as_uint(sc[a >> 3][(a & 7) * 2 + 1]);
-      return;
-    }
     pv[0] = __builtin_amdgcn_exp2f(sc[a >> 3][(a & 7) * 2]);
     pv[1] = __builtin_amdgcn_exp2f(sc[a >> 3][(a & 7) * 2 + 1]);
     if constexpr (!MSUM) ls += pv[0] + pv[1];
@@ -537,11 +499,8 @@ __global__ __launch_bounds__(NW * 64, UD_ATTN_PIPE_MINW) void attention_pipe_ker
     // (2) the first fragments (their LDS latency runs under the exponentials below), then the DMA of the tiles the NEXT iteration reads
     constexpr int F0 = LAST ? 8 : 0;                       // the last tile has no Q K^T half
 #pragma unroll
-    for (int i = F0; i < F0 + FD - 1; ++i) {
-      if constexpr (UD_ATTN_PIPE_ABL & 32) fr[i % FD] = qf[i & 3];
-      else fr[i % FD] = *(const half8*)frag_ptr(i, STG ^ 1, STG);
-    }
-    if constexpr (!LAST && !(UD_ATTN_PIPE_ABL & 2)) {
+    for (int i = F0; i < F0 + FD - 1; ++i) fr[i % FD] = *(const half8*)frag_ptr(i, STG ^ 1, STG);
+    if constexpr (!LAST) {
       issue_k(t + 2, STG);
       issue_v(t + 1, STG ^ 1);
     }
@@ -558,28 +517,17 @@ __global__ __launch_bounds__(NW * 64, UD_ATTN_PIPE_MINW) void attention_pipe_ker
     __builtin_amdgcn_sched_barrier(0);
     auto slot = [&](auto I_) {
       constexpr int i = decltype(I_)::value;
-      if constexpr (i + FD - 1 < 16 && i + FD - 1 >= F0 + FD - 1) {
-        if constexpr (UD_ATTN_PIPE_ABL & 32) fr[(i + FD - 1) % FD] = qf[i & 3];
-        else fr[(i + FD - 1) % FD] = *(const half8*)frag_ptr(i + FD - 1, STG ^ 1, STG);
-      }
+      if constexpr (i + FD - 1 < 16 && i + FD - 1 >= F0 + FD - 1) fr[(i + FD - 1) % FD] = *(const half8*)frag_ptr(i + FD - 1, STG ^ 1, STG);
       if constexpr (i < 8) {
-        if constexpr (!LAST) {
-          if constexpr (UD_ATTN_PIPE_ABL & 8) {
-            asm volatile("" ::"v"(fr[i % FD]));
-            if constexpr (i < 2) sn[i & 1] = negm;
-          } else {
-            mm_qk(I_, sn);
-          }
-        }
+        if constexpr (!LAST) mm_qk(I_, sn);
       } else {
-        if constexpr (UD_ATTN_PIPE_ABL & 16) asm volatile("" ::"v"(fr[i % FD]), "v"(pw[4 * ((i - 8) >> 1)]), "v"(pw[4 * ((i - 8) >> 1) + 3]));
-        else mm_pv(integral_constant<int, i - 8>{});
+        mm_pv(integral_constant<int, i - 8>{});
       }
       // row-sum MFMA k over pairs 2k, 2k+1 (packed in slots 2k-2, 2k-1): issued in slot 2k+1, well behind the v_cvt that wrote its operand
       if constexpr (i & 1) sm(integral_constant<int, (i / 2)>{});
       if constexpr (i < 14) ex(integral_constant<int, i + 2>{});
       // row maximum of S(t+1): complete after slot 7; block kb = 0 was finished by slot 6, so its half starts in slot 8
-      if constexpr (!LAST && KIND == 0 && i >= 8 && !(UD_ATTN_PIPE_ABL & 64)) {
+      if constexpr (!LAST && KIND == 0 && i >= 8) {
         constexpr int kb = (i - 8) >> 2, r0 = ((i - 8) & 3) * 4;
         if constexpr (i == 8) mx = sn[0][0];
         mx = fmaxf(fmaxf(mx, sn[kb][r0]), sn[kb][r0 + 1]);
@@ -602,7 +550,7 @@ __global__ __launch_bounds__(NW * 64, UD_ATTN_PIPE_MINW) void attention_pipe_ker
       }
       // (4) tiles of the next iteration landed (this wave's pieces; the barrier covers the others')
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if constexpr (!(UD_ATTN_PIPE_ABL & 1)) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) sc[kb] = sn[kb];
@@ -647,59 +595,17 @@ __global__ __launch_bounds__(NW * 64, UD_ATTN_PIPE_MINW) void attention_pipe_ker
   }
 }
 
-// split-key mode, second step: one 64-lane block per (image, head, query) row
-__global__ __launch_bounds__(64) void attention_merge_kernel(const float* part, const float* bias, float* out, int B, int NC, int H, int Nq) {
-  const int row = blockIdx.x;                       // (img * H + head) * Nq + q
-  const int q = row % Nq, ih = row / Nq;
-  const int head = ih % H, img = ih / H;
-  const int d = threadIdx.x;
-  const size_t cs = (size_t)H * Nq * UD_ATTN_PART_LD;
-  const float* pb = part + (size_t)img * NC * cs + ((size_t)head * Nq + q) * UD_ATTN_PART_LD;
-  float M = -__builtin_inff();
-  for (int c = 0; c < NC; ++c) M = fmaxf(M, pb[c * cs + 64]);
-  float L = 0.f, acc = 0.f;
-  for (int c = 0; c < NC; ++c) {
-    const float e = __expf(pb[c * cs + 64] - M);
-    L = fmaf(pb[c * cs + 65], e, L);
-    acc = fmaf(pb[c * cs + d], e, acc);
-  }
-  out[(((size_t)head * B + img) * Nq + q) * 64 + d] = acc / L + (bias ? bias[head * 64 + d] : 0.f);
-}
-
 }  // namespace
-
-extern "C" int ud_attention_merge_f32(const float* part, const float* bias, float* out, int B, int NC, int H, int Nq, void* stream) {
-  if (!part || !out || B <= 0 || NC <= 0 || H <= 0 || Nq <= 0) {
-    ud_set_error("ud_attention_merge_f32: bad argument");
-    return UD_ERR_BAD_ARG;
-  }
-  hipLaunchKernelGGL(attention_merge_kernel, dim3((unsigned)B * H * Nq), dim3(64), 0, (hipStream_t)stream, part, bias, out, B, NC, H, Nq);
-  UD_CHECK_LAUNCH("ud_attention_merge_f32 launch");
-  return UD_OK;
-}
 
 extern "C" int ud_attention_f16(const UdAttention* desc, void* stream) {
   const UdAttention& d = *desc;
-  const bool split = d.k_chunk > 0;
-  if (split && (!d.part || (d.k_chunk & 63) || d.q_prescaled || d.kv_broadcast)) {
-    ud_set_error("ud_attention_f16: split-key mode needs part, k_chunk % 64 == 0, q_prescaled == 0, kv_broadcast == 0");
-    return UD_ERR_BAD_ARG;
-  }
-  if (!d.Q || !d.K || !d.Vt || (!d.O && !split) || d.B <= 0 || d.H <= 0 || d.Nq <= 0 || d.Nk <= 0 || (d.ldq & 7) || (d.ldk & 7) ||
+  if (!d.Q || !d.K || !d.Vt || !d.O || d.B <= 0 || d.H <= 0 || d.Nq <= 0 || d.Nk <= 0 || (d.ldq & 7) || (d.ldk & 7) ||
       (d.ldo & 3) || (d.kv_ld & 63) || d.kv_ld < ((d.Nk + 63) & ~63)) {
     ud_set_error("ud_attention_f16: bad argument (ldq/ldk % 8, kv_ld % 64, kv_ld >= roundup(Nk, 64))");
     return UD_ERR_BAD_ARG;
   }
   const int pairs = d.B * d.H;
-  const int ntile = (d.Nk + 63) / 64;
   const float thr = (ud_debug_flags_host() & 1) ? -1.0f : 8.0f;
-  if (split) {
-    const int qt = (d.Nq + 127) / 128;
-    const int nc = (ntile + d.k_chunk / 64 - 1) / (d.k_chunk / 64);
-    hipLaunchKernelGGL((attention_kernel<0, 4, true>), dim3(8 * ((pairs + 7) / 8) * qt * nc), dim3(256), 0, (hipStream_t)stream, d, thr);
-    UD_CHECK_LAUNCH("ud_attention_f16 (split-key) launch");
-    return UD_OK;
-  }
   if (UD_ATTN_PIPE != 0 && d.q_prescaled) {
     constexpr int NW = UD_ATTN_PIPE_NW;
     const int qt = (d.Nq + NW * 32 - 1) / (NW * 32);

@@ -403,133 +403,44 @@ __global__ __launch_bounds__(256) void fewq_merge_kernel(const float* part, floa
   }
 }
 
-// ------------------------------------------------------------------------------------------------ Nystrom pieces
-// landmark pooling (xformers AvgPool): [G, N, C] fp16 -> n segment means per group, fp16 (GEMM operand) and fp32
-__global__ __launch_bounds__(256) void segment_mean_kernel(const half_t* in, half_t* out16, float* out32, int N, int C, int n, int ldi, int ldo) {
-  const int g = blockIdx.y, s = blockIdx.x;
-  const int seg = N / n, nround = n - N % n;
-  const int start = s < nround ? s * seg : nround * seg + (s - nround) * (seg + 1);
-  const int len = (N % n == 0 || s < nround) ? seg : seg + 1;
-  const int pairs = C >> 1;
-  if ((C & 1) == 0 && (ldi & 1) == 0 && pairs <= 256) {
-    // channel PAIRS across the lanes, the segment's tokens across 256 / pairs slices of the block (a thread per channel walking the whole
-    // segment was one dependent chain of up to 150 two-byte loads: 64 us for the 1/4-level q or k at bs 16, 79 MB at 1.2 TB/s)
-    __shared__ float red[2][256];
-    const int nsl = 256 / pairs, sl = threadIdx.x / pairs, cp = threadIdx.x - sl * pairs;
-    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
-    if (sl < nsl) {
-      const half_t* p = in + ((size_t)g * N + start) * ldi + 2 * cp;
-      int t = sl;
-      for (; t + nsl < len; t += 2 * nsl) {           // two independent accumulator pairs
-        const half2v u = *(const half2v*)(p + (size_t)t * ldi), v = *(const half2v*)(p + (size_t)(t + nsl) * ldi);
-        a0 += (float)u[0]; a1 += (float)u[1]; b0 += (float)v[0]; b1 += (float)v[1];
+// ------------------------------------------------------------------------------------------------ layers_8 / layers_4 attention
+// What the reference's NystromBlock computes (layers/nystrom_attention.py:59-62,81 -> xformers NystromAttention, oracle/stubs/xformers): the module
+// receives q, k, v as [b, n, h, d], reads `seq_len = k.size(-2)` = h, finds num_landmarks (128) >= seq_len and takes its small-sequence branch, a
+// plain softmax attention over the LAST TWO axes -- every token's h head-vectors attend to each other:
+//     att[b, n, i, j] = softmax_j((q[b, n, i, :] / sqrt(d)) . k[b, n, j, :]),   out[b, n, i, :] = sum_j att[b, n, i, j] v[b, n, j, :].
+// No landmarks, no pseudo-inverse, nothing crosses tokens.  One wave per token, lane = channel inside a head (d = 64); the NH x NH scores are wave
+// reductions, everything fp32, fp16 result (the A operand of the output projection).  HBM-bound: (3 NH 64) fp32 in + (NH 64) fp16 out per token.
+template <int NH>
+__global__ __launch_bounds__(256) void head_mix_kernel(const float* q, const float* kv, half_t* out, int M, int ldq, int ldkv, int ldo, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int nw = gridDim.x * 4;
+  for (int tok = blockIdx.x * 4 + (threadIdx.x >> 6); tok < M; tok += nw) {
+    const float* qp = q + (size_t)tok * ldq + lane;
+    const float* kp = kv + (size_t)tok * ldkv + lane;
+    float qv[NH], kk[NH], vv[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      qv[i] = qp[i * 64] * scale;                     // xformers core.py scaled_query_key_softmax: q / sqrt(d) before the product
+      kk[i] = kp[i * 64];
+      vv[i] = kp[(NH + i) * 64];
+    }
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      float sc[NH], mx = -__builtin_inff();
+#pragma unroll
+      for (int j = 0; j < NH; ++j) {
+        sc[j] = ud_wave_sum(qv[i] * kk[j]);
+        mx = fmaxf(mx, sc[j]);
       }
-      if (t < len) {
-        const half2v u = *(const half2v*)(p + (size_t)t * ldi);
-        a0 += (float)u[0]; a1 += (float)u[1];
+      float den = 0.f, acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < NH; ++j) {
+        const float e = __expf(sc[j] - mx);
+        den += e;
+        acc = fmaf(e, vv[j], acc);
       }
+      out[(size_t)tok * ldo + i * 64 + lane] = (half_t)(acc / den);
     }
-    red[0][threadIdx.x] = a0 + b0; red[1][threadIdx.x] = a1 + b1;
-    __syncthreads();
-    if (sl == 0) {
-      float s0 = 0.f, s1 = 0.f;
-      for (int k = 0; k < nsl; ++k) { s0 += red[0][k * pairs + cp]; s1 += red[1][k * pairs + cp]; }      // fixed order: deterministic
-      s0 /= (float)len; s1 /= (float)len;
-      const size_t o = ((size_t)g * n + s) * ldo + 2 * cp;
-      out16[o] = (half_t)s0; out16[o + 1] = (half_t)s1;
-      if (out32) { out32[o] = s0; out32[o + 1] = s1; }
-    }
-    return;
-  }
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float acc = 0.f;
-    const half_t* p = in + ((size_t)g * N + start) * ldi + c;
-    for (int t = 0; t < len; ++t) acc += (float)p[(size_t)t * ldi];
-    acc /= (float)len;
-    out16[((size_t)g * n + s) * ldo + c] = (half_t)acc;
-    if (out32) out32[((size_t)g * n + s) * ldo + c] = acc;
-  }
-}
-
-// batched fp32 matmul of small square-ish matrices, C = diag * I + alpha * A B  (A [G, M, K], B [G, K, N], row-major, all <= 128):
-// the Newton-Schulz pseudo-inverse iterations (xformers iterative_pinv) and pinv @ kernel_3.  On the fp32 matrix pipe:
-// v_mfma_f32_32x32x2_f32 multiplies and accumulates in fp32 exactly like the fmaf chain over ascending k that the first version of
-// this kernel ran on the VALU (15 TFLOP/s, 17.9 us per launch of 64 matrices of 128^3) -- same bits, a tenth of the issue slots.
-// 64 x 64 output tile per block, one 32 x 32 quadrant per wave, K in steps of 16 through LDS ([k][m] / [k][n]: lane = row or column).
-typedef __attribute__((ext_vector_type(16))) float f32x16v;
-__global__ __launch_bounds__(256) void bmm_small_kernel(const float* A, const float* Bm, float* Cm, int M, int N, int K, float alpha, float diag,
-                                                        float* Cm2, float alpha2, float diag2) {
-  // K in rounds of 64 (one round for the 128-landmark matrices' halves): the operands of round r + 1 are fetched into registers
-  // while round r multiplies, so a 128-deep product pays two memory latencies, not eight (K steps of 16 took 17.9 us per launch
-  // with either the VALU or the matrix pipe doing the arithmetic: the loop was a chain of load -> barrier -> multiply)
-  constexpr int KS = 64;
-  __shared__ float as[KS][65], bs[KS][65];           // stride 65: the transposing A write (lane = k) is bank-conflict free
-  const int g = blockIdx.z, tid = threadIdx.x;
-  const int lane = tid & 63, wv = tid >> 6;
-  const int wm = (wv >> 1) * 32, wn = (wv & 1) * 32;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  const float* a = A + (size_t)g * M * K;
-  const float* b = Bm + (size_t)g * K * N;
-  f32x16v acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  const int kk = lane >> 5, rc = lane & 31;
-  float ra[16], rb[16];
-  auto fetch = [&](int k0) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int idx = tid + e * 256;
-      const int am = idx >> 6, ak = idx & 63;                 // A tile: 64 rows x 64 k (k fastest: coalesced 256-byte runs)
-      ra[e] = (m0 + am < M && k0 + ak < K) ? a[(size_t)(m0 + am) * K + k0 + ak] : 0.f;
-      const int bk = idx >> 6, bn = idx & 63;                 // B tile: 64 k x 64 columns
-      rb[e] = (k0 + bk < K && n0 + bn < N) ? b[(size_t)(k0 + bk) * N + n0 + bn] : 0.f;
-    }
-  };
-  fetch(0);
-  for (int k0 = 0; k0 < K; k0 += KS) {
-    __syncthreads();                                          // the previous round's fragments have been consumed
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int idx = tid + e * 256;
-      as[idx & 63][idx >> 6] = ra[e];
-      bs[idx >> 6][idx & 63] = rb[e];
-    }
-    __syncthreads();
-    if (k0 + KS < K) fetch(k0 + KS);
-#pragma unroll
-    for (int k = 0; k < KS; k += 2)                           // lanes 0-31 feed k, lanes 32-63 k + 1
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[k + kk][wm + rc], bs[k + kk][wn + rc], acc, 0, 0, 0);
-  }
-  // accumulator register r of lane l: row 8 (r / 4) + 4 (l / 32) + r % 4, column l % 32 of the wave's quadrant
-  const int col = n0 + wn + rc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = m0 + wm + 8 * (r >> 2) + 4 * kk + (r & 3);
-    if (row < M && col < N) {
-      Cm[((size_t)g * M + row) * N + col] = alpha * acc[r] + (row == col ? diag : 0.f);
-      if (Cm2) Cm2[((size_t)g * M + row) * N + col] = alpha2 * acc[r] + (row == col ? diag2 : 0.f);      // a second affine form of the same product
-    }
-  }
-}
-
-// Z0 = K^T / max_j sum_i K[i, j]  (xformers iterative_pinv, exact 1 / ||K||_1 initialisation), K fp32 [G, n, n], n <= 256.  Block = group.
-__global__ __launch_bounds__(256) void pinv_init_kernel(const float* Km, float* Z, int n) {
-  __shared__ float red[4];
-  const int g = blockIdx.x, tid = threadIdx.x;
-  const float* k = Km + (size_t)g * n * n;
-  float cs = 0.f;
-  if (tid < n)
-    for (int i = 0; i < n; ++i) cs += k[(size_t)i * n + tid];
-  float mx = tid < n ? cs : 0.f;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-  if ((tid & 63) == 0) red[tid >> 6] = mx;
-  __syncthreads();
-  const float inv = 1.0f / fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  float* z = Z + (size_t)g * n * n;
-  for (int idx = tid; idx < n * n; idx += 256) {
-    const int i = idx / n, j = idx - i * n;
-    z[idx] = k[(size_t)j * n + i] * inv;
   }
 }
 
@@ -591,23 +502,6 @@ __global__ __launch_bounds__(256) void resize_ac_split_kernel(const float* in, h
     *(half4*)(op + C) = lo;
   }
 }
-// out fp16 [G, N, ldo] = transpose of in fp32 [G, M, N] (M <= ldo; pad columns zero): pinv @ kernel_3 as the W operand of the last Nystrom GEMM
-// nh > 0: the input groups are (head, image)-major (g = head * B + image, the order of the pseudo-inverse batch), the output groups
-// (image, head)-major -- with vt != 0 the output is then the V^T operand [image][head][N = 64][ldo] of ud_attention_f16, whose columns
-// hold the 4-row blocks of every aligned group of 16 input rows in the order [0, 2, 1, 3] (bits 2 and 3 of the index swapped).
-__global__ __launch_bounds__(256) void transpose_f32_f16_kernel(const float* in, half_t* out, int G, int M, int N, int ldo, int nh, int vt) {
-  const long long total = (long long)G * N * ldo;
-  const int B = nh > 0 ? G / nh : 0;
-  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    const int col = (int)(idx % ldo);
-    const long long r = idx / ldo;
-    const int n = (int)(r % N), go = (int)(r / N);
-    const int m = vt ? ((col & ~12) | ((col & 4) << 1) | ((col & 8) >> 1)) : col;       // the swap is its own inverse
-    const int g = nh > 0 ? (go % nh) * B + go / nh : go;
-    out[idx] = m < M ? (half_t)in[((size_t)g * M + m) * N + n] : (half_t)0.f;
-  }
-}
-
 // camera tail of V1 (decoder.py:85-99 CameraHead, :347-353 run_camera; unidepthv1.py:88-92 _postprocess): raw [B*4] ->
 // K33 at network resolution, its closed-form inverse, and the post-processed matrix ((fx, fy) / ratio, (cx - pad_l, cy - pad_t) / ratio).
 __global__ void camera_v1_kernel(const float* raw, float* K33, float* Kinv33, float* Kpost33, int B, int Hn, int Wn, float ratio, int pad_l, int pad_t) {
@@ -776,23 +670,13 @@ extern "C" int ud_v1_op(const UdV1Op* desc, void* stream) {
       UD_CHECK_LAUNCH("ud_v1_op(attn_fewq) launch");
       return UD_OK;
     }
-    case UD_V1_SEGMENT_MEAN: {   // a = in fp16 [G, N, ldi], out fp16 [G, n, ldo], out2 fp32 or NULL; i = G, N, C, n, ldi, ldo
-      if (!d.a || !d.out || i[0] <= 0 || i[3] <= 0 || i[1] < i[3]) break;
-      hipLaunchKernelGGL(segment_mean_kernel, dim3(i[3], i[0]), dim3(256), 0, s, (const half_t*)d.a, (half_t*)d.out, (float*)d.out2, i[1], i[2], i[3], i[4], i[5]);
-      UD_CHECK_LAUNCH("ud_v1_op(segment_mean) launch");
-      return UD_OK;
-    }
-    case UD_V1_BMM: {            // a, b fp32, out fp32: out[g] = f[1] * I + f[0] * a[g] b[g]; optional out2[g] = f[3] * I + f[2] * a[g] b[g]; i = G, M, N, K
-      if (!d.a || !d.b || !d.out || i[0] <= 0 || i[1] <= 0 || i[2] <= 0 || i[3] <= 0) break;
-      hipLaunchKernelGGL(bmm_small_kernel, dim3((i[2] + 63) / 64, (i[1] + 63) / 64, i[0]), dim3(256), 0, s, (const float*)d.a, (const float*)d.b, (float*)d.out, i[1], i[2], i[3], d.f[0], d.f[1],
-                         (float*)d.out2, d.f[2], d.f[3]);
-      UD_CHECK_LAUNCH("ud_v1_op(bmm) launch");
-      return UD_OK;
-    }
-    case UD_V1_PINV_INIT: {      // a = K fp32 [G, n, n], out = Z0; i = G, n
-      if (!d.a || !d.out || i[0] <= 0 || i[1] <= 0 || i[1] > 256) break;
-      hipLaunchKernelGGL(pinv_init_kernel, dim3(i[0]), dim3(256), 0, s, (const float*)d.a, (float*)d.out, i[1]);
-      UD_CHECK_LAUNCH("ud_v1_op(pinv_init) launch");
+    case UD_V1_HEAD_MIX: {       // a = q fp32 [M, ldq], b = [K | V] fp32 [M, ldkv], out fp16 [M, ldo]; i = M, heads (2 / 4 / 8 of width 64), ldq, ldkv, ldo; f[0] = scale
+      if (!d.a || !d.b || !d.out || i[0] <= 0 || (i[1] != 2 && i[1] != 4 && i[1] != 8) || i[2] < i[1] * 64 || i[3] < 2 * i[1] * 64 || i[4] < i[1] * 64) break;
+      const dim3 grid((unsigned)((i[0] + 3) / 4 < 8192 ? (i[0] + 3) / 4 : 8192));
+      if (i[1] == 2) hipLaunchKernelGGL(head_mix_kernel<2>, grid, dim3(256), 0, s, (const float*)d.a, (const float*)d.b, (half_t*)d.out, i[0], i[2], i[3], i[4], d.f[0]);
+      else if (i[1] == 4) hipLaunchKernelGGL(head_mix_kernel<4>, grid, dim3(256), 0, s, (const float*)d.a, (const float*)d.b, (half_t*)d.out, i[0], i[2], i[3], i[4], d.f[0]);
+      else hipLaunchKernelGGL(head_mix_kernel<8>, grid, dim3(256), 0, s, (const float*)d.a, (const float*)d.b, (half_t*)d.out, i[0], i[2], i[3], i[4], d.f[0]);
+      UD_CHECK_LAUNCH("ud_v1_op(head_mix) launch");
       return UD_OK;
     }
     case UD_V1_ADD: {            // out = a + b, fp32, i[0] + (i[1] << 31) elements (% 4 == 0)
@@ -823,15 +707,6 @@ extern "C" int ud_v1_op(const UdV1Op* desc, void* stream) {
       UD_CHECK_LAUNCH("ud_v1_op(copy_rows) launch");
       return UD_OK;
     }
-    case UD_V1_TRANSPOSE16: {    // a = fp32 [G, M, N] -> out fp16 [G, N, ldo] (transposed, zero padded); i = G, M, N, ldo, nh, vt
-      if (!d.a || !d.out || i[0] <= 0 || i[3] < i[1] || i[4] < 0 || (i[4] > 0 && i[0] % i[4]) || (i[5] && (i[3] & 15))) break;
-      hipLaunchKernelGGL(transpose_f32_f16_kernel, dim3(grid1((long long)i[0] * i[2] * i[3])), dim3(256), 0, s, (const float*)d.a, (half_t*)d.out, i[0], i[1], i[2], i[3],
-                         i[4], i[5]);
-      UD_CHECK_LAUNCH("ud_v1_op(transpose16) launch");
-      return UD_OK;
-    }
-    case UD_V1_ATTN_MERGE:       // a = part (ud_attention_f16 split-key mode), b = bias fp32 [H * 64] or NULL, out fp32 [H][B][Nq][64]; i = B, NC, H, Nq
-      return ud_attention_merge_f32((const float*)d.a, (const float*)d.b, (float*)d.out, i[0], i[1], i[2], i[3], stream);
     case UD_V1_CAMERA: {         // a = raw fp32 [B*4]; out = K33, out2 = Kinv33, c = Kpost33 (written); i = B, Hn, Wn, pad_l, pad_t; f[0] = ratio
       if (!d.a || !d.out || !d.out2 || !d.c || i[0] <= 0 || !(d.f[0] > 0.f)) break;
       hipLaunchKernelGGL(camera_v1_kernel, dim3((i[0] + 63) / 64), dim3(64), 0, s, (const float*)d.a, (float*)d.out, (float*)d.out2, (float*)d.c, i[0], i[1], i[2], d.f[0], i[3], i[4]);

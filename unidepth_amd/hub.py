@@ -4,11 +4,9 @@ engine class for the version from the shipped architecture config and, if `pretr
 The V2 ViT backbones and both V1 variants (`v1` / `cnvnxtl`: ConvNeXt-L; `v1` / `vitl14`: DINOv2 ViT-L/14; unidepthv1.py) run end to end on the
 engine; `v2old` raises NotImplementedError.
 
-UniDepthV1 caveat (parity UNPINNED for its two Nystrom stages): the reference computes `layers_8` / `layers_4` with
-xformers' NystromAttention, a dependency that is neither vendored nor pinned, and hands it 4-D [b, n, h, d] tensors
-(layers/nystrom_attention.py:59-62,81).  The engine implements the published algorithm per head over tokens; whether the deployed
-xformers build does the same for that layout has not been checked against a run of the real package.  Loading RELEASED V1 weights
-therefore warns (UniDepthV1.nystrom_caveat_acknowledged = True, or UNIDEPTH_V1_ACK_NYSTROM=1, silences it)."""
+UniDepthV1's `layers_8` / `layers_4` (NystromBlock, layers/nystrom_attention.py) are computed as the reference's call into xformers'
+NystromAttention computes them for its 4-D [b, n, h, d] tensors -- the module's small-sequence branch, a per-token softmax attention among the h
+head-vectors (oracle/stubs/xformers restates the module; unidepth_amd/unidepthv1.py nystrom_block) -- not as the paper's landmark algorithm."""
 from __future__ import annotations
 
 import json
@@ -20,7 +18,7 @@ BACKBONES = {"v1": ["vitl14", "cnvnxtl"], "v2": ["vitl14", "vitb14", "vits14"], 
 _CFG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs")      # architecture configs of the V2 ViT-S/B/L checkpoints
 
 
-from .unidepthv1 import UniDepthV1  # noqa: E402,F401  (ConvNeXt-L encoder + V1 decoder on the engine; Nystrom stages: see the caveat above)
+from .unidepthv1 import UniDepthV1  # noqa: E402,F401  (ConvNeXt-L encoder + V1 decoder on the engine)
 
 
 def UniDepth(version: str = "v2", backbone: str = "vitl14", pretrained: bool = True):

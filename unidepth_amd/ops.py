@@ -58,10 +58,6 @@ def gemm(**kw):
     check(lib.ud_gemm_f16(C.byref(mk(UdGemm, **kw)), cur_stream()), "ud_gemm_f16")
 
 
-def attention_merge(part, bias, out, B, NC, H, Nq):
-    check(lib.ud_attention_merge_f32(ptr(part), ptr(bias), ptr(out), B, NC, H, Nq, cur_stream()), "ud_attention_merge_f32")
-
-
 def layernorm(**kw):
     check(lib.ud_layernorm_f32_f16(C.byref(mk(UdLayerNorm, **kw)), cur_stream()), "ud_layernorm_f32_f16")
 

@@ -5,9 +5,10 @@ skip_camera), attribute `image_shape`; device arithmetic in libunidepth_hip.so.
 One launch program per (batch, input shape, camera mode): pre-processing (antialiased resize + pad), ConvNeXt-L encoder
 (backbones/convnext.py:301-471: depth-wise 7x7 conv, LayerNorm, MFMA GEMMs for stem / down-sampling / MLP, max_stack, class-token
 means), V1 decoder (unidepthv1/decoder.py: adapters, fp32 camera head, spherical-harmonics ray embeddings, single-head width-512
-attention as GEMM + softmax + GEMM, 8-head flash attention, ConvUpsample stacks, Nystrom attention blocks), multi-scale merge and
-back-projection.  Parity: against oracle/restate_v1.py, which is pinned to the reference's own code except for the Nystrom attention
-(arithmetic in the un-vendored xformers package: restated from the published algorithm, PARITY UNPINNED -- see the oracle header)."""
+attention as GEMM + softmax + GEMM, 8-head flash attention, ConvUpsample stacks, the NystromBlocks as the reference executes them -- a
+per-token softmax attention among the h head-vectors, see nystrom_block below), multi-scale merge and back-projection.  Parity: against
+oracle/restate_v1.py, pinned to the live reference running on the statement-by-statement restatement of xformers' NystromAttention
+(oracle/stubs/xformers; the package itself is un-vendored and absent -- see the oracle header)."""
 from __future__ import annotations
 
 import json
@@ -41,10 +42,6 @@ def _rup(x, m):
 # noise, a quarter of the encoder's MFMA work saved; the same blocks' fc2 (A = GELU output, every channel's mean positive: a rounding
 # error of W shifts an output channel by the same amount at every pixel) 7.8 / 8.5 / 8.1e-4; the depth decoder's LayerNorm-fed GEMMs
 # 1.1-1.2e-3: not those.  Default: split everything except the ConvNeXt fc1; UNIDEPTH_V1_WSPLIT=all splits those too.
-# Nystrom stages: kernel_1 / kernel_3 are never materialised -- softmax(q_l k^T) v runs as split-key flash attention (ud_attention_f16 with
-# k_chunk + ud_attention_merge_f32) and softmax(q k_l^T) (pinv(kernel_2) kernel_3 v) as plain flash attention over the 128 landmarks.
-# UNIDEPTH_V1_NYS_FLASH=0: the first form (GEMM -> row softmax -> GEMM through fp32 score matrices in HBM), kept for A/B runs.
-NYS_FLASH = os.environ.get("UNIDEPTH_V1_NYS_FLASH", "1") != "0"
 # UNIDEPTH_V1_WSPLIT: "all" (default since round 4) = every GEMM weight as two fp16 terms; "1" = the round-3 placement (the ConvNeXt blocks'
 # fc1 weights single fp16: -6.9 % time, but over 8 checkpoint seeds a global depth shift of up to 8.6e-4 and the one case of the sweep
 # left above 1e-3; measured 16 of 16 within the bar, worst 7.9e-4, with them split: DESIGN 10.3b); "0" = single fp16 weights everywhere.
@@ -57,14 +54,6 @@ WSPLIT_CONVNEXT_FC1 = _WSPLIT_ENV == "all"
 # (tools/r4_v1_seed_study.py: 1.30e-3 -> 8.0e-4 emulated with them exact) -- they sit directly in front of the depth output, where nothing
 # averages the noise.  UNIDEPTH_V1_ASPLIT=0: two terms as in round 3 (A/B).
 ASPLIT = WSPLIT and os.environ.get("UNIDEPTH_V1_ASPLIT", "1") != "0"
-
-
-def nystrom_key_chunks(n_tiles: int, pairs: int, target_workgroups: int = 1024):
-    """Split-key plan of the Nystrom kernel_3 product (ud_attention_f16, UdAttention.k_chunk): the n_tiles 64-key tiles of every
-    (image, head) pair are cut into chunks of `tiles_per_chunk` whole tiles so that pairs x chunks is about target_workgroups (4 per CU)
-    -> (tiles_per_chunk, chunks); every tile belongs to exactly one chunk and no chunk is empty."""
-    tpc = max(1, -(-n_tiles // max(1, target_workgroups // max(1, pairs))))
-    return tpc, -(-n_tiles // tpc)
 
 
 def _padk16(w: torch.Tensor, split: Optional[bool] = None) -> torch.Tensor:
@@ -305,11 +294,7 @@ def pack_v1_decoder(config: dict, sd: dict, device) -> dict:
             src, dst = f"{dl}{nm}.{i}.", f"{nm}.{i}."
             lin_ln16(dst + "q", src + "q", None, src + "norm_attnx")
             wkv, bkv = _fold_ln(f[src + "kv.weight"], f[src + "kv.bias"], f[src + "norm_attnctx.weight"], f[src + "norm_attnctx.bias"])
-            if NYS_FLASH:                      # one [K | V] GEMM with the V^T scatter epilogue, like layers_16
-                p16(dst + "kv.w", wkv); p32(dst + "kv.b", bkv)
-            else:
-                p16(dst + "k.w", wkv[:d]); p32(dst + "k.b", bkv[:d])
-                p16(dst + "v.w", wkv[d:]); p32(dst + "v.b", bkv[d:])
+            p16(dst + "kv.w", wkv); p32(dst + "kv.b", bkv)       # one [K | V] GEMM
             p16(dst + "out.w", f[src + "out.weight"] * f[src + "ls1.gamma"][:, None]); p32(dst + "out.b", f[src + "out.bias"] * f[src + "ls1.gamma"])
             mlp16(dst, src + "mlp.", f[src + "ls2.gamma"])
     for nm, d in (("up8", C), ("up4", C // 2), ("up2", C // 4)):
@@ -491,8 +476,6 @@ class UniDepthV1(EngineModule):
         else:
             raise NotImplementedError(f"UniDepthV1 pixel_encoder {name!r}: the ConvNeXt-L (config_v1_cnvnxtl) and DINOv2 ViT-L/14 (config_v1_vitl14) "
                                       "backbones are implemented on this engine")
-        # PARITY UNPINNED for the Nystrom stages (see hub.py / oracle/restate_v1.py): warn once per model when it first runs infer()
-        self.nystrom_caveat_acknowledged = os.environ.get("UNIDEPTH_V1_ACK_NYSTROM", "0") == "1"
         self.image_shape = list(config["data"]["image_shape"])                         # unidepthv1.py:444
         self._sd = None
         self._w = None
@@ -659,14 +642,6 @@ class UniDepthV1(EngineModule):
         [3,3] / [B,3,3] of the INPUT image, skip_camera (use the given camera instead of running the camera head)
         -> {"intrinsics" [B,3,3], "points" [B,3,H,W], "depth" [B,1,H,W]} at the input resolution."""
         self._ensure_packed()
-        if not self.nystrom_caveat_acknowledged:
-            import warnings
-            warnings.warn("UniDepthV1 on the MI355X engine: the two Nystrom attention stages (layers_8 / layers_4) implement the published algorithm "
-                          "per head over tokens; the reference delegates them to the un-vendored, un-pinned xformers NystromAttention with 4-D "
-                          "[b, n, h, d] inputs and that call has not been reproduced offline -- parity with RELEASED V1 weights is UNPINNED "
-                          "(everything else is pinned to the reference).  Set model.nystrom_caveat_acknowledged = True or "
-                          "UNIDEPTH_V1_ACK_NYSTROM=1 to silence this.", RuntimeWarning, stacklevel=2)
-            self.nystrom_caveat_acknowledged = True
         if rgbs.ndim == 3:
             rgbs = rgbs.unsqueeze(0)
         if intrinsics is not None and intrinsics.ndim == 2:
@@ -1038,105 +1013,19 @@ class _FullPlan:
                    flops=2.0 * B * hh * ww * 4 * 9 * Cl)
             return o
 
-        # ---------------- Nystrom attention block (layers/nystrom_attention.py:22-84; xformers NystromAttention, 128 landmarks -- PARITY UNPINNED)
+        # ---------------- NystromBlock (layers/nystrom_attention.py:22-84) AS THE REFERENCE EXECUTES IT: q, k, v reach xformers' NystromAttention as
+        # [b, n, h, d]; the module reads `seq_len = k.size(-2)` = h (4 / 2), finds num_landmarks (128) >= seq_len and takes its plain-softmax branch
+        # over the last two axes -- every token's h head-vectors attend to each other, nothing crosses tokens (oracle/stubs/xformers restates the
+        # module statement by statement; rounds 2-4 had built the PAPER's landmark / pseudo-inverse algorithm here, which this layout never reaches).
         def nystrom_block(pre, x, e_tok, n, Cl, nh):
-            (nystrom_block_flash if NYS_FLASH else nystrom_block_scores)(pre, x, e_tok, n, Cl, nh)
-
-        def nystrom_pinv(K2, G, Lm):
-            """Z ~ pinv(kernel_2) for all (head, image) pairs at once: Z0 = K^T / (||K||_1 ||K||_inf), six Newton-Schulz steps
-            Z <- 1/4 Z (13 I - KZ (15 I - KZ (7 I - KZ)))  (xformers iterative_pinv)."""
-            Z = z(G * Lm, Lm, dtype=f32); Zn = z(G * Lm, Lm, dtype=f32); KZ = z(G * Lm, Lm, dtype=f32); T1 = z(G * Lm, Lm, dtype=f32); T2 = z(G * Lm, Lm, dtype=f32)
-            P.v1(L.UD_V1_PINV_INIT, a=K2, out=Z, i=(G, Lm), tag="pinv")
-            za, zb = Z, Zn
-            for _ in range(6):
-                P.v1(L.UD_V1_BMM, a=K2, b=za, out=KZ, out2=T1, i=(G, Lm, Lm, Lm), f=(1.0, 0.0, -1.0, 7.0), tag="pinv")   # KZ and 7 I - KZ
-                P.v1(L.UD_V1_BMM, a=KZ, b=T1, out=T2, i=(G, Lm, Lm, Lm), f=(-1.0, 15.0), tag="pinv")      # 15 I - KZ (7 I - KZ)
-                P.v1(L.UD_V1_BMM, a=KZ, b=T2, out=T1, i=(G, Lm, Lm, Lm), f=(-1.0, 13.0), tag="pinv")      # 13 I - KZ (...)
-                P.v1(L.UD_V1_BMM, a=za, b=T1, out=zb, i=(G, Lm, Lm, Lm), f=(0.25, 0.0), tag="pinv")       # Z <- 1/4 Z (...)
-                za, zb = zb, za
-            return za
-
-        def nystrom_block_flash(pre, x, e_tok, n, Cl, nh):
-            """out = kernel_1 pinv(kernel_2) (kernel_3 v) with kernel_1 = softmax(q k_l^T), kernel_2 = softmax(q_l k_l^T), kernel_3 = softmax(q_l k^T),
-            q_l / k_l = 128 segment means (layers/nystrom_attention.py:22-84 -> xformers NystromAttention).  Only kernel_2 (128 x 128) exists
-            in memory: kernel_3 v is a flash attention of the 128 landmark queries over all n keys, split along the keys (one pair alone
-            would walk up to 300 key tiles) and merged; kernel_1 (...) is a flash attention of the n queries over the 128 landmark keys
-            whose "values" are T = pinv(kernel_2) kernel_3 v."""
             M = B * n
-            npad = _rup(n, 64)
-            Lm = 128
-            xn = z(M, Cl); q = z(M, Cl); k = z(M, Cl); vt = z(B, nh, 64, npad); ao = z(M, Cl)
+            xn = z(M, Cl); q = z(M, Cl, dtype=f32); kv = z(M, 2 * Cl, dtype=f32); ao = z(M, Cl)
             ln(x, xn, M, Cl)
-            gemm(xn, pre + "q", q, M, Cl, Cl, epi=UD_EPI_F16, add=e_tok, ldadd=Cl)
-            P.gemm(A=xn, W=w[pre + "kv.w"], bias=w[pre + "kv.b"], out=k, out2=vt, M=M, N=2 * Cl, lda=Cl, ldc=Cl, epi=UD_EPI_QKV, vsplit=Cl, **_wk(w[pre + "kv.w"], Cl),
-                   tok_per_img=n, kv_ld=npad, heads_v=nh, tag="v1.nys.kv")
-            ql = z(B * Lm, Cl); kl = z(B * Lm, Cl)
-            P.v1(L.UD_V1_SEGMENT_MEAN, a=q, out=ql, i=(B, n, Cl, Lm, Cl, Cl), tag="landmarks")
-            P.v1(L.UD_V1_SEGMENT_MEAN, a=k, out=kl, i=(B, n, Cl, Lm, Cl, Cl), tag="landmarks")
-            sc = 64 ** -0.5
-            G = nh * B                                                         # (head, image) groups of the small fp32 matrices
-            S2 = z(B * Lm, Lm, dtype=f32); K2 = z(G * Lm, Lm, dtype=f32)
-            for hd in range(nh):
-                o2 = hd * 64 * 2                                                 # byte offset of the head's 64 columns in an fp16 row
-                P.gemm(A=ql.data_ptr() + o2, W=kl.data_ptr() + o2, out=S2, M=Lm, N=Lm, K=64, lda=Cl, ldw=Cl, ldc=Lm, epi=UD_EPI_F32, groups=B, gA=Lm * Cl,
-                       gW=Lm * Cl, gOut=Lm * Lm, tag="v1.nys.k2")
-                P.v1(L.UD_V1_SOFTMAX, a=S2, out=K2[hd * B * Lm:(hd + 1) * B * Lm], i=(B * Lm, Lm, Lm, Lm, 1, 0), f=(sc,), tag="softmax")
-            # kernel_3 v: ~1024 workgroups (chunks of whole 64-key tiles), then the merge into the (head, image)-major fp32 batch
-            tpc, nc = nystrom_key_chunks(npad // 64, G)
-            part = z(B * nc * nh * Lm, L.UD_ATTN_PART_LD, dtype=f32); k3 = z(G * Lm, 64, dtype=f32)
-            P.attention(Q=ql, K=k, Vt=vt, O=None, B=B, H=nh, Nq=Lm, Nk=n, ldq=Cl, ldk=Cl, ldo=Cl, kv_ld=npad, q_rows_per_img=Lm, k_rows_per_img=n, scale=sc,
-                        k_chunk=tpc * 64, part=part, tag="v1.nys.k3v")
-            P.v1(L.UD_V1_ATTN_MERGE, a=part, out=k3, i=(B, nc, nh, Lm), tag="nys.merge")
-            za = nystrom_pinv(K2, G, Lm)
-            T = z(G * Lm, 64, dtype=f32); Tt = z(B, nh, 64, Lm)
-            P.v1(L.UD_V1_BMM, a=za, b=k3, out=T, i=(G, Lm, 64, Lm), f=(1.0, 0.0), tag="nys.pinv_k3")
-            P.v1(L.UD_V1_TRANSPOSE16, a=T, out=Tt, i=(G, Lm, 64, Lm, nh, 1), tag="nys.T")
-            P.attention(Q=q, K=kl, Vt=Tt, O=ao, B=B, H=nh, Nq=n, Nk=Lm, ldq=Cl, ldk=Cl, ldo=Cl, kv_ld=Lm, q_rows_per_img=n, k_rows_per_img=Lm, scale=sc,
-                        tag="v1.nys.out")
+            gemm(xn, pre + "q", q, M, Cl, Cl, epi=UD_EPI_F32, add=e_tok, ldadd=Cl)
+            gemm(xn, pre + "kv", kv, M, 2 * Cl, Cl, epi=UD_EPI_F32)
+            P.v1(L.UD_V1_HEAD_MIX, a=q, b=kv, out=ao, i=(M, nh, Cl, 2 * Cl, Cl), f=(64 ** -0.5,), tag="head_mix")
             gemm(ao, pre + "out", x, M, Cl, Cl, epi=UD_EPI_F32, accumulate=1)
             mlp(x, pre, M, Cl, 4)
-            self._keep = getattr(self, "_keep", []) + [ql, kl]                  # raw-pointer operands of the per-head launches
-
-        def nystrom_block_scores(pre, x, e_tok, n, Cl, nh):
-            M = B * n
-            npad = _rup(n, 64)
-            Lm = 128
-            xn = z(M, Cl); q = z(M, Cl); k = z(M, Cl); vt = z(B, Cl, npad); ao = z(M, Cl)
-            ln(x, xn, M, Cl)
-            gemm(xn, pre + "q", q, M, Cl, Cl, epi=UD_EPI_F16, add=e_tok, ldadd=Cl)
-            gemm(xn, pre + "k", k, M, Cl, Cl, epi=UD_EPI_F16)
-            P.gemm(A=w[pre + "v.w"], W=xn, out=vt, M=Cl, N=n, ldw=Cl, ldc=npad, epi=UD_EPI_F16, groups=B, gA=0, gW=n * Cl, gOut=Cl * npad, tag="v1.nys.vT",
-                   **_ak(w[pre + "v.w"], Cl))
-            ql = z(B * Lm, Cl); kl = z(B * Lm, Cl)
-            P.v1(L.UD_V1_SEGMENT_MEAN, a=q, out=ql, i=(B, n, Cl, Lm, Cl, Cl), tag="landmarks")
-            P.v1(L.UD_V1_SEGMENT_MEAN, a=k, out=kl, i=(B, n, Cl, Lm, Cl, Cl), tag="landmarks")
-            sc = 64 ** -0.5
-            G = nh * B                                                         # (head, image) groups of the small fp32 matrices
-            S1 = z(M, Lm, dtype=f32); P1 = z(nh, M, Lm); S2 = z(B * Lm, Lm, dtype=f32); K2 = z(G * Lm, Lm, dtype=f32)
-            S3 = z(B * Lm, n, dtype=f32); P3 = z(B * Lm, npad); k3 = z(G * Lm, 64, dtype=f32)
-            T = z(G * Lm, 64, dtype=f32); Tt = z(G * 64, Lm)
-            for hd in range(nh):
-                o2 = hd * 64 * 2                                                 # byte offset of the head's 64 columns in an fp16 row
-                P.gemm(A=q.data_ptr() + o2, W=kl.data_ptr() + o2, out=S1, M=n, N=Lm, K=64, lda=Cl, ldw=Cl, ldc=Lm, epi=UD_EPI_F32, groups=B, gA=n * Cl,
-                       gW=Lm * Cl, gOut=n * Lm, tag="v1.nys.k1")
-                P.v1(L.UD_V1_SOFTMAX, a=S1, out=P1[hd], i=(M, Lm, Lm, Lm, 0, 0), f=(sc,), tag="softmax")
-                P.gemm(A=ql.data_ptr() + o2, W=kl.data_ptr() + o2, out=S2, M=Lm, N=Lm, K=64, lda=Cl, ldw=Cl, ldc=Lm, epi=UD_EPI_F32, groups=B, gA=Lm * Cl,
-                       gW=Lm * Cl, gOut=Lm * Lm, tag="v1.nys.k2")
-                P.v1(L.UD_V1_SOFTMAX, a=S2, out=K2[hd * B * Lm:(hd + 1) * B * Lm], i=(B * Lm, Lm, Lm, Lm, 1, 0), f=(sc,), tag="softmax")
-                P.gemm(A=ql.data_ptr() + o2, W=k.data_ptr() + o2, out=S3, M=Lm, N=n, K=64, lda=Cl, ldw=Cl, ldc=n, epi=UD_EPI_F32, groups=B, gA=Lm * Cl,
-                       gW=n * Cl, gOut=Lm * n, tag="v1.nys.k3")
-                P.v1(L.UD_V1_SOFTMAX, a=S3, out=P3, i=(B * Lm, n, n, npad, 0, 0), f=(sc,), tag="softmax")
-                P.gemm(A=P3, W=vt.data_ptr() + hd * 64 * npad * 2, bias=w[pre + "v.b"].data_ptr() + hd * 64 * 4, out=k3[hd * B * Lm:(hd + 1) * B * Lm], M=Lm, N=64,
-                       K=npad, lda=npad, ldw=npad, ldc=64, epi=UD_EPI_F32, groups=B, gA=Lm * npad, gW=Cl * npad, gBias=0, gOut=Lm * 64, tag="v1.nys.k3v")
-            za = nystrom_pinv(K2, G, Lm)
-            P.v1(L.UD_V1_BMM, a=za, b=k3, out=T, i=(G, Lm, 64, Lm), f=(1.0, 0.0), tag="nys.pinv_k3")
-            P.v1(L.UD_V1_TRANSPOSE16, a=T, out=Tt, i=(G, Lm, 64, Lm), tag="nys.T")
-            for hd in range(nh):
-                P.gemm(A=P1[hd], W=Tt[hd * B * 64:(hd + 1) * B * 64], out=ao.data_ptr() + hd * 64 * 2, M=n, N=64, K=Lm, lda=Lm, ldw=Lm, ldc=Cl, epi=UD_EPI_F16,
-                       groups=B, gA=n * Lm, gW=64 * Lm, gOut=n * Cl, tag="v1.nys.out")
-            gemm(ao, pre + "out", x, M, Cl, Cl, epi=UD_EPI_F32, accumulate=1)
-            mlp(x, pre, M, Cl, 4)
-            self._keep = getattr(self, "_keep", []) + [q, k, kl, ql, vt, ao, xn]        # raw-pointer operands of the per-head launches
 
         lat8, lat8_16 = conv_upsample("up8", lat, e16, h, wd, C)
         tap("up8", lambda: lat8.view(B, 4 * hw, C // 2).clone())
