@@ -61,4 +61,22 @@ timeout 400 python tools/bench_v1.py --by-tag > $O/bench_v1_tags.txt 2>&1
 cat $O/v1_tests.txt $O/attn_tests.txt; tail -60 $O/sweep_v1.txt; tail -12 $O/bench_v1.txt; tail -45 $O/bench_v1_tags.txt
 }
 
+# round 5, GPU call 5: one infer() as two (four) sub-batches in flight (model.latency_split): bit-identity tests, the one-call latency with and
+# without it on the headline workload
+call5() {
+O=gpurun_out/r5c5 && mkdir -p $O
+timeout 600 python -m pytest tests/test_infer_gpu.py -q -m gpu -k "latency_split or pipeline or headline" 2>&1 | grep -v "^$\|amdgpu.ids" | tail -8 > $O/tests.txt
+lat() { python -c "
+import json,sys
+try:
+    d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', 'value', d['value'], 'p50', d['p50_latency_ms'], 'p90', d['p90_latency_ms'], 'unsplit p50', d.get('p50_latency_ms_unsplit'), 'split', d.get('latency_split'))
+except Exception as e: print('$1 FAILED', e)"; }
+for r in 1 2; do
+  for sp in 1 2 4; do
+    timeout 300 python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-extra-configs --no-kernel-timing --latency-split $sp 2>$O/err.txt | lat "split=$sp" >> $O/latency_ab.txt
+  done
+done
+cat $O/tests.txt $O/latency_ab.txt; tail -5 $O/err.txt
+}
+
 "$@"
