@@ -73,7 +73,6 @@ def parse_args(argv=None):
     ap.add_argument("--gather-algo", default="collective", choices=["collective", "direct"],
                     help="exchange step: RCCL all_gather_into_tensor, or the all-pairs send/recv group (unidepth_amd.dist.all_gather_direct)")
     ap.add_argument("--dump-ops", default="", help="write per-launch timings (tsv) to this file")
-    ap.add_argument("--latency-split", type=int, default=-1, help="model.latency_split for the one-call latency (-1 = the model's default; 1 = off)")
     ap.add_argument("--inflight", type=int, default=2, help="infer() calls in flight per GPU during the timed steps (1 = one call at a time)")
     return ap.parse_args(argv)
 
@@ -199,26 +198,12 @@ def main():
         step()
     elapsed = timed(args.steps)                      # THE timed region: exactly K steps, barrier + synchronize on both sides, max over ranks
     # latency of ONE call with nothing else in flight (outside the timed region)
-    if args.latency_split >= 1:
-        model.latency_split = args.latency_split
-
-    def one_call_latencies():
-        for _ in range(3):                         # warm-up: the split form has its own plans
-            step_single()
+    lat = []
+    for _ in range(max(30, min(args.steps, 50))):
+        ts = time.perf_counter()
+        step_single()
         torch.cuda.synchronize()
-        ts_ = []
-        for _ in range(max(30, min(args.steps, 50))):
-            ts = time.perf_counter()
-            step_single()
-            torch.cuda.synchronize()
-            ts_.append((time.perf_counter() - ts) * 1e3)
-        return ts_
-    lat = one_call_latencies()
-    p50_unsplit = None
-    if model.latency_split > 1:                    # the same call as one launch program, for the record
-        keep, model.latency_split = model.latency_split, 1
-        p50_unsplit = statistics.median(one_call_latencies())
-        model.latency_split = keep
+        lat.append((time.perf_counter() - ts) * 1e3)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
     p50 = statistics.median(lat)
@@ -229,7 +214,6 @@ def main():
         "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "p50_latency_ms": round(p50, 4), "p90_latency_ms": round(p90, 4), "latency_samples": len(lat),
         "value_one_call": round(world * B / (p50 * 1e-3), 3),
-        "latency_split": model.latency_split, "p50_latency_ms_unsplit": None if p50_unsplit is None else round(p50_unsplit, 4),
         "inflight": max(1, args.inflight),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
         "data": "synthetic uint8 RGB (seeded) resident in HBM; seeded random-init weights of the named architecture",

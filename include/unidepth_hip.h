@@ -13,6 +13,7 @@
  */
 #ifndef UNIDEPTH_HIP_H
 #define UNIDEPTH_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -355,6 +356,18 @@ typedef struct UdV1Op {
   float f[4];
 } UdV1Op;
 int ud_v1_op(const UdV1Op* desc, void* stream);
+
+/* ---- the exchange step of batch data parallelism: all-gather of the packed output rows over RCCL / xGMI ----
+ * The reference has no distributed inference path (unidepth/utils/distributed.py:153-176 sync_tensor_across_gpus is its pad -> gather -> trim
+ * helper for variable-length gathers; unidepth_amd/dist.py keeps that pattern on the host).  One process per GPU, one communicator per
+ * process; librccl is opened on first use.  Rank 0 calls ud_rccl_unique_id and hands the 128 bytes to the other ranks by any host channel;
+ * every rank then calls ud_rccl_init with the calling thread's HIP device set.
+ *   ud_rccl_allgather_outputs: recv [world][bytes_per_rank] <- every rank's `send` [bytes_per_rank] (device buffers, equal size on all ranks),
+ *   enqueued on `stream`; direct != 0: the all-pairs send / receive group (every peer over its own xGMI link) instead of ncclAllGather. */
+int ud_rccl_unique_id(void* id128);
+int ud_rccl_init(const void* id128, int world, int rank);
+int ud_rccl_allgather_outputs(const void* send, void* recv, size_t bytes_per_rank, int direct, void* stream);
+int ud_rccl_finalize(void);
 
 /* ---- the reference's two native extensions (evaluation / loss side), forward only ----
  * K nearest neighbours of every p1 point among the p2 points of the same cloud: replaces KNN.knn_points_idx

@@ -178,39 +178,6 @@ def test_infer_mixed_shapes_single_gpu(engine_cls):
         assert ((o["intrinsics"] - ref["intrinsics"][0]).abs() / ref["intrinsics"][0].abs().clamp_min(1.0)).max().item() <= 1e-5
 
 
-@pytest.mark.parametrize("arch,B,H,W,cam", [("vitl14", 8, 518, 518, None), ("vits14", 4, 252, 336, "one"), ("vits14", 6, 240, 320, "per_image"), ("vits14", 3, 252, 336, None)])
-def test_latency_split_bit_identical(engine_cls, arch, B, H, W, cam):
-    """model.latency_split / infer(split=): ONE call as sub-batches in flight on their own HIP streams returns, bit for bit, what the whole-batch
-    launch program returns (every image's arithmetic is independent of its batch position and of the batch size), for predicted cameras, one
-    shared GT camera and one GT camera per image; an odd batch falls back to the unsplit program."""
-    cfg = synth.load_config(arch)
-    sd = synth.make_synthetic_checkpoint(cfg, 77)
-    model = engine_cls(cfg).load_state_dict(sd).to("cuda").eval()
-    g = torch.Generator().manual_seed(B + H)
-    rgb = torch.randint(0, 256, (B, 3, H, W), dtype=torch.uint8, generator=g).cuda()
-    K = None
-    if cam is not None:
-        n = 1 if cam == "one" else B
-        K = torch.eye(3).repeat(n, 1, 1)
-        K[:, 0, 0] = torch.linspace(0.9, 1.3, n) * W
-        K[:, 1, 1] = torch.linspace(1.0, 1.2, n) * W
-        K[:, 0, 2] = W / 2 + 3
-        K[:, 1, 2] = H / 2 - 2
-        K = K[0] if cam == "one" else K
-    ref = model.infer(rgb, K, split=1)
-    torch.cuda.synchronize()
-    got = model.infer(rgb, K, split=2)
-    torch.cuda.synchronize()
-    for k in ref:
-        assert got[k].shape == ref[k].shape and torch.equal(got[k], ref[k]), k
-    model.latency_split = 2                                             # the attribute form, three calls back to back on the same buffers
-    for _ in range(3):
-        got = model.infer(rgb, K)
-    torch.cuda.synchronize()
-    for k in ref:
-        assert torch.equal(got[k], ref[k]), k
-
-
 def test_pipeline_two_calls_in_flight(engine_cls):
     """unidepth_amd.pipeline: calls on separate HIP streams with separate buffer slots reproduce sequential infer() bit for bit
     (shared read-only weights, no shared activation state)."""

@@ -117,6 +117,10 @@ def _load():
         "ud_gemm_f16": [P(UdGemm), vp],
         "ud_gemm_pick": [P(UdGemm)],
         "ud_layernorm_f32_f16": [P(UdLayerNorm), vp],
+        "ud_rccl_unique_id": [vp],
+        "ud_rccl_init": [vp, i32, i32],
+        "ud_rccl_allgather_outputs": [vp, vp, C.c_size_t, i32, vp],
+        "ud_rccl_finalize": [],
         "ud_attention_f16": [P(UdAttention), vp],
         "ud_row_stats_finalize": [vp, vp, i32, i32, i32, f32, vp],
         "ud_program_add_row_stats_finalize": [vp, vp, vp, i32, i32, i32, f32],

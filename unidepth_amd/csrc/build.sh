@@ -21,6 +21,7 @@ done
 ( hipcc $FLAGS -ffp-contract=off "$@" -c evalops.hip -o $BD/evalops.o ) & pids+=($!)
 ( hipcc $FLAGS -x hip -c api.cpp -o $BD/api.o ) & pids+=($!)
 ( hipcc $FLAGS -x hip -c program.cpp -o $BD/program.o ) & pids+=($!)
+( hipcc $FLAGS -x hip -c rccl.cpp -o $BD/rccl.o ) & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC $BD/*.o -o $OUT
+hipcc --offload-arch=gfx950 -shared -fPIC $BD/*.o -ldl -o $OUT
 echo "built $(realpath $OUT)"

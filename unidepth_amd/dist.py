@@ -76,23 +76,40 @@ def _camera_count(camera) -> int:
     return int(params.shape[0]) if params is not None and getattr(params, "ndim", 1) > 1 else 1
 
 
-def infer_data_parallel(model, rgb: torch.Tensor, camera=None, keys: Optional[Iterable[str]] = ("depth", "confidence", "intrinsics"),
-                        group=None, gather_algo: Optional[str] = None, **kw) -> Dict[str, torch.Tensor]:
-    """Every rank passes the SAME global batch `rgb` [B,3,H,W] (any device); rank r runs infer() on its contiguous shard and
-    all ranks return the gathered global outputs for `keys` (None = all seven).  A single camera broadcasts; a per-image
-    camera batch is sharded like the images."""
+def infer_data_parallel(model, rgb: Optional[torch.Tensor] = None, camera=None, keys: Optional[Iterable[str]] = ("depth", "confidence", "intrinsics"),
+                        group=None, gather_algo: Optional[str] = None, *, rgb_local: Optional[torch.Tensor] = None, n_images: Optional[int] = None,
+                        **kw) -> Dict[str, torch.Tensor]:
+    """Rank r runs infer() on its contiguous shard of a global batch of B images (shard_bounds) and all ranks return the gathered global
+    outputs for `keys` (None = all seven).  Two ways to hand over the images:
+      * `rgb` [B,3,H,W]: every rank passes the SAME global batch (any device) and slices its shard out of it;
+      * `rgb_local` [b_r,3,H,W] + `n_images` = B: every rank passes ONLY its own shard (b_r = the size shard_bounds gives rank r; a rank
+        without images passes [0,3,H,W]) -- no redundant host-to-device copy of the other ranks' images (8x at 8 GPUs).
+    A single camera broadcasts; a per-image camera batch [B,3,3] is global in both forms (it is tiny) and sharded like the images."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    B = rgb.shape[0]
+    if (rgb is None) == (rgb_local is None):
+        raise ValueError("infer_data_parallel: pass either the global batch `rgb` or this rank's shard `rgb_local` (+ n_images)")
+    if rgb_local is not None and n_images is None:
+        raise ValueError("infer_data_parallel: rgb_local needs n_images (the size of the global batch)")
+    B = rgb.shape[0] if rgb is not None else int(n_images)
     bounds = shard_bounds(B, world)
     lo, hi = bounds[rank]
     counts = [b - a for a, b in bounds]
+    if rgb_local is not None:
+        if rgb_local.ndim != 4 or rgb_local.shape[0] != hi - lo:
+            raise ValueError(f"infer_data_parallel: rank {rank} holds images [{lo}, {hi}) of {B}: rgb_local must be [{hi - lo},3,H,W], "
+                             f"got {tuple(rgb_local.shape)}")
+        mine = rgb_local
+    else:
+        mine = rgb[lo:hi]
     cam = camera
-    if isinstance(camera, torch.Tensor) and camera.ndim == 3 and camera.shape[0] == B and B > 1:
+    per_image_cam = isinstance(camera, torch.Tensor) and camera.ndim == 3 and camera.shape[0] == B and B > 1
+    if per_image_cam:
         cam = camera[lo:hi]
     if hi > lo:
-        out = model.infer(rgb[lo:hi], cam, **kw)
-    else:                                  # empty shard: run one image to learn shapes, contribute zero rows
-        out = {k: v[:0] for k, v in model.infer(rgb[:1], camera if cam is camera else camera[:1], **kw).items()}
+        out = model.infer(mine, cam, **kw)
+    else:                                  # empty shard: run one (blank, if the images live elsewhere) image to learn shapes, contribute zero rows
+        probe = rgb[:1] if rgb is not None else torch.zeros((1,) + tuple(rgb_local.shape[1:]), dtype=rgb_local.dtype, device=rgb_local.device)
+        out = {k: v[:0] for k, v in model.infer(probe, camera[:1] if per_image_cam else camera, **kw).items()}
     keys = list(out.keys()) if keys is None else list(keys)
     res = {}
     # a single GT camera (one K / one camera object for B > 1 images) yields ONE ray map, identical on every rank: it is not
@@ -114,7 +131,10 @@ def infer_data_parallel(model, rgb: torch.Tensor, camera=None, keys: Optional[It
     for k in keys:
         t = out[k]
         if k == "rays" and rays_shared:
-            res[k] = t[:1] if t.shape[0] else model.infer(rgb[:1], camera, **kw)["rays"][:1]   # identical on every rank, nothing to exchange
+            if t.shape[0] == 0:            # empty shard: the shared ray map comes from a one-image probe (the rays depend on the camera only)
+                probe = rgb[:1] if rgb is not None else torch.zeros((1,) + tuple(rgb_local.shape[1:]), dtype=rgb_local.dtype, device=rgb_local.device)
+                t = model.infer(probe, camera, **kw)["rays"]
+            res[k] = t[:1]                 # identical on every rank, nothing to exchange
             continue
         res[k] = all_gather_batch(t.contiguous(), counts, group, gather_algo)
     return res

@@ -49,10 +49,7 @@ class InferPipeline:
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(st)
         with torch.cuda.stream(st):
-            if self.depth > 1 and hasattr(self.model, "latency_split"):
-                out = self.model.infer(rgb, camera, normalize, slot=i, split=1)      # several requests in flight: whole batches (see latency_split)
-            else:
-                out = self.model.infer(rgb, camera, normalize, slot=i)
+            out = self.model.infer(rgb, camera, normalize, slot=i)
             if post is not None:
                 post(out)
             ev = torch.cuda.Event()

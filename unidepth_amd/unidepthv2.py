@@ -453,10 +453,6 @@ class UniDepthV2(EngineModule):
         # True: a plan's launch program is replayed as ONE hipGraph launch (recorded on the second call of a signature).  For the launch-bound
         # small-batch calls (bs = 1: ~280 kernels of 2-10 us each); at bs = 8 the stream is never idle and eager replay is as fast.
         self.use_graph = os.environ.get("UNIDEPTH_GRAPH", "0") == "1"
-        # > 1: one infer() runs as that many sub-batches in flight on their own HIP streams (_infer_split): a latency knob for ONE request at a
-        # time; the throughput pipeline (several requests in flight, unidepth_amd/pipeline.py) submits whole batches
-        self.latency_split = 1
-        self._split_streams: list = []
 
     # ---- checkpoint I/O (HF mixin layout: config.json + model.safetensors / pytorch_model.bin) ----
     @classmethod
@@ -574,12 +570,11 @@ class UniDepthV2(EngineModule):
 
     # ---- the hot path ----
     @torch.no_grad()
-    def infer(self, rgb: torch.Tensor, camera=None, normalize: bool = True, *, slot: int = 0, split: Optional[int] = None):
+    def infer(self, rgb: torch.Tensor, camera=None, normalize: bool = True, *, slot: int = 0):
         """Same contract as the reference infer() (unidepthv2.py:239-339).  `slot` (engine extension, keyword only) selects an
         independent set of activation buffers: calls with different slots may be in flight at the same time on different HIP
-        streams (unidepth_amd/pipeline.py); calls with the same slot must be stream-ordered, as with the reference module.
-        `split` overrides model.latency_split for this call (1 = the batch as one launch program)."""
-        return self._infer(rgb, camera, normalize, slot, None, split)
+        streams (unidepth_amd/pipeline.py); calls with the same slot must be stream-ordered, as with the reference module."""
+        return self._infer(rgb, camera, normalize, slot, None)
 
     @torch.no_grad()
     def infer_with_taps(self, rgb: torch.Tensor, camera=None, normalize: bool = True, names=None):
@@ -590,7 +585,7 @@ class UniDepthV2(EngineModule):
         out = self._infer(rgb, camera, normalize, 0, (taps, None if names is None else set(names)))
         return out, taps
 
-    def _infer(self, rgb, camera, normalize, slot, taps, split=None):
+    def _infer(self, rgb, camera, normalize, slot, taps):
         # F.interpolate(..., align_corners=False) in the reference's _postprocess (unidepthv2.py:80-89) accepts exactly these two for 4-D input
         if self.interpolation_mode not in ("bilinear", "bicubic"):
             raise ValueError(f"interpolation_mode {self.interpolation_mode!r}: 'bilinear' or 'bicubic' (align_corners=False) expected")
@@ -610,75 +605,28 @@ class UniDepthV2(EngineModule):
             if Kc is not None:
                 assert Kc.shape[-1] == 3 and Kc.shape[-2] == 3, "camera tensor should be of shape (..., 3, 3): assume pinhole"
                 Kc = Kc.detach().reshape(-1, 3, 3).float().cpu()
-        cam_nb = 0 if camera is None else (Kc.shape[0] if Kc is not None else cam_obj.params.shape[0])
-        # one camera broadcasts over the batch, otherwise one per image (the reference fails with a shape error here too)
-        assert cam_nb in (0, 1, B), f"camera batch {cam_nb} does not match the image batch {B} (one camera, or one per image)"
-        gt_mode = 0 if camera is None else (GT_PINHOLE if Kc is not None else cam_obj.gt_mode)
-        nsplit = self.latency_split if split is None else int(split)
-        if taps is not None or nsplit < 2 or B < 2 * nsplit or B % nsplit or (cam_obj is not None and cam_nb > 1):
-            nsplit = 1
+        is_u8 = rgb.dtype == torch.uint8
         with torch.cuda.device(self._device):
-            if nsplit == 1:
-                plan = self._launch(rgb, Kc, cam_obj, cam_nb, gt_mode, normalize, int(slot), taps)
-                return self._collect(plan, B)
-            return self._infer_split(rgb, Kc, cam_obj, cam_nb, gt_mode, normalize, int(slot), nsplit)
-
-    def _launch(self, rgb, Kc, cam_obj, cam_nb, gt_mode, normalize, slot, taps) -> _Plan:
-        """Copy one batch's inputs into the plan of its signature and replay the plan's launch program on the current stream."""
-        B, _, H, W = rgb.shape
-        is_u8 = rgb.dtype == torch.uint8
-        plan = self._plan(B, H, W, cam_nb, is_u8, bool(normalize), slot, gt_mode)
-        plan.rgb.copy_(rgb if is_u8 else rgb.float(), non_blocking=True)
-        if cam_obj is not None:
-            pn = cam_obj.network_params(plan.paddings, plan.rf)               # [n, <= 16] -> the parameter slots of the ray kernel
-            buf = torch.zeros(pn.shape[0], plan.kinv_gt.shape[1])
-            buf[:, :pn.shape[1]] = pn
-            plan.kinv_gt.copy_(buf)
-        if Kc is not None:
-            pl, _, pt, _ = plan.paddings
-            Kn = Kc.clone()                                    # camera.crop(-pad) then .resize(rf): utils/camera.py:78-81,115-120
-            Kn[:, 0, 2] += pl
-            Kn[:, 1, 2] += pt
-            Kn[:, :2, :] *= plan.rf
-            plan.kinv_gt.copy_(torch.inverse(Kn).reshape(-1, 9))
-        self._run(plan, 0, len(plan.prog), taps, graph=self.use_graph)
-        return plan
-
-    def _infer_split(self, rgb, Kc, cam_obj, cam_nb, gt_mode, normalize, slot, nsplit):
-        """ONE infer() as `nsplit` sub-batches in flight on their own HIP streams (model.latency_split): what a second request recovers in
-        throughput mode (unidepth_amd/pipeline.py: partial tile rounds, HBM-bound passes beside an idle matrix pipe) a single request gets from
-        its own other half.  Every image's arithmetic is that of the whole-batch plan (batch position never enters a summation order:
-        tests/test_infer_gpu.py), so the outputs are bit-identical to the unsplit call; the sub-batches write straight into the slices of
-        the call's output tensors."""
-        B = rgb.shape[0]
-        dev = self._device
-        cur = torch.cuda.current_stream(dev)
-        if len(self._split_streams) < nsplit:
-            self._split_streams += [torch.cuda.Stream(device=dev) for _ in range(nsplit - len(self._split_streams))]
-        bh = B // nsplit
-        is_u8 = rgb.dtype == torch.uint8
-        sub_nb = (1 if cam_nb == 1 else bh) if cam_nb else 0
-        plan0 = self._plan(bh, rgb.shape[2], rgb.shape[3], sub_nb, is_u8, bool(normalize), 1000 + nsplit * slot, gt_mode)
-        out = self._alloc_outputs(plan0, B, 1 if plan0.nb == 1 else B)              # on the caller's stream, like the unsplit call
-        for i in range(nsplit):
-            st = self._split_streams[i]
-            st.wait_stream(cur)                                      # inputs produced (and the output blocks last used) on the caller's stream
-            if rgb.is_cuda:
-                rgb.record_stream(st)
-            for t in out.values():
-                t.record_stream(st)
-            with torch.cuda.stream(st):
-                Ki = None if Kc is None else (Kc if cam_nb == 1 else Kc[i * bh:(i + 1) * bh])
-                plan = self._launch(rgb[i * bh:(i + 1) * bh], Ki, cam_obj, sub_nb, gt_mode, normalize, 1000 + nsplit * slot + i, None)
-                views = {k: (v if (k == "rays" and plan.nb == 1) else v[i * bh:(i + 1) * bh]) for k, v in out.items() if k not in ("intrinsics", "depth_features")}
-                if plan.nb == 1 and i > 0:                           # one GT camera: the rays are the same for every sub-batch, the first one writes them
-                    views["rays"] = torch.empty_like(out["rays"])
-                plan.finalize(views, 1 if self.interpolation_mode == "bicubic" else 0)
-                out["intrinsics"][i * bh:(i + 1) * bh].copy_(plan.Kpost.view(bh, 3, 3))
-                out["depth_features"][i * bh:(i + 1) * bh].copy_(plan.depth_features)
-        for i in range(nsplit):
-            cur.wait_stream(self._split_streams[i])
-        return {k: out[k] for k in ("confidence", "intrinsics", "radius", "depth", "points", "rays", "depth_features")}
+            cam_nb = 0 if camera is None else (Kc.shape[0] if Kc is not None else cam_obj.params.shape[0])
+            # one camera broadcasts over the batch, otherwise one per image (the reference fails with a shape error here too)
+            assert cam_nb in (0, 1, B), f"camera batch {cam_nb} does not match the image batch {B} (one camera, or one per image)"
+            gt_mode = 0 if camera is None else (GT_PINHOLE if Kc is not None else cam_obj.gt_mode)
+            plan = self._plan(B, H, W, cam_nb, is_u8, bool(normalize), int(slot), gt_mode)
+            plan.rgb.copy_(rgb if is_u8 else rgb.float(), non_blocking=True)
+            if cam_obj is not None:
+                pn = cam_obj.network_params(plan.paddings, plan.rf)               # [n, <= 16] -> the parameter slots of the ray kernel
+                buf = torch.zeros(pn.shape[0], plan.kinv_gt.shape[1])
+                buf[:, :pn.shape[1]] = pn
+                plan.kinv_gt.copy_(buf)
+            if Kc is not None:
+                pl, _, pt, _ = plan.paddings
+                Kn = Kc.clone()                                    # camera.crop(-pad) then .resize(rf): utils/camera.py:78-81,115-120
+                Kn[:, 0, 2] += pl
+                Kn[:, 1, 2] += pt
+                Kn[:, :2, :] *= plan.rf
+                plan.kinv_gt.copy_(torch.inverse(Kn).reshape(-1, 9))
+            self._run(plan, 0, len(plan.prog), taps, graph=self.use_graph)
+            return self._collect(plan, B)
 
     @staticmethod
     def _run(plan: _Plan, first: int, last: int, taps=None, graph: bool = False):
@@ -699,23 +647,18 @@ class UniDepthV2(EngineModule):
         if last > pos:
             plan.prog.run(pos, last)
 
-    def _alloc_outputs(self, plan: _Plan, B: int, nb_rays: int):
+    def _collect(self, plan: _Plan, B: int):
         dev, f32 = self._device, torch.float32
-        return {
+        out = {
             "confidence": torch.empty(B, 1, plan.Ho, plan.Wo, dtype=f32, device=dev),
             "radius": torch.empty(B, 1, plan.Ho, plan.Wo, dtype=f32, device=dev),
             "depth": torch.empty(B, 1, plan.Ho, plan.Wo, dtype=f32, device=dev),
             "points": torch.empty(B, 3, plan.Ho, plan.Wo, dtype=f32, device=dev),
-            "rays": torch.empty(nb_rays, 3, plan.Ho, plan.Wo, dtype=f32, device=dev),
-            "intrinsics": torch.empty(B, 3, 3, dtype=f32, device=dev),
-            "depth_features": torch.empty((B,) + tuple(plan.depth_features.shape[1:]), dtype=plan.depth_features.dtype, device=dev),
+            "rays": torch.empty(plan.nb, 3, plan.Ho, plan.Wo, dtype=f32, device=dev),
         }
-
-    def _collect(self, plan: _Plan, B: int):
-        out = self._alloc_outputs(plan, B, plan.nb)
         plan.finalize(out, 1 if self.interpolation_mode == "bicubic" else 0)
-        out["intrinsics"].copy_(plan.Kpost.view(B, 3, 3))
-        out["depth_features"].copy_(plan.depth_features)
+        out["intrinsics"] = plan.Kpost.view(B, 3, 3).clone()
+        out["depth_features"] = plan.depth_features.clone()
         return {k: out[k] for k in ("confidence", "intrinsics", "radius", "depth", "points", "rays", "depth_features")}
 
     __call__ = infer
