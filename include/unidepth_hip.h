@@ -426,19 +426,8 @@ int ud_program_add_patchify4(UdProgram*, const float* img, void* out, int B, int
 int ud_program_add_max(UdProgram*, float* dst, const float* src, long long n, int init);
 int ud_program_add_spatial_mean(UdProgram*, const float* x, float* out, int B, int HW, int C, int ldo);
 int ud_program_add_v1_op(UdProgram*, const UdV1Op*);
-/* side branch: mode 0 = the ops that follow run on the program's own second stream, behind everything recorded so far; 1 = back on the
- * caller's stream (the branch keeps running); 2 = the caller's stream waits for the branch.  Independent launch chains of one forward pass
- * side by side (HIP streams + events where the reference's module graph is one eager sequence: decoder.py:405-462 computes the camera head
- * and the feature adapters one after the other).  The branches must write disjoint buffers; a range that ends inside a branch is joined. */
-int ud_program_add_side(UdProgram*, int mode);
-/* run ops [first, last) on `stream`; returns 0 or the first failing op's error code */
+/* run ops [first, last) on `stream`; returns 0 or the first failing op's error code.  Stateless: a recorded program is never modified by a replay */
 int ud_program_run(const UdProgram*, int first, int last, void* stream);
-/* the same replay through a hipGraph (HIP graphs in place of the reference's eager module calls, unidepthv2.py:341-379): the first call
- * for a range runs it eagerly, the second records + instantiates it, every later call is one hipGraphLaunch on `stream` (which may be the
- * default stream).  Results are bit-identical to ud_program_run (same kernels, same order).  ud_program_graph_count: instantiated ranges. */
-int ud_program_run_graph(UdProgram*, int first, int last, void* stream);
-int ud_program_graph_count(const UdProgram*);
-void ud_program_drop_graphs(UdProgram*);
 
 /* library info; ud_struct_size(i): sizeof the i-th descriptor struct in declaration order (UdGemm = 0 ... UdLinearF32 = 8, UdDwConv7 = 9, UdV1Op = 10, UdKnn = 11, UdExtractPatches = 12) */
 int ud_version(void);

@@ -70,6 +70,43 @@ def test_data_parallel_direct_all_pairs_gather_gloo(world, B):
     assert sorted(res) == [(r, True) for r in range(world)]
 
 
+def _worker_local(rank, world, port, B, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unidepth_amd.dist import infer_data_parallel, shard_bounds
+    g = torch.Generator().manual_seed(0)
+    rgb = torch.randint(0, 256, (B, 3, 6, 5), dtype=torch.uint8, generator=g)
+    lo, hi = shard_bounds(B, world)[rank]
+    ref = infer_data_parallel(_FakeModel(), rgb, keys=("depth", "intrinsics", "confidence"))
+    out = infer_data_parallel(_FakeModel(), keys=("depth", "intrinsics", "confidence"), rgb_local=rgb[lo:hi].clone(), n_images=B)   # only this rank's images
+    ok = all(torch.equal(out[k], ref[k]) for k in ref) and out["depth"].shape[0] == B
+    try:
+        infer_data_parallel(_FakeModel(), rgb_local=torch.zeros(hi - lo + 1, 3, 6, 5, dtype=torch.uint8), n_images=B)     # wrong shard size: a clear error, on every rank alike
+        ok = False
+    except ValueError:
+        pass
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,B", [(2, 8), (2, 5), (3, 2)])
+def test_data_parallel_local_shards_equal_global_batch_gloo(world, B):
+    """infer_data_parallel(rgb_local=, n_images=): every rank hands over ONLY its shard (no redundant copy of the other ranks' images) and
+    gets the same gathered outputs as with the global batch on every rank -- even shards, uneven shards, and a rank with no image at all."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_local, args=(r, world, port, B, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(r, True) for r in range(world)]
+
+
 def test_shard_bounds():
     from unidepth_amd.dist import shard_bounds
     assert shard_bounds(64, 8) == [(i * 8, i * 8 + 8) for i in range(8)]

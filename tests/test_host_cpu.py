@@ -479,11 +479,10 @@ def test_v1_plan_builder_dry_run_validates_every_gemm_descriptor(monkeypatch):
     assert len(three) == 9, three                              # up{8,4,2}.up.0, up{8,4,2}.up.2, out{8,4,2}
 
 
-def test_v2_plan_builder_dry_run_side_branch_and_descriptors(monkeypatch):
+def test_v2_plan_builder_dry_run_order_and_descriptors(monkeypatch):
     """The UniDepthV2 launch program recorded on the host (nothing runs): every GEMM descriptor passes the C side's argument validation, and
-    the decoder starts with the two branches the program's side stream separates -- camera head + rays + ray embedding between
-    side.begin / side.end, the feature adapters / LayerNorm / q projection between side.end / side.join, the K / V projection of the
-    ray embedding right behind the join (ud_program_add_side)."""
+    the decoder starts with the grouped feature adapters, then the camera head + rays + ray embedding, then LayerNorm / q projection and the
+    K / V projection of the ray embedding."""
     import contextlib
     from oracle import synth
     from unidepth_amd import UniDepthV2, _lib, ops
@@ -496,7 +495,6 @@ def test_v2_plan_builder_dry_run_side_branch_and_descriptors(monkeypatch):
     m._w = pack(cfg, m._sd, dev)
     m._device = dev
     m.resolution_level = 2
-    monkeypatch.setenv("UNIDEPTH_SIDE", "1")                   # the branch form (off by default: measured neutral)
     monkeypatch.setattr(torch.cuda, "device", lambda d: contextlib.nullcontext())
     monkeypatch.setattr(ops, "ptr", lambda t: None if t is None else (t if isinstance(t, int) else t.data_ptr()))
     real_add, seen = _lib.lib.ud_program_add_gemm, []
@@ -509,29 +507,31 @@ def test_v2_plan_builder_dry_run_side_branch_and_descriptors(monkeypatch):
     plan = m._plan(1, 462, 616, 0, True, True)
     assert len(seen) > 60 and not [r for r in seen if r[0] != -2], [r for r in seen if r[0] != -2][:3]     # -2 = UD_ERR_LAUNCH: arguments accepted
     tags = [t[1] for t in plan.prog.meta]
-    i0, i1, i2 = tags.index("side.begin"), tags.index("side.end"), tags.index("side.join")
-    assert plan.dec_first == plan.enc_last == i0 and tags.count("side.begin") == 1
-    cam = tags[i0 + 1:i1]
-    assert cam.count("cam.adapter") == 4 and cam[-2:] == ["rays", "ray_embed"] and "camera_intrinsics" in cam and not any(t.startswith("dec.") or t.startswith("dh.") for t in cam)
-    assert tags[i1 + 1:i2] == ["dec.adapters(x4)", "layernorm", "dh.q(x4)"] and tags[i2 + 1] == "dh.kv(x4)"
-    assert ops.lib.ud_program_add_side(plan.prog.h, 3) < 0                                                # unknown mode: refused
+    i0 = tags.index("dec.adapters(x4)")
+    assert plan.dec_first == plan.enc_last == i0
+    cam = tags[i0 + 1:tags.index("ray_embed") + 1]
+    assert cam.count("cam.adapter") == 4 and cam[-2:] == ["rays", "ray_embed"] and "camera_intrinsics" in cam and not any(t.startswith("dh.") for t in cam)
+    assert tags[tags.index("ray_embed") + 1:tags.index("ray_embed") + 4] == ["layernorm", "dh.q(x4)", "dh.kv(x4)"]
 
 
-def test_program_graph_and_side_api_argument_checks_without_gpu():
-    """ud_program_run_graph / ud_program_add_side / ud_program_graph_count on the host: ranges and modes are validated before anything
-    touches the device, an empty range is a no-op, a program without recorded graphs reports none, destroy releases everything."""
+def test_program_api_argument_checks_without_gpu():
+    """ud_program_run on the host: ranges are validated before anything touches the device, an empty range is a no-op."""
     from unidepth_amd import _lib
     lib = _lib.lib
     p = lib.ud_program_create()
-    assert p and lib.ud_program_size(p) == 0 and lib.ud_program_graph_count(p) == 0
-    assert lib.ud_program_add_side(p, 0) == 0 and lib.ud_program_add_side(p, 1) == 1 and lib.ud_program_add_side(p, 2) == 2
-    assert lib.ud_program_add_side(p, 7) == -1 and lib.ud_program_add_side(None, 0) == -1          # UD_ERR_BAD_ARG
-    assert lib.ud_program_size(p) == 3
-    assert lib.ud_program_run_graph(p, 2, 1, None) == -1 and b"bad range" in lib.ud_last_error()
-    assert lib.ud_program_run_graph(p, 0, 9, None) == -1
-    assert lib.ud_program_run(p, -1, 2, None) == -1
-    assert lib.ud_program_run_graph(p, 1, 1, None) == 0                                              # empty range: nothing to do
-    assert lib.ud_program_run(p, 1, 2, None) == 0                                                    # a bare END marker touches no device state
-    lib.ud_program_drop_graphs(p)
-    assert lib.ud_program_graph_count(p) == 0
+    assert p and lib.ud_program_size(p) == 0
+    assert lib.ud_program_run(p, -1, 2, None) == -1 and b"bad range" in lib.ud_last_error()
+    assert lib.ud_program_run(p, 0, 1, None) == -1
+    assert lib.ud_program_run(p, 0, 0, None) == 0                                                    # empty range: nothing to do
     lib.ud_program_destroy(p)
+
+
+def test_rccl_cabi_argument_checks_without_gpu():
+    """ud_rccl_* (the exchange step of batch data parallelism behind the C-ABI): arguments are validated and a missing communicator is an
+    error, before librccl or a device is touched."""
+    from unidepth_amd import _lib
+    lib = _lib.lib
+    assert lib.ud_rccl_unique_id(None) == -1
+    assert lib.ud_rccl_init(None, 2, 0) == -1 and lib.ud_rccl_init(b"x" * 128, 2, 2) == -1 and lib.ud_rccl_init(b"x" * 128, 0, 0) == -1
+    assert lib.ud_rccl_allgather_outputs(None, None, 16, 0, None) == -1 and b"no communicator" in lib.ud_last_error()
+    assert lib.ud_rccl_finalize() == 0

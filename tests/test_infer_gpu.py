@@ -231,74 +231,3 @@ def test_interrupted_replay_leaves_no_state_behind(engine_cls):
     torch.cuda.synchronize()
     for k in out0:
         assert torch.equal(out0[k], out1[k]), k
-
-
-def test_graph_replay_bit_identical(engine_cls):
-    """model.use_graph (csrc/program.cpp ud_program_run_graph: call 1 of a signature eager, call 2 recorded into a hipGraph and launched,
-    later calls one hipGraphLaunch): the same kernels in the same order -> the same bits as the eager replay, on fresh inputs too (the graph
-    reads the plan's input buffer, not a snapshot), for the launch-bound bs=1 shape of BASELINE configs[0] and with a GT camera."""
-    case = cases.CASES["vits_462x616_b1"]
-    cfg = synth.load_config(case["arch"])
-    sd = synth.make_synthetic_checkpoint(cfg, case["ckpt_seed"])
-    eager = engine_cls(cfg).load_state_dict(sd).to("cuda").eval()
-    graph = engine_cls(cfg).load_state_dict(sd).to("cuda").eval()
-    eager.resolution_level = graph.resolution_level = 2
-    graph.use_graph = True
-    g = torch.Generator().manual_seed(21)
-    K = torch.tensor([[500.0, 0.0, 308.0], [0.0, 500.0, 231.0], [0.0, 0.0, 1.0]])
-    for cam in (None, K):
-        for i in range(4):
-            rgb = torch.randint(0, 256, (1, 3, 462, 616), dtype=torch.uint8, generator=g).cuda()
-            a = eager.infer(rgb, None if cam is None else cam.cuda())
-            b = graph.infer(rgb, None if cam is None else cam.cuda())
-            torch.cuda.synchronize()
-            for k in a:
-                assert torch.equal(a[k], b[k]), (k, i, cam is not None)
-    counts = [p.prog.graph_count() for p in graph._plans.values()]
-    assert counts == [1, 1], counts                       # one instantiated graph per plan signature (no camera / GT camera)
-    assert all(p.prog.graph_count() == 0 for p in eager._plans.values())
-
-
-def test_side_branch_bit_identical(engine_cls, monkeypatch):
-    """The decoder's camera branch on the program's side stream (ud_program_add_side: fork / join by events) against the one-stream replay
-    (UNIDEPTH_SIDE=0): the branches write disjoint buffers, so every output must carry the same bits -- eager, as a hipGraph (the side
-    stream joins the capture through its fork event), through the tap replay (ranges that end or start inside a branch) and with the
-    calls of two pipeline slots in flight."""
-    case = cases.CASES["vits_462x616_b1"]
-    cfg = synth.load_config(case["arch"])
-    sd = synth.make_synthetic_checkpoint(cfg, case["ckpt_seed"])
-    monkeypatch.setenv("UNIDEPTH_SIDE", "0")
-    one = engine_cls(cfg).load_state_dict(sd).to("cuda").eval()
-    one.resolution_level = 2
-    g = torch.Generator().manual_seed(33)
-    rgbs = [torch.randint(0, 256, (2, 3, 462, 616), dtype=torch.uint8, generator=g).cuda() for _ in range(3)]
-    K = torch.tensor([[480.0, 0.0, 300.0], [0.0, 470.0, 240.0], [0.0, 0.0, 1.0]]).cuda()
-    ref = [one.infer(r) for r in rgbs] + [one.infer(rgbs[0], K)]
-    torch.cuda.synchronize()
-    assert "side.begin" not in [m[1] for m in next(iter(one._plans.values())).prog.meta]
-    monkeypatch.setenv("UNIDEPTH_SIDE", "1")
-    for use_graph in (False, True):
-        two = engine_cls(cfg).load_state_dict(sd).to("cuda").eval()
-        two.resolution_level = 2
-        two.use_graph = use_graph
-        assert two is not one
-        for rep in range(2):                                   # graph: eager, record; then launches
-            outs = [two.infer(r) for r in rgbs] + [two.infer(rgbs[0], K)]
-        torch.cuda.synchronize()
-        assert "side.begin" in [m[1] for m in next(iter(two._plans.values())).prog.meta]
-        for a, b in zip(ref, outs):
-            for k in a:
-                assert torch.equal(a[k], b[k]), (k, use_graph)
-        if not use_graph:
-            o, taps = two.infer_with_taps(rgbs[1])             # segmented replay: tap points sit inside and behind the branches
-            torch.cuda.synchronize()
-            for k in ref[1]:
-                assert torch.equal(ref[1][k], o[k]), k
-            assert torch.isfinite(taps["intrinsics4"]).all() and torch.isfinite(taps["input_adapter.0"]).all()
-            from unidepth_amd.pipeline import InferPipeline
-            pipe = InferPipeline(two, depth=2)
-            po = [pipe.submit(r) for r in rgbs]
-            pipe.sync()
-            for a, b in zip(ref[:3], po):
-                for k in a:
-                    assert torch.equal(a[k], b[k]), ("pipeline", k)

@@ -189,16 +189,21 @@ def test_v1_depth_error_distribution(arch):
     _hist(f"UniDepthV1 {arch} intrinsics max-rel", kk, 1e-3)
     over = sum(d > 1e-3 for d in dep)
     print(f"UniDepthV1 {arch}: {len(dep) - over} of {len(dep)} cases within 1e-3; worst {max(dep):.2e}")
-    # MEASURED, round 4 (profiles/r04_v1_sweep_*.txt, r04_parity_sweep.txt):
-    #   ConvNeXt-L  round-3 build        median 9.2e-4  max 1.54e-3  10 of 16 within 1e-3
-    #               + three-term tail     median 7.0e-4  max 1.09e-3  15 of 16   (activation rounding of the ConvUpsample tails / output convs removed)
-    #               + fc1 weights split   median 5.6e-4  max 7.9e-4   16 of 16   (the default build: the north-star bar, with 21 % of margin on the worst case)
-    #   ViT-L/14    round-3 build        median 1.03e-3 max 1.93e-3   8 of 16
-    #               + three-term tail     median 8.1e-4  max 1.48e-3  11 of 16   (the rest is the fp16-operand ENCODER against an fp32 reference: a global
-    #                                                                             shift through the class tokens, tools/r4_v1_seed_study.py; bar NOT met)
-    # The camera is not the cause in either (K <= 4.2e-4 everywhere).  Asserted: ConvNeXt-L (SURVEY 8f / BASELINE configs[3]) at the bar itself;
-    # the ViT-L/14 variant at the level its distribution supports with margin, so that a precision regression still fails.
+    # MEASURED (profiles/r04_v1_sweep_*.txt, profiles/r05_v1_parity_sweep_head_mix.txt):
+    #   ConvNeXt-L  round-3 build                         median 9.2e-4  max 1.54e-3  10 of 16 within 1e-3
+    #               + three-term tail, fc1 weights split  median 5.6e-4  max 7.9e-4   16 of 16   (round 4)
+    #               + NystromBlocks as the reference executes them (round 5)   median 5.9e-4  max 7.9e-4  16 of 16
+    #   ViT-L/14    round-3 build                         median 1.03e-3 max 1.93e-3   8 of 16
+    #               + three-term tail                      median 8.1e-4  max 1.48e-3  11 of 16   (round 4)
+    #               + NystromBlocks as the reference executes them (round 5)   median 7.6e-4  max 1.08e-3  15 of 16
+    #                 (what is left is the fp16-operand ENCODER against an fp32 reference: a global shift through the class tokens)
+    # The camera is not the cause in either (K <= 3.6e-4 everywhere).  Asserted: ConvNeXt-L (SURVEY 8f / BASELINE configs[3]) at the bar itself; the
+    # ViT-L/14 variant at the level its distribution supports with margin (a precision regression still fails) -- and every case of it that is
+    # above 1e-3 turns the test into a visible XFAIL instead of a silent pass.
     if arch == "cnvnxtl":
         assert max(dep) <= 1e-3 and max(kk) <= 1e-3, (float(np.median(dep)), max(dep), max(kk))
     else:
-        assert float(np.median(dep)) <= 1.0e-3 and max(dep) <= 2.0e-3 and max(kk) <= 1e-3, (float(np.median(dep)), max(dep), max(kk))
+        assert float(np.median(dep)) <= 1.0e-3 and max(dep) <= 1.5e-3 and over <= 3 and max(kk) <= 1e-3, (float(np.median(dep)), max(dep), over, max(kk))
+        if over:
+            pytest.xfail(f"UniDepthV1 ViT-L/14: {over} of {len(dep)} cases above the 1e-3 bar (worst {max(dep):.2e}): the north-star bar is NOT met on every checkpoint "
+                         "for this variant (fp16-operand encoder against the reference's fp32 path)")

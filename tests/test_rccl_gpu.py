@@ -45,3 +45,33 @@ def test_bench_self_launch_two_ranks_shared_gpu():
         pytest.skip("covered by the RCCL test on this box")
     d = _run_bench({"UD_BENCH_SHARE_GPU": "1", "UD_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["rccl"]["ranks_seen"] == [0, 1] and d["rccl"]["all_blocks_valid"]
+
+
+def test_cabi_allgather_single_rank_communicator():
+    """ud_rccl_* (include/unidepth_hip.h; SURVEY.md 8b `rccl_allgather_outputs`): unique id -> communicator of ONE rank on this GPU -> the
+    all-gather of a packed output block, both forms (ncclAllGather and the all-pairs send / receive group), on a side stream; double init and
+    a call after finalize are errors.  The multi-rank exchange itself needs >= 2 GPUs (test_bench_two_ranks_rccl)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import ctypes as C
+    from unidepth_amd import _lib
+    L = _lib.lib
+    uid = C.create_string_buffer(128)
+    assert L.ud_rccl_unique_id(uid) == 0, L.ud_last_error()
+    assert L.ud_rccl_init(uid, 1, 0) == 0, L.ud_last_error()
+    try:
+        assert L.ud_rccl_init(uid, 1, 0) != 0                                   # one communicator per process
+        src = torch.randn(3, 1000, device="cuda")
+        st = torch.cuda.Stream()
+        for direct in (0, 1):
+            dst = torch.zeros_like(src)
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                rc = L.ud_rccl_allgather_outputs(src.data_ptr(), dst.data_ptr(), src.numel() * 4, direct, st.cuda_stream)
+            assert rc == 0, L.ud_last_error()
+            st.synchronize()
+            assert torch.equal(dst, src), direct
+        assert L.ud_rccl_allgather_outputs(None, src.data_ptr(), 16, 0, None) != 0
+    finally:
+        assert L.ud_rccl_finalize() == 0
+    assert L.ud_rccl_allgather_outputs(src.data_ptr(), src.data_ptr(), 16, 0, None) != 0   # no communicator any more

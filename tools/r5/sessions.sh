@@ -79,4 +79,18 @@ done
 cat $O/tests.txt $O/latency_ab.txt; tail -5 $O/err.txt
 }
 
+# round 5, GPU call 6: the whole GPU suite after the clean-up (side branch / hipGraph replay / env switches / split-key attention removed,
+# ud_rccl_* added), a bench line, two bs = 4 requests in flight against one (how much do half-size programs overlap?)
+call6() {
+O=gpurun_out/r5c6 && mkdir -p $O
+t0=$(date +%s)
+timeout 1500 python -m pytest tests -q -m gpu -x --deselect tests/test_parity_sweep_gpu.py 2>&1 | grep -v "^$\|amdgpu.ids" | tail -15 > $O/suite.txt
+echo "[suite done $(( $(date +%s) - t0 )) s]" >> $O/suite.txt
+timeout 400 python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-extra-configs 2>$O/err.txt | line "bs8 inflight2" > $O/bench.txt
+for inf in 1 2; do
+  timeout 300 python bench.py --batch 4 --inflight $inf --steps 20 --warmup 4 --no-cpu-baseline --no-extra-configs --no-kernel-timing 2>>$O/err.txt | line "bs4 inflight$inf" >> $O/bench.txt
+done
+cat $O/suite.txt $O/bench.txt; tail -3 $O/err.txt
+}
+
 "$@"

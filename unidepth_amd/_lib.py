@@ -168,10 +168,7 @@ def _load():
         "ud_knn_points": [P(UdKnn), vp],
         "ud_knn_split": [P(UdKnn)],
         "ud_extract_patches": [P(UdExtractPatches), vp],
-        "ud_program_add_side": [vp, i32],
         "ud_program_run": [vp, i32, i32, vp],
-        "ud_program_run_graph": [vp, i32, i32, vp],
-        "ud_program_graph_count": [vp],
         "ud_version": [],
         "ud_struct_size": [i32],
     }
@@ -179,8 +176,6 @@ def _load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = None if name == "ud_program_destroy" else i32
-    lib.ud_program_drop_graphs.argtypes = [vp]
-    lib.ud_program_drop_graphs.restype = None
     lib.ud_program_create.argtypes = []
     lib.ud_program_create.restype = vp
     lib.ud_last_error.argtypes = []

@@ -1463,12 +1463,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   }
 }
 
-// W3 form of the 192-row tile list (3-deep weight ring, see the kernel): dense problems with at least two K-tiles.  UD_GEMM_W3=0 in the
-// environment keeps the 2-deep form (A/B runs; read once per process).
-inline bool w3_enabled() {
-  static const int on = [] { const char* e = getenv("UD_GEMM_W3"); return (e && e[0] == '0') ? 0 : 1; }();
-  return on != 0;
-}
+// W3 form of the 192-row tile list (3-deep weight ring, see the kernel): dense problems with at least two K-tiles.
+inline bool w3_enabled() { return true; }
 
 template <int MH, int EPI, int AMODE, bool LNC = false, bool GRP = false>
 int launch256(const UdGemm& d, hipStream_t s) {
@@ -1990,10 +1986,7 @@ int launch_conv_tile(const UdGemm& d, hipStream_t s) {
   return UD_OK;
 }
 
-inline bool head_regw_enabled() {
-  static const int on = [] { const char* e = getenv("UD_HEAD_REGW"); return (e && e[0] == '0') ? 0 : 1; }();
-  return on != 0;
-}
+inline bool head_regw_enabled() { return true; }
 
 // eligibility: dense images (rows_img == H*W), N in {32, 64}, Cin multiple of 64, weights laid out [N][tap*Cin + ci]
 inline bool conv_tile_ok(const UdGemm& d) {

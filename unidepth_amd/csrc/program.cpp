@@ -1,15 +1,10 @@
 // Launch programs: the host-side runtime piece of the engine.  A forward pass is recorded once per
 // (model, batch, shape) as a flat list of kernel descriptors and replayed with ONE call from Python, so the
-// per-launch host cost is a C++ switch instead of a ctypes round trip (the recorded range can also be captured
-// into a hipGraph by the caller: every launch goes to the stream passed to ud_program_run).
-// ud_program_run_graph does that capture itself: the second replay of a range records it on a private capture stream (the caller's stream
-// may be the legacy default stream, which cannot capture), instantiates the graph once and from then on a replay is ONE hipGraphLaunch.
-// Measured on MI355X: bit-identical to the eager replay and NOT faster, at bs = 8 or at bs = 1 -- the small-batch programs
-// are paced by dependent, under-filled kernels on the GPU, not by this file's launch loop.  Kept as an option, off by default.
-// ud_program_add_side: a second stream per program with fork / join events for independent launch chains.
+// per-launch host cost is a C++ switch instead of a ctypes round trip.  A program is immutable once recorded and ud_program_run keeps no
+// state: any number of threads / streams may replay one program concurrently as long as they may share its buffers.
+// (Rounds 1 and 4 replayed programs through hipGraphs and round 4 forked the camera branch onto a second stream: both bit-identical, both
+// measured neutral twice -- the programs are paced by dependent kernels on the GPU, not by this launch loop -- and removed in round 5.)
 #include <hip/hip_runtime.h>
-#include <map>
-#include <utility>
 #include <vector>
 #include <new>
 #include "../../include/unidepth_hip.h"
@@ -17,7 +12,7 @@
 void ud_set_error(const char* msg);
 
 namespace {
-enum Kind { K_LIN32, K_ATTS, K_GEMM, K_LN, K_ATTN, K_PRE, K_FILL, K_CAM, K_RAYS, K_RAYS_CAM, K_EMBED, K_UP2, K_RESIZE, K_FINAL, K_T, K_DW7, K_LNP2, K_PATCH4, K_MAX, K_MEAN, K_V1, K_RSF, K_SIDE };
+enum Kind { K_LIN32, K_ATTS, K_GEMM, K_LN, K_ATTN, K_PRE, K_FILL, K_CAM, K_RAYS, K_RAYS_CAM, K_EMBED, K_UP2, K_RESIZE, K_FINAL, K_T, K_DW7, K_LNP2, K_PATCH4, K_MAX, K_MEAN, K_V1, K_RSF };
 struct FillArgs { float* dst; const float* src; int n_img, rows_per_img, row_off, D, ld; };
 struct CamArgs { const float* raw; int raw_stride; float* intr4; float* K33; float* Kinv33; float* Kpost33; int B, Hn, Wn; float rf; int pad_l, pad_t; };
 struct RaysArgs { const float* Kinv33; float* rays; int nb, Hn, Wn, gt_mode; };
@@ -34,42 +29,21 @@ struct Op {
   union {
     UdGemm gemm; UdLayerNorm ln; UdAttention attn; UdPreprocess pre; FillArgs fill; CamArgs cam; RaysArgs rays; RaysCamArgs rays_cam;
     UdRayEmbed embed; UdUpsample2x up2; UdResizeAC resize; UdFinalize fin; TArgs t; UdLinearF32 lin32; AttSArgs atts;
-    UdDwConv7 dw7; UdV1Op v1; LnP2Args lnp2; Patch4Args patch4; MaxArgs mx; MeanArgs mean; RsfArgs rsf; int side;
+    UdDwConv7 dw7; UdV1Op v1; LnP2Args lnp2; Patch4Args patch4; MaxArgs mx; MeanArgs mean; RsfArgs rsf;
   };
   Op() {}
 };
 }  // namespace
 
-struct UdGraph { hipGraphExec_t exec = nullptr; int device = -1; int runs = 0; };
 struct UdProgram {
   std::vector<Op> ops;
-  std::map<std::pair<int, int>, UdGraph> graphs;      // (first, last) -> instantiated graph of that range
-  // side branch (ud_program_add_side): a second stream of this program and the two events that fork it from / join it to the caller's
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  int side_device = -1;
 };
 
 extern "C" {
 UdProgram* ud_program_create(void) { return new (std::nothrow) UdProgram(); }
-static void drop_graphs(UdProgram* p) {
-  for (auto& kv : p->graphs)
-    if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
-  p->graphs.clear();
-}
-static void drop_side(UdProgram* p) {
-  if (p->side) (void)hipStreamDestroy(p->side);
-  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
-  if (p->ev_join) (void)hipEventDestroy(p->ev_join);
-  p->side = nullptr; p->ev_fork = p->ev_join = nullptr; p->side_device = -1;
-}
-void ud_program_destroy(UdProgram* p) {
-  if (p) { drop_graphs(p); drop_side(p); }
-  delete p;
-}
+void ud_program_destroy(UdProgram* p) { delete p; }
 int ud_program_size(const UdProgram* p) { return p ? (int)p->ops.size() : 0; }
 
-// (a recorded graph holds the descriptors BY VALUE: appending ops does not change it, but a range that grew is a different key)
 #define ADD(KIND, FIELD, SRC)       \
   if (!p) return UD_ERR_BAD_ARG;    \
   Op op; op.kind = KIND; op.FIELD = SRC; p->ops.push_back(op); return (int)p->ops.size() - 1;
@@ -132,70 +106,13 @@ int ud_program_add_row_stats_finalize(UdProgram* p, const float* partials, float
   RsfArgs a = {partials, stats, M, slabs, D, eps};
   ADD(K_RSF, rsf, a)
 }
-// Side branch of a program: independent launch chains of one forward pass on two HIP streams (the V2 camera head -- ~25 dependent launches
-// of a few workgroups each -- beside the decoder's adapter GEMMs, which do not depend on the camera).
-//   mode 0  BEGIN  the ops that follow run on the program's side stream, ordered behind everything recorded so far (event fork)
-//   mode 1  END    the ops that follow run on the caller's stream again; the side branch keeps running
-//   mode 2  JOIN   the caller's stream waits for the side branch (event join); a no-op when nothing is outstanding
-// A replayed RANGE that starts inside a branch runs those ops on the caller's stream (correct, just serial); a range that ends before the
-// JOIN is joined at its end, so a caller that synchronises its stream sees all the work of the range.  The two branches must write
-// disjoint buffers: results are then bit-identical to the one-stream replay.
-int ud_program_add_side(UdProgram* p, int mode) {
-  if (mode < 0 || mode > 2) return UD_ERR_BAD_ARG;
-  ADD(K_SIDE, side, mode)
-}
-
-static int side_setup(UdProgram* p) {
-  int dev = -1;
-  if (hipGetDevice(&dev) != hipSuccess) return UD_ERR_LAUNCH;
-  if (p->side && p->side_device == dev) return UD_OK;
-  drop_side(p);
-  if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess) {
-    drop_side(p);
-    ud_set_error("ud_program_run: cannot create the side stream / events of a program");
-    return UD_ERR_LAUNCH;
-  }
-  p->side_device = dev;
-  return UD_OK;
-}
-
-int ud_program_run(const UdProgram* cp, int first, int last, void* stream) {
-  UdProgram* p = const_cast<UdProgram*>(cp);           // the side stream and its events are created on first use
+int ud_program_run(const UdProgram* p, int first, int last, void* stream) {
   if (!p || first < 0 || last > (int)p->ops.size() || first > last) { ud_set_error("ud_program_run: bad range"); return UD_ERR_BAD_ARG; }
-  hipStream_t main_s = (hipStream_t)stream;
-  void* cur = stream;
-  bool outstanding = false;                             // side work issued in this range and not yet joined
-  auto join = [&]() -> int {
-    if (!outstanding) return UD_OK;
-    if (hipEventRecord(p->ev_join, p->side) != hipSuccess || hipStreamWaitEvent(main_s, p->ev_join, 0) != hipSuccess) {
-      ud_set_error("ud_program_run: joining the side branch failed");
-      return UD_ERR_LAUNCH;
-    }
-    outstanding = false;
-    return UD_OK;
-  };
+  void* const cur = stream;
   for (int i = first; i < last; ++i) {
     const Op& op = p->ops[i];
     int rc = UD_OK;
     switch (op.kind) {
-      case K_SIDE:
-        if (op.side == 0) {
-          if ((rc = side_setup(p)) != UD_OK) break;
-          if (hipEventRecord(p->ev_fork, main_s) != hipSuccess || hipStreamWaitEvent(p->side, p->ev_fork, 0) != hipSuccess) {
-            ud_set_error("ud_program_run: forking the side branch failed");
-            rc = UD_ERR_LAUNCH;
-            break;
-          }
-          cur = (void*)p->side;
-          outstanding = true;
-        } else if (op.side == 1) {
-          cur = stream;
-        } else {
-          cur = stream;
-          rc = join();
-        }
-        break;
       case K_GEMM: rc = ud_gemm_f16(&op.gemm, cur); break;
       case K_LIN32: rc = ud_linear_f32(&op.lin32, cur); break;
       case K_ATTS: rc = ud_attention_small_f32(op.atts.q, op.atts.kv, op.atts.out, op.atts.B, op.atts.T, op.atts.H, op.atts.C, op.atts.scale, cur); break;
@@ -219,55 +136,8 @@ int ud_program_run(const UdProgram* cp, int first, int last, void* stream) {
       case K_RSF: rc = ud_row_stats_finalize(op.rsf.part, op.rsf.stats, op.rsf.M, op.rsf.slabs, op.rsf.D, op.rsf.eps, cur); break;
       case K_T: rc = ud_nhwc_to_nchw_f32(op.t.in, op.t.out, op.t.B, op.t.hw, op.t.C, op.t.ld, op.t.rows_per_img, cur); break;
     }
-    if (rc != UD_OK) { (void)join(); return rc; }
+    if (rc != UD_OK) return rc;
   }
-  return join();
-}
-
-// Replay ops [first, last) through a hipGraph.  Replay 1 of a range runs eagerly (module loads, one-time hipFuncSetAttribute calls and the
-// LDS-size opt-ins happen there, outside any capture); replay 2 is recorded on a private non-blocking stream in RELAXED capture mode
-// (other threads may keep calling HIP: pipeline slots) and instantiated; the recording itself executes nothing, so the graph is launched
-// for replay 2 as well.  Every later replay is one hipGraphLaunch on the caller's stream.  The graph bakes in the descriptors' device
-// pointers: the buffers of a plan live as long as its program does (unidepth_amd _Plan), which is the contract of ud_program_run too.
-int ud_program_run_graph(UdProgram* p, int first, int last, void* stream) {
-  if (!p || first < 0 || last > (int)p->ops.size() || first > last) { ud_set_error("ud_program_run_graph: bad range"); return UD_ERR_BAD_ARG; }
-  if (first == last) return UD_OK;
-  int dev = -1;
-  if (hipGetDevice(&dev) != hipSuccess) { ud_set_error("ud_program_run_graph: hipGetDevice failed"); return UD_ERR_LAUNCH; }
-  UdGraph& g = p->graphs[std::make_pair(first, last)];
-  if (g.exec && g.device != dev) { (void)hipGraphExecDestroy(g.exec); g = UdGraph(); }
-  if (!g.exec) {
-    if (g.runs++ == 0) return ud_program_run(p, first, last, stream);
-    hipStream_t cs = nullptr;
-    if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { ud_set_error("ud_program_run_graph: cannot create the capture stream"); return UD_ERR_LAUNCH; }
-    hipGraph_t graph = nullptr;
-    int rc = UD_OK;
-    if (hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed) != hipSuccess) {
-      ud_set_error("ud_program_run_graph: hipStreamBeginCapture failed");
-      rc = UD_ERR_LAUNCH;
-    } else {
-      rc = ud_program_run(p, first, last, cs);
-      const hipError_t e = hipStreamEndCapture(cs, &graph);          // always end the capture, also after a failed op
-      if (rc == UD_OK && (e != hipSuccess || !graph)) { ud_set_error("ud_program_run_graph: hipStreamEndCapture failed"); rc = UD_ERR_LAUNCH; }
-    }
-    if (rc == UD_OK && hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-      g.exec = nullptr;
-      ud_set_error("ud_program_run_graph: hipGraphInstantiate failed");
-      rc = UD_ERR_LAUNCH;
-    }
-    if (graph) (void)hipGraphDestroy(graph);
-    (void)hipStreamDestroy(cs);
-    (void)hipGetLastError();
-    if (rc != UD_OK) { g.runs = 0; return rc; }
-    g.device = dev;
-  }
-  if (hipGraphLaunch(g.exec, (hipStream_t)stream) != hipSuccess) { ud_set_error("ud_program_run_graph: hipGraphLaunch failed"); return UD_ERR_LAUNCH; }
   return UD_OK;
 }
-int ud_program_graph_count(const UdProgram* p) {
-  int n = 0;
-  if (p) for (const auto& kv : p->graphs) n += kv.second.exec != nullptr;
-  return n;
-}
-void ud_program_drop_graphs(UdProgram* p) { if (p) drop_graphs(p); }
 }

@@ -229,34 +229,42 @@ def infer_mixed(model, images: List[torch.Tensor], cameras: Optional[List[Option
         # plans); the previous bound comes back when the call returns (_restore_plans) and the LRU evicts down to it
         sigs = {(len(idx), s, bool(cameras is not None and any(cameras[i] is not None for i in idx))) for (s, idx), r in zip(micro, owner) if r == rank}
         cap = int(os.environ.get("UNIDEPTH_MIXED_MAX_PLANS", "24"))
-        model.reserve_plans(min(len(sigs) * max(1, inflight) + 2, max(cap, prev_max_plans or 0)))
+        need = len(sigs) * max(1, inflight) + 2
+        if need > max(cap, prev_max_plans or 0):
+            import warnings
+            warnings.warn(f"infer_mixed: this rank cycles through {need} (micro-batch, shape, slot) plans but the cache is capped at "
+                          f"{max(cap, prev_max_plans or 0)} (UNIDEPTH_MIXED_MAX_PLANS): plans will be evicted and rebuilt (a device synchronise + "
+                          "a multi-GB allocation each) -- raise the cap or pass fewer distinct shapes per call", RuntimeWarning, stacklevel=2)
+        model.reserve_plans(min(need, max(cap, prev_max_plans or 0)))
 
     def _restore_plans():
         if prev_max_plans is not None and hasattr(model, "trim_plans"):
             model.trim_plans(prev_max_plans)
-    submitted = []
-    for (s, idx), r in zip(micro, owner):
-        if r != rank:
-            continue
-        rgb = torch.stack([images[i] for i in idx])
-        cam = None
-        if cameras is not None and len(idx) == 1 and idx[0] in solo:
-            cam = cameras[idx[0]]
-        elif cameras is not None and any(isinstance(cameras[i], torch.Tensor) for i in idx):
-            assert all(isinstance(cameras[i], torch.Tensor) for i in idx), "plan_mixed keeps K and camera-less images apart"
-            cam = torch.stack([cameras[i].reshape(3, 3) for i in idx])
-        if pipe is not None:
-            out = pipe.submit(rgb, cam, **kw)
-            submitted.append(out)
-        else:
-            out = model.infer(rgb, cam, **kw)
-        mine.setdefault(s, []).append((idx, {k: out[k] for k in keys}))
-        if not distributed:
-            for b, i in enumerate(idx):
-                results[i] = {k: out[k][b] for k in keys}
-    for out in submitted:                              # only now: a wait on the caller's stream would order later submissions behind it
-        pipe.wait(out)
-    _restore_plans()
+    try:
+        submitted = []
+        for (s, idx), r in zip(micro, owner):
+            if r != rank:
+                continue
+            rgb = torch.stack([images[i] for i in idx])
+            cam = None
+            if cameras is not None and len(idx) == 1 and idx[0] in solo:
+                cam = cameras[idx[0]]
+            elif cameras is not None and any(isinstance(cameras[i], torch.Tensor) for i in idx):
+                assert all(isinstance(cameras[i], torch.Tensor) for i in idx), "plan_mixed keeps K and camera-less images apart"
+                cam = torch.stack([cameras[i].reshape(3, 3) for i in idx])
+            if pipe is not None:
+                out = pipe.submit(rgb, cam, **kw)
+                submitted.append(out)
+            else:
+                out = model.infer(rgb, cam, **kw)
+            mine.setdefault(s, []).append((idx, {k: out[k] for k in keys}))
+            if not distributed:
+                for b, i in enumerate(idx):
+                    results[i] = {k: out[k][b] for k in keys}
+        for out in submitted:                              # only now: a wait on the caller's stream would order later submissions behind it
+            pipe.wait(out)
+    finally:
+        _restore_plans()               # also when infer() or the pipeline raised: the enlarged bound must not pin multi-GB plans
     if not distributed:
         return results  # type: ignore[return-value]
     for s in sorted({m[0] for m in micro}):

@@ -52,6 +52,8 @@ class EngineModule(torch.nn.Module, _HubMixin):
         for a in args:
             if isinstance(a, torch.dtype):
                 dtype = a
+            elif isinstance(a, bool):
+                continue                                    # positional non_blocking (nn.Module.to(device, dtype, non_blocking)): nothing to do
             elif isinstance(a, (str, torch.device, int)):
                 device = a
             elif isinstance(a, torch.Tensor):

@@ -111,9 +111,8 @@ class Program:
         tiles = -(-kw["M"] // 128) * -(-n // 128)
         if (g == 1 and kw.get("amode", 0) == UD_A_DENSE and kw.get("epi", 0) in (UD_EPI_F16, UD_EPI_F32) and tiles <= 128
                 and kw["K"] >= 1024 and kw["K"] % 128 == 0 and "splitk_ws" not in kw):
-            # small problems (small batches): see UdGemm.splitk_ws in include/unidepth_hip.h.  One workspace per BRANCH of the program: launches
-            # of the side branch (Program.side) run concurrently with the caller's stream and must not share partial-sum storage with it
-            key = 1 if getattr(self, "_in_side", False) else 0
+            # small problems (small batches): see UdGemm.splitk_ws in include/unidepth_hip.h; one workspace per program
+            key = 0
             if not isinstance(self._splitk, dict):
                 self._splitk = {}
             if key not in self._splitk:
@@ -131,12 +130,11 @@ class Program:
             cls = "gemm_kernel<Cfg<128, 64, 64>, %d, %d, 4, %s>" % (epi, amode, "true" if pick == 7 else "false")
         elif pick <= 4:
             # 7th template argument: the 3-deep weight ring of the 192-row tile list (csrc/gemm.hip launch256: dense A, not grouped, K >= 128)
-            w3 = (pick == 3 and amode == UD_A_DENSE and grp == "false" and kw["K"] >= 128 and kw.get("tile_hint", 0) != 9
-                  and os.environ.get("UD_GEMM_W3", "1")[:1] != "0")
+            w3 = pick == 3 and amode == UD_A_DENSE and grp == "false" and kw["K"] >= 128 and kw.get("tile_hint", 0) != 9
             cls = "gemm256_kernel<%d, %d, %d, false, %s, %s, %s>" % (pick, epi, amode, lnc, grp, "true" if w3 else "false")
         elif pick == 8:     # row-balanced schedule of the 256-column kernel
             cls = "gemm256_kernel<4, %d, %d, true, %s, false, false>" % (epi, amode, lnc)
-        elif amode == 3 and kw.get("Cin", 0) == 64 and epi == UD_EPI_HEAD and os.environ.get("UD_HEAD_REGW", "1")[:1] != "0":
+        elif amode == 3 and kw.get("Cin", 0) == 64 and epi == UD_EPI_HEAD:
             cls = "conv_head_regw_kernel"                       # head conv with its weights in registers
         else:
             cls = "conv_tile_kernel<%d, %d, %s, %s>" % (n // 16, epi, "true" if amode >= 2 else "false", "true" if amode == 3 else "false")
@@ -247,21 +245,7 @@ class Program:
         self.meta.append(("v1." + tag, tag, 0.0, 0.0))
         return check(lib.ud_program_add_v1_op(self.h, C.byref(v1_desc(kind, a, b, c, out, out2, i, f))))
 
-    def side(self, mode):
-        """Side branch marker (include/unidepth_hip.h ud_program_add_side): 0 begin, 1 end, 2 join."""
-        self.meta.append(("side", ("side.begin", "side.end", "side.join")[mode], 0.0, 0.0))
-        self._in_side = mode == 0
-        return check(lib.ud_program_add_side(self.h, int(mode)))
-
-    def run(self, first=0, last=None, stream=None, graph=False):
-        """Replay ops [first, last) on the current (or given) stream; graph=True: through ud_program_run_graph (eager the first time the
-        range is seen, recorded into a hipGraph the second, one hipGraphLaunch from then on; same kernels, same order, same bits)."""
+    def run(self, first=0, last=None, stream=None):
+        """Replay ops [first, last) on the current (or given) stream."""
         last = len(self) if last is None else last
-        fn = lib.ud_program_run_graph if graph else lib.ud_program_run
-        check(fn(self.h, first, last, cur_stream() if stream is None else stream), "ud_program_run_graph" if graph else "ud_program_run")
-
-    def graph_count(self):
-        return int(lib.ud_program_graph_count(self.h))
-
-    def drop_graphs(self):
-        lib.ud_program_drop_graphs(self.h)
+        check(lib.ud_program_run(self.h, first, last, cur_stream() if stream is None else stream), "ud_program_run")

@@ -27,11 +27,8 @@ class InferPipeline:
         assert depth >= 1
         self.model = model
         self.depth = depth
-        # UNIDEPTH_PIPE_PRIO=1 (A/B switch): the first stream at high priority -- its kernels dispatch first and the other calls only fill
-        # what it leaves idle, instead of the two queues alternating launch by launch
-        import os
-        prio = os.environ.get("UNIDEPTH_PIPE_PRIO", "0") == "1"
-        self.streams = [torch.cuda.Stream(device=model.device, priority=(-1 if (prio and i == 0) else 0)) for i in range(depth)]
+        # (round 4 A/B: the first stream at high priority measured 602.8 against 603.9 images/s -- equal priorities)
+        self.streams = [torch.cuda.Stream(device=model.device) for _ in range(depth)]
         self._events: List[Optional[torch.cuda.Event]] = [None] * depth
         self._n = 0
         self._pending: Dict[int, torch.cuda.Event] = {}

@@ -56,6 +56,12 @@ WSPLIT_CONVNEXT_FC1 = _WSPLIT_ENV == "all"
 ASPLIT = WSPLIT and os.environ.get("UNIDEPTH_V1_ASPLIT", "1") != "0"
 
 
+def _split_mode() -> str:
+    """The fp16 operand layout in force (module-level switches read once at import): packed weights carry it, plan builders assert it, so weights
+    packed under one setting are never multiplied under another (e.g. a [hi | lo] weight against a single-term K)."""
+    return f"w{int(WSPLIT)}.fc1{int(WSPLIT_CONVNEXT_FC1)}.a{int(ASPLIT)}"
+
+
 def _padk16(w: torch.Tensor, split: Optional[bool] = None) -> torch.Tensor:
     """[N, K] fp32 -> fp16 GEMM operand, K zero-padded to a multiple of 64; split: [hi | lo] halves of the padded width each."""
     split = WSPLIT if split is None else split
@@ -136,6 +142,7 @@ def pack_convnext(config: dict, sd: dict, device) -> dict:
             p16(f"blk.{s}.{i}.fc1.w", w1 * g[None, :], split=WSPLIT_CONVNEXT_FC1); p32(f"blk.{s}.{i}.fc1.b", b1 + w1 @ b)
             ls = f[r + "gamma"]
             p16(f"blk.{s}.{i}.fc2.w", f[r + "mlp.fc2.weight"] * ls[:, None]); p32(f"blk.{s}.{i}.fc2.b", f[r + "mlp.fc2.bias"] * ls)
+    w["meta.split"] = _split_mode()                    # the operand layout these weights were packed for (checked by the plan builders)
     return w
 
 
@@ -163,6 +170,7 @@ def pack_vit(config: dict, sd: dict, device) -> dict:
     pack_vit_blocks(f, a["D"], a["depth"], a["heads"], put16, put32)
     w["host.pos_embed"] = f["pixel_encoder.pos_embed"]
     w["host.cls_token"] = f["pixel_encoder.cls_token"].reshape(-1)
+    w["meta.split"] = _split_mode()                    # the operand layout these weights were packed for (checked by the plan builders)
     return w
 
 
@@ -318,6 +326,7 @@ def pack_v1_decoder(config: dict, sd: dict, device) -> dict:
         rows[0] = r0
         bias = torch.zeros(4); bias[0] = f[f"{dl}{nm}.bias"][0]
         w[f"{nm}.w"] = _padk16(rows, split=False).to(device); p32(f"{nm}.b", bias)
+    w["meta.split"] = _split_mode()                    # the operand layout these weights were packed for (checked by the plan builders)
     return w
 
 
@@ -481,7 +490,6 @@ class UniDepthV1(EngineModule):
         self._w = None
         self._plans = OrderedDict()                 # LRU: a plan owns all activation buffers of its signature (same policy as UniDepthV2)
         self.max_plans = max(1, int(os.environ.get("UNIDEPTH_MAX_PLANS", "4")))
-        self.use_graph = os.environ.get("UNIDEPTH_GRAPH", "0") == "1"      # infer(): the plan's program as one hipGraph launch (see UniDepthV2.use_graph)
 
     # ---- checkpoint I/O (same HF layout as V2) ----
     @classmethod
@@ -673,7 +681,7 @@ class UniDepthV1(EngineModule):
                 kinv[:, 0, 0], kinv[:, 1, 1], kinv[:, 2, 2] = 1.0 / gtK[:, 0, 0], 1.0 / gtK[:, 1, 1], 1.0
                 kinv[:, 0, 2], kinv[:, 1, 2] = -gtK[:, 0, 2] / gtK[:, 0, 0], -gtK[:, 1, 2] / gtK[:, 1, 1]
                 plan.Kinv_gt.copy_(kinv.reshape(n_gt, 9))
-            plan.prog.run(graph=self.use_graph)
+            plan.prog.run()
             dev = self._device
             points = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
             depth = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
@@ -750,6 +758,7 @@ class _FullPlan:
         from . import _lib as L
         from .ops import UD_A_CONV3_ZERO, UD_ACT_NONE, UD_EPI_QKV
         w, dev = model._w, model.device
+        assert w.get("meta.split") == _split_mode(), f"weights packed for operand layout {w.get('meta.split')!r}, plans built for {_split_mode()!r}"
         f16, f32 = torch.float16, torch.float32
         C = model.config["model"]["pixel_decoder"]["hidden_dim"]
         heads = model.config["model"]["num_heads"]

@@ -134,14 +134,10 @@ class _Plan:
         # Q|K and the attention output live inside `hid`: between fc2 of block i and fc1 of block i+1 the hidden activations are dead, and
         # q|k / ao are dead while fc1 / fc2 run.  The block's working set drops from 272 MB to 204 MB at bs = 8 (ViT-L) -- under the 256 MB
         # Infinity Cache, so what one launch writes the next one reads on-die (tools/r4_insitu.py: the step's launches ran 36 us per block
-        # behind the same launches on warm operands).  V^T keeps its own buffer: its pad columns must stay zero.  UNIDEPTH_ALIAS=0: separate.
-        if os.environ.get("UNIDEPTH_ALIAS", "1") != "0":
-            flat = hid.view(-1)
-            qk = flat[: M * 2 * D].view(M, 2 * D)
-            ao = flat[M * 2 * D: M * 3 * D].view(M, D)
-        else:
-            qk = z(M, 2 * D)
-            ao = z(M, D)
+        # behind the same launches on warm operands).  V^T keeps its own buffer: its pad columns must stay zero.
+        flat = hid.view(-1)
+        qk = flat[: M * 2 * D].view(M, 2 * D)
+        ao = flat[M * 2 * D: M * 3 * D].view(M, D)
         featn_all = z(4, B * hwp, D)                                  # stacked: the 4 levels are processed by grouped launches
         featn = [featn_all[j] for j in range(4)]
         clsn = [z(_rup(B, 8), D, dtype=f32) for _ in range(4)]       # final-LN'd cls tokens stay fp32: they feed the fp32 camera head
@@ -167,10 +163,10 @@ class _Plan:
         # ... and where the producers (proj / fc2, N = D) run about one tile per workgroup: measured on one box (gpurun_out r3c12), bs = 8:
         # +2.5 %, 644x966 bs = 4 (264 tiles): +0.3 %, bs = 16 (460 tiles): +-0, bs = 32 (916 tiles): -1.2 % -- with several tiles per
         # workgroup the per-tile drain + ticket of the in-kernel reduction sits inside the tile stream, and the LayerNorm kernels it
-        # replaces are efficient HBM streams at that size.  UNIDEPTH_LN_FOLD=1 forces it on, =0 off.
+        # replaces are efficient HBM streams at that size.  model.ln_fold_force (tests): True forces it on, False off.
         prod_tiles = -(-M // 192) * -(-D // 256)
-        env = os.environ.get("UNIDEPTH_LN_FOLD", "")
-        fold = big and env != "0" and (prod_tiles <= 320 or env == "1")
+        force = getattr(model, "ln_fold_force", None)
+        fold = big and force is not False and (prod_tiles <= 320 or force is True)
         self.ln_fold = fold
         self.row_tickets = rticket          # tests: every completed launch leaves its ticket set at zero
         lnc = dict(row_stats_in=rstats, ln_slabs=slabs, ln_D=D, ln_eps=1e-6)
@@ -224,28 +220,20 @@ class _Plan:
         Md = B * hwp
         feat_all = z(4, Md, C, dtype=f32)
         ct = z(B * 4, C, dtype=f32)
-        # Two independent launch chains start here: the CAMERA branch (4 token adapters, the fp32 camera head, intrinsics, rays, ray embedding:
-        # ~30 dependent launches of a few workgroups each, 0.35-0.45 ms when run alone) and the FEATURE branch (the grouped adapter GEMM, its
-        # LayerNorm, the q projection of the four cross-attention blocks: 0.16 ms of full-chip launches) -- they meet at the K / V projection
-        # of the ray embedding.  The camera branch is recorded as the program's side branch (ud_program_add_side: a second HIP stream, fork /
-        # join by events) with UNIDEPTH_SIDE=1.  Disjoint buffers: same bits (test_side_branch_bit_identical).  MEASURED (profiles/
-        # r04_side_branch_ab.txt, three interleaved rounds on one box): one-call p50 14.22 / 14.20 / 14.22 ms on one stream against 14.25 / 14.24 /
-        # 14.25 ms with the branch, 604.6-605.5 against 604.2-604.8 images/s two calls in flight -- nothing: the 0.16 ms of feature-branch launches
-        # fill every CU's LDS (144 KB per workgroup), the camera kernels wait for them to drain instead of running beside them, and the fork /
-        # join events cost what little overlap is left.  Off by default; the mechanism stays in the ABI.
-        side = os.environ.get("UNIDEPTH_SIDE", "0") == "1"
+        # The camera branch (4 token adapters, the fp32 camera head, intrinsics, rays, ray embedding: ~30 dependent launches of a few workgroups
+        # each, 0.35-0.45 ms) and the feature branch (grouped adapter GEMM, LayerNorm, the q projection of the four cross-attention blocks) are
+        # independent until the K / V projection of the ray embedding.  Round 4 ran them on two streams (fork / join by events): same bits,
+        # one-call p50 14.22 ms on one stream against 14.25 ms forked (profiles/r04_side_branch_ab.txt) -- the feature-branch launches fill every
+        # CU's LDS, the camera kernels wait for them instead of running beside them.  One stream; the mechanism was removed in round 5.
         self.dec_first = self.enc_last
 
         def feature_branch_head():
             P.gemm(A=featn_all, W=w["dec.adapterg.w"], bias=w["dec.adapterg.b"], out=feat_all, M=Md, N=C, K=D, lda=D, ldw=D, ldc=C,
                    epi=UD_EPI_F32, groups=4, gA=Md * D, gW=C * D, gBias=C, gOut=Md * C, tag="dec.adapters(x4)",
-                   **({"tile_hint": 1} if os.environ.get("UNIDEPTH_GRP_BIG", "1") == "0" else {}))
+                   )
             for j in range(4):
                 tap(f"input_adapter.{j}", lambda j=j: feat_all[j].view(B, hwp, C)[:, :hw].clone())
-        if side:
-            P.side(0)
-        else:
-            feature_branch_head()
+        feature_branch_head()
         for j in range(4):
             P.linear_f32(x=clsn[j], W=w[f"dec.camadapter.{j}.w"], bias=w[f"dec.camadapter.{j}.b"], out=ct.data_ptr() + j * C * 4,
                          M=B, N=C, K=D, ldx=D, ldw=D, ldc=4 * C, tag="cam.adapter")
@@ -320,15 +308,10 @@ class _Plan:
         fn = z(4, Md, C); qd = z(4, Md, HC); kd = z(4, Mk, HC); vtd = z(4, nb, Hd, 64, hwkp); aod = z(4, Md, HC); hidd = z(4, Md, 4 * C)
         c16_all = z(4, Md, C)
         c16 = [c16_all[j] for j in range(4)]
-        G4 = dict(groups=4, **({"tile_hint": 1} if os.environ.get("UNIDEPTH_GRP_BIG", "1") == "0" else {}))      # A/B switch: 128-row blockIdx.z form
-        if side:
-            P.side(1)                                    # camera branch recorded; what follows runs beside it on the caller's stream
-            feature_branch_head()
+        G4 = dict(groups=4)
         ln(feat_all, fn, 4 * Md)
         P.gemm(A=fn, W=w["dhg.q.w"], bias=w["dhg.q.b"], out=qd, M=Md, N=HC, K=C, lda=C, ldw=C, ldc=HC, epi=UD_EPI_F16,
                gA=Md * C, gW=HC * C, gBias=HC, gOut=Md * HC, tag="dh.q(x4)", **G4)
-        if side:
-            P.side(2)                                    # the K / V projection below reads the ray embedding of the camera branch
         P.gemm(A=emb, W=w["dhg.kv.w"], bias=w["dhg.kv.b"], out=kd, out2=vtd, M=Mk, N=2 * HC, K=C, lda=C, ldw=C, ldc=HC, epi=UD_EPI_QKV,
                vsplit=HC, tok_per_img=hwp, kv_ld=hwkp, heads_v=Hd, gA=0, gW=2 * HC * C, gBias=2 * HC, gOut=Mk * HC,
                gOut2=nb * Hd * 64 * hwkp, tag="dh.kv(x4)", **G4)
@@ -352,10 +335,10 @@ class _Plan:
         P.nhwc_to_nchw(lat, self.depth_features, B, hw, C, C, hwp)
         gh, gw, rows_img = h, wg, hwp
         xh = None
-        # The x2 up-sampling behind a stage's 1x1 conv feeds only the next stage's ConvTranspose accumulate: with UNIDEPTH_UPFUSE (default on) that
+        # The x2 up-sampling behind a stage's 1x1 conv feeds only the next stage's ConvTranspose accumulate: the ConvTranspose
         # accumulate interpolates the 1x1 conv's output itself (UdGemm.up_src) -- the up-sampled fp32 map is never written and read back
-        # (45 + 90 MB at bs = 8, two launches).  =0: ud_upsample2x_nhwc + plain read-modify-write as before (A/B).
-        upfuse = os.environ.get("UNIDEPTH_UPFUSE", "1") != "0"
+        # (45 + 90 MB at bs = 8, two launches).
+        upfuse = True
         pending_up = {}
         for i in range(3):
             cur, outd = meta["chans"][i]
@@ -452,7 +435,6 @@ class UniDepthV2(EngineModule):
         self._pos_cache: dict = {}
         # True: a plan's launch program is replayed as ONE hipGraph launch (recorded on the second call of a signature).  For the launch-bound
         # small-batch calls (bs = 1: ~280 kernels of 2-10 us each); at bs = 8 the stream is never idle and eager replay is as fast.
-        self.use_graph = os.environ.get("UNIDEPTH_GRAPH", "0") == "1"
 
     # ---- checkpoint I/O (HF mixin layout: config.json + model.safetensors / pytorch_model.bin) ----
     @classmethod
@@ -625,15 +607,14 @@ class UniDepthV2(EngineModule):
                 Kn[:, 1, 2] += pt
                 Kn[:, :2, :] *= plan.rf
                 plan.kinv_gt.copy_(torch.inverse(Kn).reshape(-1, 9))
-            self._run(plan, 0, len(plan.prog), taps, graph=self.use_graph)
+            self._run(plan, 0, len(plan.prog), taps)
             return self._collect(plan, B)
 
     @staticmethod
-    def _run(plan: _Plan, first: int, last: int, taps=None, graph: bool = False):
-        """Replay ops [first, last) of the plan; with `taps` = (dict, names or None) the replay stops at every tap point in range.
-        graph (model.use_graph): the whole range as one hipGraph launch from its third replay on (csrc/program.cpp ud_program_run_graph)."""
+    def _run(plan: _Plan, first: int, last: int, taps=None):
+        """Replay ops [first, last) of the plan; with `taps` = (dict, names or None) the replay stops at every tap point in range."""
         if taps is None:
-            plan.prog.run(first, last, graph=graph)
+            plan.prog.run(first, last)
             return
         store, names = taps
         pos = first
