@@ -49,3 +49,33 @@ def test_camera_model_arithmetic_matches_oracle(host_lib, name, model, params):
     assert np.allclose(np.linalg.norm(rays, axis=0), 1.0, atol=1e-6)
     if model != 6 and any(abs(v) > 0 for v in params[4:10]):
         assert 1 <= steps < 10                                   # the image-wide exit fired before the iteration cap
+
+
+def test_batch_camera_wrapper_host_logic():
+    """unidepth_amd.cameras.BatchCamera (the reference's multi-camera wrapper, utils/camera.py:1145-1308): members are matched by class name,
+    nested lists flatten, one closed-form class collapses to the batched object the ray kernel takes, mixed / iterative models stay a list."""
+    from unidepth_amd import cameras as C
+
+    class Pinhole:                                             # stand-ins for the reference's classes: matched by class name + .params
+        def __init__(self, p):
+            self.params = torch.tensor([p])
+
+    class EUCM(Pinhole):
+        pass
+
+    class OPENCV(Pinhole):
+        pass
+
+    class BatchCamera:
+        def __init__(self, cams):
+            self.cameras = cams
+    pin = [Pinhole([100.0 + i, 101.0, 50.0, 40.0]) for i in range(3)]
+    b = C.as_camera(BatchCamera(pin))
+    assert isinstance(b, C.BatchCamera) and b.gt_modes == (C.GT_PINHOLE,) * 3
+    u = b.uniform()
+    assert isinstance(u, C.Pinhole) and u.params.shape == (3, 4) and float(u.K[2, 0, 0]) == 102.0
+    mixed = C.as_camera(BatchCamera([[pin[0]], [EUCM([90.0, 91.0, 50.0, 40.0, 0.6, 1.1]), OPENCV([80.0, 81.0, 50.0, 40.0] + [0.0] * 12)]]))
+    assert mixed.gt_modes == (C.GT_PINHOLE, C.GT_EUCM, C.GT_OPENCV) and mixed.uniform() is None and mixed.params.shape == (3, 16)
+    assert isinstance(C.as_camera(BatchCamera([pin[1]])), C.Pinhole)              # a wrapper around one camera is that camera
+    with pytest.raises(AssertionError):
+        C.BatchCamera([])

@@ -253,6 +253,41 @@ def test_bicubic_interpolation_mode(engine_cls):
         model.infer(rgb.cuda())
 
 
+def test_batch_camera_one_model_per_image(engine_cls):
+    """A BatchCamera with one camera PER IMAGE, of different models (the reference's wrapper: unproject concatenates every member's own
+    unproject, utils/camera.py:1166-1171; entered at unidepthv2.py:267-274): every image must get exactly the rays a single-camera call with its
+    camera produces, and a depth within the cross-batch-size tolerance of that call; a wrapper whose members share one closed-form class
+    takes the batched kernel and must agree with the [B,3,3] K tensor form bit for bit."""
+    from unidepth_amd import cameras as C
+    cfg = synth.load_config("vits14")
+    sd = synth.make_synthetic_checkpoint(cfg, 19)
+    model = engine_cls(cfg).load_state_dict(sd).to("cuda").eval()
+    g = torch.Generator().manual_seed(4)
+    H, W = 300, 400
+    rgb = torch.randint(0, 256, (4, 3, H, W), dtype=torch.uint8, generator=g).cuda()
+    cams = [C.Pinhole(params=torch.tensor([[310.0, 305.0, 200.0, 150.0]])),
+            C.EUCM(torch.tensor([[250.0, 251.0, 198.0, 152.0, 0.55, 1.05]])),
+            C.OPENCV(torch.tensor([[300.0, 302.0, 201.0, 149.0, -0.2, 0.05, -0.01, 0, 0, 0, 1e-3, -1e-3, 0, 0, 0, 0]])),
+            C.MEI(torch.tensor([[260.0, 262.0, 199.0, 151.0, -0.1, 0.02, 1e-3, -1e-3, 0.9]]))]
+    out = model.infer(rgb, C.BatchCamera(cams))
+    torch.cuda.synchronize()
+    assert out["rays"].shape == (4, 3, H, W)
+    for i, c in enumerate(cams):
+        one = model.infer(rgb[i:i + 1], c)
+        torch.cuda.synchronize()
+        assert torch.equal(out["rays"][i], one["rays"][0]), i
+        arel = ((out["depth"][i] - one["depth"][0]).abs() / one["depth"][0]).mean().item()
+        assert arel < 2e-3, (i, arel)                                   # bs = 4 and bs = 1 plans differ in GEMM tile shapes, not in the camera
+    pins = [C.Pinhole(params=torch.tensor([[300.0 + 5 * i, 301.0, 200.0, 150.0]])) for i in range(4)]
+    a = model.infer(rgb, C.BatchCamera(pins))
+    b = model.infer(rgb, torch.cat([p.K for p in pins]).cuda())
+    torch.cuda.synchronize()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    with pytest.raises(AssertionError):
+        model.infer(rgb[:3], C.BatchCamera(cams))                       # four cameras, three images
+
+
 def test_camera_batch_mismatch_is_rejected(engine_cls):
     cfg = synth.load_config("vits14")
     sd = synth.make_synthetic_checkpoint(cfg, 123)

@@ -93,4 +93,13 @@ done
 cat $O/suite.txt $O/bench.txt; tail -3 $O/err.txt
 }
 
+# round 5, GPU call 7: the GPU suite again (INTEGRATION.md snippet fixed; BatchCamera with one model per image), without -x
+call7() {
+O=gpurun_out/r5c7 && mkdir -p $O
+t0=$(date +%s)
+timeout 1800 python -m pytest tests -q -m gpu --deselect tests/test_parity_sweep_gpu.py 2>&1 | grep -v "^$\|amdgpu.ids" | tail -25 > $O/suite.txt
+echo "[suite done $(( $(date +%s) - t0 )) s]" >> $O/suite.txt
+cat $O/suite.txt
+}
+
 "$@"

@@ -109,6 +109,40 @@ class MEI(_SingleCamera):
     n_params = 9
 
 
+class BatchCamera(Camera):
+    """Several cameras, one per image of the batch, possibly of DIFFERENT models (the reference's wrapper utils/camera.py:1145-1308: its
+    unproject() concatenates every member's own unproject, :1166-1171; infer() crops / resizes each member, :1173-1186).  Members are
+    single-camera objects of the classes above.  uniform(): the same cameras as ONE batched object when every member is of one closed-form
+    class (Pinhole / EUCM / Spherical), which the batched ray kernel takes; None otherwise (the plan then records one ray launch per image)."""
+    gt_mode = -1
+
+    def __init__(self, cameras):
+        self.cameras = list(cameras)
+        assert self.cameras and all(isinstance(c, Camera) and not isinstance(c, BatchCamera) and c.params.shape[0] == 1 for c in self.cameras), \
+            "BatchCamera: a non-empty list of single cameras"
+        self.params = torch.zeros(len(self.cameras), 16)
+        for i, c in enumerate(self.cameras):
+            self.params[i, : c.params.shape[1]] = c.params[0]
+
+    @property
+    def gt_modes(self):
+        return tuple(c.gt_mode for c in self.cameras)
+
+    def uniform(self):
+        cls = type(self.cameras[0])
+        if cls in (Pinhole, EUCM, Spherical) and all(type(c) is cls for c in self.cameras):
+            p = torch.cat([c.params for c in self.cameras], dim=0)
+            return Pinhole(params=p) if cls is Pinhole else cls(p)
+        return None
+
+
+def _flatten(cams):
+    out = []
+    for c in cams:
+        out.extend(_flatten(c) if isinstance(c, (list, tuple)) else [c])
+    return out
+
+
 _BY_NAME = {"Pinhole": Pinhole, "EUCM": EUCM, "Spherical": Spherical, "OPENCV": OPENCV, "Fisheye624": Fisheye624, "MEI": MEI}
 
 
@@ -118,9 +152,8 @@ def as_camera(obj) -> Camera:
         return obj
     name = type(obj).__name__
     if name == "BatchCamera" and getattr(obj, "cameras", None):
-        if len(obj.cameras) != 1:
-            raise NotImplementedError("BatchCamera with several cameras: pass a [B,3,3] K tensor, or one camera object per infer() call")
-        return as_camera(obj.cameras[0])
+        cams = [as_camera(c) for c in _flatten(obj.cameras)]
+        return cams[0] if len(cams) == 1 else BatchCamera(cams)
     cls = _BY_NAME.get(name)
     if cls is None or not hasattr(obj, "params"):
         raise NotImplementedError(f"camera model '{name}' is not implemented ({', '.join(_BY_NAME)} are)")

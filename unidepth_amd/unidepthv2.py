@@ -25,7 +25,7 @@ import torch
 from . import ops
 from .ops import (UD_A_CONV3_REFLECT, UD_A_CONV3_REFLECT_UP, UD_A_CONV3_ZERO, UD_ACT_GELU, UD_ACT_LRELU, UD_ACT_NONE, UD_EPI_D2S, UD_EPI_F16,
                   UD_EPI_F32, UD_EPI_HEAD, UD_EPI_QKV)
-from .cameras import GT_OPENCV, GT_PINHOLE, as_camera
+from .cameras import GT_OPENCV, GT_PINHOLE, BatchCamera, as_camera
 
 GT_GIVEN_RAYS = 15          # plan tag: the ray map itself is supplied (pixel_decoder seam, decoder.py:400 `rays_gt`)
 from .module import EngineModule
@@ -287,6 +287,15 @@ class _Plan:
         self.rays = z(nb, 3, Hn, Wn, dtype=f32)
         if cam_nb and gt_mode == GT_GIVEN_RAYS:                             # pixel_decoder(inputs={"rays": ...}): the caller fills self.rays
             pass
+        elif cam_nb and isinstance(gt_mode, tuple):                         # BatchCamera of mixed / iterative models: image i has its own model
+            # (utils/camera.py:1166-1171: BatchCamera.unproject concatenates every member's own unproject)
+            self.kinv_gt = z(nb, 16, dtype=f32)
+            self.cam_scratch = z(4 * Hn * Wn + 16, dtype=f32)
+            for i, gm in enumerate(gt_mode):
+                if gm >= GT_OPENCV:
+                    P.rays_camera(self.kinv_gt[i:i + 1], self.rays[i:i + 1], self.cam_scratch, Hn, Wn, gm)
+                else:
+                    P.rays(self.kinv_gt[i:i + 1], self.rays[i:i + 1], 1, Hn, Wn, gm)
         elif cam_nb and gt_mode >= GT_OPENCV:                               # iterative models: OPENCV, Fisheye624, MEI (one camera)
             self.kinv_gt = z(1, 16, dtype=f32)
             self.cam_scratch = z(4 * Hn * Wn + 16, dtype=f32)
@@ -582,6 +591,8 @@ class UniDepthV2(EngineModule):
                 Kc = camera
             else:
                 cam_obj = as_camera(camera)                        # reference-class objects are matched by class name
+                if isinstance(cam_obj, BatchCamera) and cam_obj.uniform() is not None:
+                    cam_obj = cam_obj.uniform()                    # one closed-form model for every image: the batched ray kernel
                 if cam_obj.gt_mode == GT_PINHOLE:
                     Kc, cam_obj = cam_obj.K, None
             if Kc is not None:
@@ -593,9 +604,27 @@ class UniDepthV2(EngineModule):
             # one camera broadcasts over the batch, otherwise one per image (the reference fails with a shape error here too)
             assert cam_nb in (0, 1, B), f"camera batch {cam_nb} does not match the image batch {B} (one camera, or one per image)"
             gt_mode = 0 if camera is None else (GT_PINHOLE if Kc is not None else cam_obj.gt_mode)
+            mixed = isinstance(cam_obj, BatchCamera)               # one camera per image, models differ (or are iterative): one ray launch per image
+            if mixed:
+                assert cam_nb == B, f"BatchCamera of {cam_nb} cameras for a batch of {B} images (one per image)"
+                gt_mode = cam_obj.gt_modes
             plan = self._plan(B, H, W, cam_nb, is_u8, bool(normalize), int(slot), gt_mode)
             plan.rgb.copy_(rgb if is_u8 else rgb.float(), non_blocking=True)
-            if cam_obj is not None:
+            if mixed:
+                buf = torch.zeros(B, 16)
+                pl, _, pt, _ = plan.paddings
+                for i, c in enumerate(cam_obj.cameras):
+                    if c.gt_mode == GT_PINHOLE:                    # camera.crop(-pad) then .resize(rf), K^-1 in the first nine slots
+                        Kn = c.K.clone()
+                        Kn[:, 0, 2] += pl
+                        Kn[:, 1, 2] += pt
+                        Kn[:, :2, :] *= plan.rf
+                        buf[i, :9] = torch.inverse(Kn).reshape(9)
+                    else:
+                        pn = c.network_params(plan.paddings, plan.rf)
+                        buf[i, : pn.shape[1]] = pn[0]
+                plan.kinv_gt.copy_(buf)
+            elif cam_obj is not None:
                 pn = cam_obj.network_params(plan.paddings, plan.rf)               # [n, <= 16] -> the parameter slots of the ray kernel
                 buf = torch.zeros(pn.shape[0], plan.kinv_gt.shape[1])
                 buf[:, :pn.shape[1]] = pn
