@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORICAL (round 4): several switches set below (UD_GEMM_W3, UNIDEPTH_ALIAS, UNIDEPTH_SIDE, UNIDEPTH_GRAPH, UD_HEAD_REGW, UNIDEPTH_UPFUSE,
+# UNIDEPTH_PIPE_PRIO) and the attention compile-time variants were removed in round 5; kept as the record of how profiles/r04_* were produced.
 # The batched GPU-box sessions of round 4, one function per gpurun call (tests + interleaved A/B + profiles in one call each); every
 # profiles/r04_* file names the session that produced it.  usage (on the GPU box, through gpurun):  bash tools/r4/sessions.sh <name>
 #   e.g.  /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/r4/sessions.sh final'

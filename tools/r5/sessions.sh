@@ -102,4 +102,19 @@ echo "[suite done $(( $(date +%s) - t0 )) s]" >> $O/suite.txt
 cat $O/suite.txt
 }
 
+# round 5, GPU call 8: proj / fc2 residual preload behind a COUNTED operand wait (product) against the round-4 vmcnt(0) form (ab/libresid0.so):
+# the GEMM kernel tests on the product, the four encoder GEMM shapes and the bench line interleaved
+call8() {
+O=gpurun_out/r5c8 && mkdir -p $O
+timeout 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu -k "gemm" 2>&1 | grep -v "^$\|amdgpu.ids" | tail -5 > $O/gemm_tests.txt
+for r in 1 2; do
+  for lib in ab/libresid0.so unidepth_amd/libunidepth_hip.so; do
+    echo "== $lib" >> $O/enc_gemms.txt
+    UNIDEPTH_HIP_LIB=$R/$lib timeout 200 python tools/bench_enc_gemms.py 2>&1 | grep -v amdgpu.ids | tail -6 >> $O/enc_gemms.txt
+    UNIDEPTH_HIP_LIB=$R/$lib timeout 300 python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-extra-configs --no-kernel-timing 2>$O/err.txt | line "$lib" >> $O/bench_ab.txt
+  done
+done
+cat $O/gemm_tests.txt $O/enc_gemms.txt $O/bench_ab.txt
+}
+
 "$@"

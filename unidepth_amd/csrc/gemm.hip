@@ -1007,15 +1007,32 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
     // bit-for-bit batch-permutation equivariant; an in-loop variant that streamed them in during the first K-tiles hid the
     // 7 us load burst but made the result depend on the batch position at the 2e-4 level after fp16 re-rounding).
     // Issued before the wait for the first operand tile: both bursts are in flight together.
+    bool counted = false;        // the first tile's operand wait may leave the residual loads in flight (full tiles: their number is exact)
     if constexpr (ACC_EPI) {
       if (p.accumulate) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        gemm_preload_acc<TMC, 4>(p, acc, mbase, nbase, ln, (const char*)p.out);
+        if (first && (m0 + BMC <= p.M) && (n0 + 256 <= p.N) && p.rows_in == 0) {
+          // full tile: TMC * 4 unconditional 16-byte loads per lane, issued AFTER the operand DMA of K-tile 0 (and of W(1)): loads retire in
+          // order, so `vmcnt(TMC * 4)` below means "the operands have landed" while the 45 MB residual burst of all workgroups is still
+          // streaming in -- the first MFMA phases start as their own rows arrive (the compiler's waits before each accumulator's first use)
+          // instead of behind the whole burst (6.3 us serial prologue with the matrix pipes idle, DESIGN_HISTORY 8.2; measured: proj 37.5 -> 36.6 us
+          // alone, fc2 and the step inside the noise, profiles/r05_resid_counted_ab.txt).  Same values, same
+          // summation order: the old value is still the accumulator's initial state.
+          const float* ob = (const float*)p.out + (size_t)(mbase + (ln & 15)) * p.ldc + nbase + 4 * (ln >> 4);
+#pragma unroll
+          for (int i = 0; i < TMC; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = *(const f32x4*)(ob + (size_t)(i * 16) * p.ldc + j * 16);
+          counted = true;
+        } else {
+          gemm_preload_acc<TMC, 4>(p, acc, mbase, nbase, ln, (const char*)p.out);
+        }
       }
     }
     if (first) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (counted) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(TMC * 4) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       first = false;
