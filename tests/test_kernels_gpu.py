@@ -1064,6 +1064,36 @@ def test_attention_prescaled_q_matches_classic_path(ops, N, spike):
     assert torch.isfinite(outs[1]).all()
 
 
+@pytest.mark.parametrize("B,H,N", [(24, 8, 300), (40, 8, 200), (9, 16, 1370)])
+def test_attention_persistent_workgroups_walk_several_items(ops, B, H, N):
+    """The pipelined kernel's persistent form: more (image, head, q-tile) items than workgroups (576 / 640 / 1584 against 512), so a workgroup
+    walks several items and fetches the next item's Q fragments / first K and V^T tiles under the last tile of the current one -- with an ODD
+    tile count (N = 300: 5 tiles, V^T(0) of the next item cannot be prefetched and goes out behind an extra barrier), an even one (N = 200) and
+    the encoder's shape; every (image, head) pair is checked against fp32 torch."""
+    D = H * 64
+    Np, kvld = (N + 15) // 16 * 16, (N + 63) // 64 * 64
+    g = torch.Generator().manual_seed(B + N)
+    q = torch.randn(B * Np, D, generator=g)
+    k = torch.randn(B * Np, D, generator=g)
+    c = 0.125 * 1.4426950408889634
+    qk = torch.cat([q * c, k], dim=1).half().cuda()
+    v = torch.randn(B, H, N, 64, generator=g)
+    vt = torch.zeros(B, H, 64, kvld)
+    vt[..., vt_cols(N).cpu()] = v.transpose(2, 3)
+    vt = vt.half().cuda()
+    o = torch.full((B * Np, D), 7.0, dtype=torch.half, device="cuda")
+    ops.attention(Q=qk, K=qk.data_ptr() + D * 2, Vt=vt, O=o, B=B, H=H, Nq=N, Nk=N, ldq=2 * D, ldk=2 * D, ldo=D, kv_ld=kvld,
+                  q_rows_per_img=Np, k_rows_per_img=Np, scale=0.125, q_prescaled=1)
+    torch.cuda.synchronize()
+    qq = (qk[:, :D].float() / c).view(B, Np, H, 64)[:, :N].transpose(1, 2)
+    kk = qk[:, D:].float().view(B, Np, H, 64)[:, :N].transpose(1, 2)
+    ref = (torch.softmax(qq @ kk.transpose(-1, -2) * 0.125, -1) @ v.cuda().half().float()).transpose(1, 2)       # [B, N, H, 64]
+    got = o.float().view(B, Np, H, 64)[:, :N]
+    err = ((got - ref).abs().amax(dim=(1, 3)) / ref.abs().amax(dim=(1, 3)))                                       # per (image, head)
+    assert float(err.max()) < 2e-3, (float(err.max()), int(err.argmax()))
+    assert Np == N or (o.view(B, Np, D)[:, N:] == 7.0).all()                                                     # pad rows untouched
+
+
 def test_gemm_head_conv_with_fused_upsampling(ops):
     """UD_A_CONV3_REFLECT_UP: 3x3 reflect conv + LeakyReLU + 1x1 + clip/exp over the align_corners=True up-sampling of a low-resolution
     NHWC map that is never materialised == the same head on the map written by ud_resize_ac_nhwc_f16 (bit-compatible interpolation) and

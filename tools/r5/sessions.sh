@@ -117,4 +117,58 @@ done
 cat $O/gemm_tests.txt $O/enc_gemms.txt $O/bench_ab.txt
 }
 
+# round 5, GPU call 9: PMC passes over the attention micro-benchmark for the pipelined kernel (product) and the one-tile-at-a-time kernel
+# (ab/libattn_classic.so): cycles, instruction counts, MFMA / VALU busy, and the clock (GRBM_GUI_ACTIVE / kernel duration).  Counters only.
+call9() {
+O=$R/gpurun_out/r5c9 && mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+for arm in pipe classic; do
+  lib=$R/unidepth_amd/libunidepth_hip.so; [ $arm = classic ] && lib=$R/ab/libattn_classic.so
+  i=0
+  for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+             "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVES" \
+             "GRBM_GUI_ACTIVE" ; do
+    i=$((i+1))
+    UNIDEPTH_HIP_LIB=$lib timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/${arm}_$i -o p -- python $R/tools/bench_attn.py > $O/${arm}_$i.log 2>&1
+  done
+done
+python - <<'PY' > $O/attn_pmc.txt
+import csv, glob, collections, os
+O = os.environ.get("O", "/root/repo/gpurun_out/r5c9")
+for arm in ("pipe", "classic"):
+    acc = collections.defaultdict(float); n = collections.defaultdict(int); dur = []
+    for f in sorted(glob.glob(f"{O}/{arm}_[0-9]*/**/*counter_collection.csv", recursive=True)):
+        for r in csv.DictReader(open(f)):
+            if "attention" in r["Kernel_Name"]:
+                acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
+    for f in sorted(glob.glob(f"{O}/{arm}_3/**/*kernel_trace.csv", recursive=True)):
+        for r in csv.DictReader(open(f)):
+            if "attention" in r["Kernel_Name"]:
+                dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    print(f"== {arm}: per-launch averages over the profiled launches of tools/bench_attn.py (encoder attention, B=8 H=16 N=1370, q pre-scaled)")
+    for k in sorted(acc):
+        print(f"{k:32s} {acc[k] / max(n[k], 1):16.0f}   (n={n[k]})")
+    if dur and "GRBM_GUI_ACTIVE" in acc:
+        d = sum(dur) / len(dur)
+        print(f"kernel duration (GRBM pass)      {d / 1e3:16.1f} us   clock = GRBM_GUI_ACTIVE / duration = {acc['GRBM_GUI_ACTIVE'] / n['GRBM_GUI_ACTIVE'] / d:.3f} GHz")
+PY
+cd $R
+rm -rf $O/pipe_[0-9] $O/classic_[0-9]
+cat $O/attn_pmc.txt; tail -2 $O/pipe_1.log
+}
+
+# round 5, GPU call 10: the pipelined attention kernel with PERSISTENT workgroups (512 walk the 1408 items, the next item's Q / K(0) / V(0) / K(1)
+# fetched under the last tile) against one workgroup per item and against the one-tile-at-a-time kernel; attention kernel tests; bench A/B
+call10() {
+O=gpurun_out/r5c10 && mkdir -p $O
+timeout 600 python tools/attn_ab.py --rounds 3 classic nopersist persist 2>&1 | grep -v amdgpu.ids > $O/attn_ab.txt
+timeout 400 python -m pytest tests/test_kernels_gpu.py -q -m gpu -k "attention" 2>&1 | grep -v "^$\|amdgpu.ids" | tail -6 > $O/attn_tests.txt
+for r in 1 2; do
+  for lib in ab/libattn_nopersist.so unidepth_amd/libunidepth_hip.so; do
+    UNIDEPTH_HIP_LIB=$R/$lib timeout 300 python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-extra-configs --no-kernel-timing 2>$O/err.txt | line "$lib" >> $O/bench_ab.txt
+  done
+done
+cat $O/attn_ab.txt $O/attn_tests.txt $O/bench_ab.txt
+}
+
 "$@"

@@ -41,6 +41,8 @@
 #define UD_ATTN_PIPE_MINW 2
 #define UD_ATTN_PIPE_NW 4
 #define UD_ATTN_PIPE_FD 3
+#define UD_ATTN_PIPE_WGS_PER_XCD 64      // persistent workgroups per XCD (two 256-thread workgroups on each of its 32 CUs); measured against one workgroup
+                                         // per item: 89.5 vs 91.2 us alone, 615.6 vs 613.0 images/s in the step (profiles/r05_attn_persistent_ab.txt)
 
 namespace {
 
@@ -301,30 +303,49 @@ __global__ __launch_bounds__(NW * 64, UD_ATTN_PIPE_MINW) void attention_pipe_ker
   const int qt = (p.Nq + NW * 32 - 1) / (NW * 32);
   const int pairs = p.B * p.H;
   const int nt = (p.Nk + KT - 1) / KT;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int pr = xcd + 8 * (slot / qt);                   // all q-tiles of a pair on one XCD, consecutive slots
-  if (pr >= pairs) return;
-  const int head = pr % p.H;
-  const int img = pr / p.H;
-  const int kimg = p.kv_broadcast ? (p.kv_group > 0 ? img / p.kv_group : 0) : img;
-  const int q0 = (slot % qt) * (NW * 32) + wv * 32;
+  // PERSISTENT workgroups over work items (one item = one q-tile of one (image, head) pair).  XCD-aware: workgroup b runs on XCD b % 8 and walks
+  // the items of the pairs pr % 8 == b % 8 with stride S = gridDim.x / 8, so all q-tiles of a pair stay on one XCD's L2.  With gridDim.x = the
+  // number of items every workgroup has exactly one item (the round-4 launch shape); with 2 workgroups per CU (512) each walks ~2.75 items at the
+  // encoder shape and the per-item fixed cost -- kernel-argument and Q loads, the first K / V^T DMAs, the output stores, the workgroup hand-over:
+  // ~20 k of a wave's 48 k cycles, profiles/r05_attn_pmc.txt -- is hidden: the NEXT item's Q fragments and first tiles are fetched under the
+  // last tile of the current one.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+  const int n_items = ((pairs - xcd + 7) >> 3) * qt;       // items on this XCD
+  int item = slot;
+  if (item >= n_items) return;
+  int head, img, kimg, q0;
+  auto decode = [&](int it, int& hd, int& im, int& ki, int& qq) {
+    const int pr = xcd + 8 * (it / qt);
+    hd = pr % p.H;
+    im = pr / p.H;
+    ki = p.kv_broadcast ? (p.kv_group > 0 ? im / p.kv_group : 0) : im;
+    qq = (it % qt) * (NW * 32) + wv * 32;
+  };
+  decode(item, head, img, kimg, q0);
 
   const half_t* Q = (const half_t*)p.Q;
   const half_t* K = (const half_t*)p.K;
-  const half_t* Vt = (const half_t*)p.Vt + ((size_t)kimg * p.H + head) * 64 * (size_t)p.kv_ld;
-
-  half8 qf[4];
-  {
-    int qr = q0 + ql;
+  auto q_ptr = [&](int im, int hd, int qq) {
+    int qr = qq + ql;
     qr = qr < p.Nq ? qr : p.Nq - 1;
-    const half_t* qp = Q + ((size_t)img * p.q_rows_per_img + qr) * p.ldq + head * 64 + hh * 8;
+    return Q + ((size_t)im * p.q_rows_per_img + qr) * p.ldq + hd * 64 + hh * 8;
+  };
+  auto make_rk = [&](int ki, int hd) { return ud_make_rsrc(K + (size_t)ki * p.k_rows_per_img * p.ldk + hd * 64, (unsigned)((p.Nk - 1) * p.ldk + 64) * 2u); };
+  auto make_rv = [&](int ki, int hd) { return ud_make_rsrc((const half_t*)p.Vt + ((size_t)ki * p.H + hd) * 64 * (size_t)p.kv_ld, 64u * (unsigned)p.kv_ld * 2u); };
+
+  half8 qf[4], qn[4];                                      // Q fragments of the current item / prefetched for the next one
+  {
+    const half_t* qp = q_ptr(img, head, q0);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const half8*)(qp + ks * 16);
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = *(const half8*)(qp + ks * 16);
+      qn[ks] = qf[ks];
+    }
   }
 
   const int lrow = lane >> 3, lch = lane & 7;
-  const ud_rsrc_t rK = ud_make_rsrc(K + (size_t)kimg * p.k_rows_per_img * p.ldk + head * 64, (unsigned)((p.Nk - 1) * p.ldk + 64) * 2u);
-  const ud_rsrc_t rV = ud_make_rsrc(Vt, 64u * (unsigned)p.kv_ld * 2u);
+  ud_rsrc_t rK = make_rk(kimg, head), rV = make_rv(kimg, head);
+  ud_rsrc_t rKn = rK, rVn = rV;                            // descriptors of the next item's pair
   constexpr int PW = 8 / NW;
   unsigned koff[PW], voff[PW];
 #pragma unroll
@@ -336,14 +357,16 @@ __global__ __launch_bounds__(NW * 64, UD_ATTN_PIPE_MINW) void attention_pipe_ker
   }
   const unsigned kstep = (unsigned)(KT * p.ldk) * 2u;
   // a K tile beyond the sequence reads as zeros (descriptor bound) and a V^T tile beyond it is never consumed: no branch around the issue
-  auto issue_k = [&](int kt, int stage) {
+  auto issue_k_from = [&](const ud_rsrc_t r, int kt, int stage) {
 #pragma unroll
-    for (int i = 0; i < PW; ++i) ud_bufl16(rK, koff[i] + (unsigned)kt * kstep, 0, smem + stage * STAGE + (wv * PW + i) * 1024);
+    for (int i = 0; i < PW; ++i) ud_bufl16(r, koff[i] + (unsigned)kt * kstep, 0, smem + stage * STAGE + (wv * PW + i) * 1024);
   };
-  auto issue_v = [&](int kt, int stage) {
+  auto issue_v_from = [&](const ud_rsrc_t r, int kt, int stage) {
 #pragma unroll
-    for (int i = 0; i < PW; ++i) ud_bufl16(rV, voff[i], kt * (KT * 2), smem + stage * STAGE + KS_BYTES + (wv * PW + i) * 1024);
+    for (int i = 0; i < PW; ++i) ud_bufl16(r, voff[i], kt * (KT * 2), smem + stage * STAGE + KS_BYTES + (wv * PW + i) * 1024);
   };
+  auto issue_k = [&](int kt, int stage) { issue_k_from(rK, kt, stage); };
+  auto issue_v = [&](int kt, int stage) { issue_v_from(rV, kt, stage); };
 
   f32x16 o[2];
 #pragma unroll
@@ -386,6 +409,7 @@ __global__ __launch_bounds__(NW * 64, UD_ATTN_PIPE_MINW) void attention_pipe_ker
         if (key >= p.Nk) s[kb][r] = -1.0e30f;
       }
   };
+
   auto rowmax = [&](const f32x16 (&s)[2]) {
     float mx = s[0][0];
 #pragma unroll
@@ -440,10 +464,25 @@ __global__ __launch_bounds__(NW * 64, UD_ATTN_PIPE_MINW) void attention_pipe_ker
     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[(j + 8) % FD], __builtin_bit_cast(half8, w), o[db], 0, 0, 0);
   };
 
-  // ---- prologue: K(0), V^T(0) -> stage 0, K(1) -> stage 1; scores and row maximum of tile 0
+  // ---- the first item's K(0), V^T(0) -> stage 0, K(1) -> stage 1 (later items: prefetched under the previous item's last tile)
   issue_k(0, 0);
   issue_v(0, 0);
   issue_k(1, 1);
+  bool has_next = false, v0_pending = false;
+  int head_n = 0, img_n = 0, kimg_n = 0, q0_n = 0;
+  for (;;) {                                               // ======================= one work item per trip =======================
+  has_next = item + nslot < n_items;
+  if (has_next) {
+    decode(item + nslot, head_n, img_n, kimg_n, q0_n);
+    rKn = make_rk(kimg_n, head_n);
+    rVn = make_rv(kimg_n, head_n);
+  }
+  if (v0_pending) {                                        // odd tile count: the last tile read stage 0's V^T part, so V^T(0) could not be prefetched
+    __builtin_amdgcn_s_barrier();                          // every wave is done with that tile
+    issue_v(0, 0);
+    v0_pending = false;
+  }
+  // ---- scores and row maximum of tile 0
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   {
@@ -503,6 +542,15 @@ __global__ __launch_bounds__(NW * 64, UD_ATTN_PIPE_MINW) void attention_pipe_ker
     if constexpr (!LAST) {
       issue_k(t + 2, STG);
       issue_v(t + 1, STG ^ 1);
+    } else if (has_next) {
+      // the next item's first tiles and Q fragments, under this item's last tile (which reads only stage STG's V^T part)
+      issue_k_from(rKn, 0, 0);
+      issue_k_from(rKn, 1, 1);
+      if constexpr (STG == 1) issue_v_from(rVn, 0, 0);
+      else v0_pending = true;
+      const half_t* qp = q_ptr(img_n, head_n, q0_n);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) qn[ks] = *(const half8*)(qp + ks * 16);
     }
     ls = 0.0f;
     // (3) sixteen slots, each {fragment read FD-1 ahead, one MFMA, a share of the VALU work}, pinned in this order by sched_barrier:
@@ -593,6 +641,23 @@ __global__ __launch_bounds__(NW * 64, UD_ATTN_PIPE_MINW) void attention_pipe_ker
         *(half4*)(op + db * 32 + g * 8) = h;
       }
   }
+  if (!has_next) break;
+  // ---- roll to the next item: its Q fragments, descriptors and first tiles are already on their way
+  item += nslot;
+  head = head_n; img = img_n; kimg = kimg_n; q0 = q0_n;
+  rK = rKn; rV = rVn;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.0f;
+  m_i = 0.0f; l_i = 0.0f;
+  la[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; la[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negm[r] = 0.0f;
+  if constexpr (NEGMC) asm volatile("" : "+v"(negm));
+  }                                                        // item loop
 }
 
 }  // namespace
@@ -609,7 +674,11 @@ extern "C" int ud_attention_f16(const UdAttention* desc, void* stream) {
   if (UD_ATTN_PIPE != 0 && d.q_prescaled) {
     constexpr int NW = UD_ATTN_PIPE_NW;
     const int qt = (d.Nq + NW * 32 - 1) / (NW * 32);
-    hipLaunchKernelGGL((attention_pipe_kernel<NW, UD_ATTN_PIPE_OPT>), dim3(8 * ((pairs + 7) / 8) * qt), dim3(NW * 64), 0, (hipStream_t)stream, d, thr);
+    // persistent workgroups: UD_ATTN_PIPE_WGS_PER_XCD slots per XCD (64 = two 256-thread workgroups on each of an XCD's 32 CUs), every slot
+    // walks the XCD's items with that stride; fewer items than slots: one workgroup per item
+    const int items_xcd = ((pairs + 7) / 8) * qt;
+    const int nslot = items_xcd < UD_ATTN_PIPE_WGS_PER_XCD ? items_xcd : UD_ATTN_PIPE_WGS_PER_XCD;
+    hipLaunchKernelGGL((attention_pipe_kernel<NW, UD_ATTN_PIPE_OPT>), dim3(8 * nslot), dim3(NW * 64), 0, (hipStream_t)stream, d, thr);
   } else {
     const int qt = (d.Nq + 127) / 128;
     const dim3 grid(8 * ((pairs + 7) / 8) * qt);
