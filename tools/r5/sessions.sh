@@ -171,4 +171,35 @@ done
 cat $O/attn_ab.txt $O/attn_tests.txt $O/bench_ab.txt
 }
 
+# round 5, the end-of-round run: rocprofv3 kernel stats + FETCH / WRITE passes over bench.py (and the V1 trace), GEMM PMC passes, the full bench line with
+# per-launch timings, the WHOLE GPU suite (incl. the parity sweeps), smoke()
+final() {
+O=gpurun_out/r5final && mkdir -p $O
+t0=$(date +%s)
+timeout 700 bash tools/profile_bench.sh r05 > $O/profile_bench.log 2>&1
+python tools/update_profiles.py r05 r05_bench_bs8_vitl >> $O/profile_bench.log 2>&1
+echo "[profiles done $(( $(date +%s) - t0 )) s]"
+timeout 300 bash tools/pmc_gemm.sh 2>&1 | grep -v amdgpu.ids > $O/gemm_pmc.txt
+echo "[pmc done $(( $(date +%s) - t0 )) s]"
+timeout 900 python bench.py --dump-ops $O/ops_per_launch.tsv > $O/bench.json 2> $O/bench.err
+echo "[bench done $(( $(date +%s) - t0 )) s]"
+mkdir -p $O/profiles && cp profiles/r05_bench_bs8_vitl_kernel_stats.csv profiles/r05_hbm_traffic.json profiles/r05_v1_cnvnxtl_640x480_bs16_kernel_stats.csv $O/profiles/ 2>/dev/null
+cp gpurun_out/prof_r05.v1.log $O/profiles/r05_v1_trace_breakdown.txt 2>/dev/null
+rm -rf gpurun_out/prof_r05/*/ gpurun_out/pmcg_* gpurun_out/pmca_*          # raw traces stay on the box
+timeout 1800 python -m pytest tests/ -q -s -m gpu 2>&1 | grep -v "^$\|amdgpu.ids" > $O/suite_full.txt
+tail -15 $O/suite_full.txt > $O/suite.txt
+echo "[suite done $(( $(date +%s) - t0 )) s]" >> $O/suite.txt
+timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('__SMOKE_OK__')" 2>&1 | grep -v amdgpu.ids | tail -4 > $O/smoke.txt
+tail -4 $O/profile_bench.log; head -12 $O/gemm_pmc.txt; cat $O/suite.txt $O/smoke.txt; tail -3 $O/bench.err
+python - <<'P'
+import json
+d = json.loads(open("gpurun_out/r5final/bench.json").read().strip().splitlines()[-1])
+print({k: d[k] for k in ("value", "ms_per_step", "p50_latency_ms", "value_one_call")})
+print(json.dumps(d["roofline"])[:900])
+print(json.dumps(d.get("cpu_baseline"))[:400])
+for k, v in d.get("configs", {}).items():
+    print(k, v.get("value"), v.get("ms_per_step"), v.get("error"))
+P
+}
+
 "$@"
