@@ -377,7 +377,7 @@ def kernel_timing(torch, model, fl, B, dump=""):
                  for k, v in sorted(tot.items(), key=lambda kv: -kv[1]["ms"])}
     # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the json)
     traffic, traffic_src = None, None
-    for name in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    for name in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if traffic is None and os.path.exists(tpath):
             short = dom.replace("Cfg<", "(anonymous namespace)::Cfg<")
@@ -493,10 +493,10 @@ def extra_configs(torch, model_v2, dev, cpu=True):
                "ms_per_step": round(dt * 1e3, 3), "steps": 10, "launches": len(plan.prog),
                "dtype": "f16 MFMA operands, fp32 accumulate" + ("; weights as TWO fp16 terms (W_hi + W_lo, ~22-bit weights: UdGemm.a_wrap)" + ("" if v1mod.WSPLIT_CONVNEXT_FC1 else " except the ConvNeXt blocks' fc1") if v1mod.WSPLIT else "")
                         + ("; the ConvUpsample tails and the output convs as THREE-term products ([A_hi | A_lo] x [W_hi | W_hi | W_lo])" if getattr(v1mod, "ASPLIT", False) else "")
-                        + "; depth-wise convolutions, LayerNorm / softmax statistics, the camera transformer, the Nystrom pseudo-inverse and all residual streams in fp32",
+                        + "; depth-wise convolutions, LayerNorm / softmax statistics, the camera transformer, the NystromBlocks' per-token head attention and all residual streams in fp32",
                "parity": "depth ARel <= 1e-3 per image vs the fp32 oracle at this batch (tests/test_v1_gpu.py::test_v1_infer_config4_bs16_vs_oracle); over 8 checkpoint "
-                         "seeds x 2 sizes (tests/test_parity_sweep_gpu.py): median 5.6e-4, max 7.9e-4, 16 of 16 within 1e-3 (profiles/r04_v1_sweep_three_term_all_split.txt); "
-                         "Nystrom stages: parity unpinned (oracle header)",
+                         "seeds x 2 sizes (tests/test_parity_sweep_gpu.py): median 5.9e-4, max 7.9e-4, 16 of 16 within 1e-3 (profiles/r05_parity_sweep.txt); "
+                         "NystromBlocks as the reference executes them (oracle/stubs/xformers restates xformers' NystromAttention)",
                "model_tflops_per_s": round(fl_total / dt / 1e12, 1),
                "roofline": {"bound": "mfma", "kernel": dom + " (v_mfma_f32_16x16x32_f16)", "achieved": round(dv[1] / (dv[0] * 1e-3) / 1e12, 2),
                             "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(dv[1] / (dv[0] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
