@@ -202,4 +202,16 @@ for k, v in d.get("configs", {}).items():
 P
 }
 
+# what the driver runs at the end of the round, in its order and with its flags, on a fresh box
+rehearsal() {
+O=gpurun_out/r5rehearsal && mkdir -p $O
+t0=$(date +%s)
+timeout 1500 python -m pytest tests/ -x -q -m gpu 2>&1 | grep -v "^$\|amdgpu.ids" | tail -8 > $O/suite.txt
+echo "[suite $(( $(date +%s) - t0 )) s]" >> $O/suite.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('__SMOKE_OK__')" 2>&1 | grep -v amdgpu.ids | tail -3 > $O/smoke.txt
+timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
+echo "[all $(( $(date +%s) - t0 )) s]" >> $O/suite.txt
+cat $O/suite.txt $O/smoke.txt; tail -2 $O/bench.err; cut -c1-400 $O/bench.json
+}
+
 "$@"
