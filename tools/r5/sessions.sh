@@ -214,4 +214,80 @@ echo "[all $(( $(date +%s) - t0 )) s]" >> $O/suite.txt
 cat $O/suite.txt $O/smoke.txt; tail -2 $O/bench.err; cut -c1-400 $O/bench.json
 }
 
+# XCD row-owner tile map of the single-round large-tile launches (ab/libown.so) against the product library: tests, bench A/B (interleaved),
+# FETCH_SIZE pass of both
+call11() {
+O=$R/gpurun_out/r5c11 && mkdir -p $O
+ARMS="${ARMS:-base own rm}"
+libof() { if [ $1 = base ]; then echo $R/unidepth_amd/libunidepth_hip.so; else echo $R/ab/lib$1.so; fi; }
+for arm in $ARMS; do
+  [ $arm = base ] && continue
+  UNIDEPTH_HIP_LIB=$(libof $arm) timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_infer_gpu.py tests/test_parity_gpu.py -q -x -m gpu 2>&1 | grep -v "^$\|amdgpu.ids" | tail -3 > $O/tests_$arm.txt
+done
+for rep in 1 2 3; do
+  for arm in $ARMS; do
+    UNIDEPTH_HIP_LIB=$(libof $arm) timeout 600 python bench.py --no-cpu-baseline --no-extra-configs --dump-ops $O/ops_${arm}_$rep.tsv > $O/bench_${arm}_$rep.json 2> $O/bench_${arm}_$rep.err
+  done
+done
+( cd /tmp && export TMPDIR=/tmp
+  ARGS="$R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-extra-configs --inflight 1"
+  for arm in $ARMS; do
+    UNIDEPTH_HIP_LIB=$(libof $arm) timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/f_$arm -o f -- python $ARGS > $O/f_$arm.log 2>&1
+  done )
+ARMS="$ARMS" python - <<'P' | tee $O/ab.txt
+import collections, csv, glob, json, os
+O = "gpurun_out/r5c11"
+for arm in os.environ["ARMS"].split():
+    vals, p50s = [], []
+    t = collections.defaultdict(list)
+    for rep in (1, 2, 3):
+        try:
+            d = json.loads(open(f"{O}/bench_{arm}_{rep}.json").read().strip().splitlines()[-1])
+            vals.append(d["value"]); p50s.append(d["p50_latency_ms"])
+            for line in open(f"{O}/ops_{arm}_{rep}.tsv"):
+                c = line.rstrip("\n").split("\t")
+                if len(c) >= 4 and c[2] in ("enc.qkv", "enc.attn", "enc.proj", "enc.fc1", "enc.fc2", "patch.w"):
+                    t[c[2]].append(float(c[3]))
+        except Exception as e:
+            print(arm, rep, "bench failed", e)
+    print(arm, "value", vals, "p50", p50s)
+    print(arm, {k: round(sum(v) / len(v), 2) for k, v in t.items()})
+    a = collections.defaultdict(list)
+    for path in glob.glob(f"{O}/f_{arm}/**/f_counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(path)):
+            a[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    for k, v in sorted(a.items()):
+        if "gemm256" in k:
+            print(f"  {arm} read MB/launch {sum(v) / len(v) * 2048 / 1e6:8.1f}  x{len(v):4d}  {k[28:90]}")
+P
+for arm in $ARMS; do rm -rf $O/f_$arm; done
+cat $O/tests_*.txt
+}
+
+# FETCH_SIZE / WRITE_SIZE against known byte counts in the access patterns of the large-tile GEMM (tools/ubench/fetch_calib.hip)
+calib() {
+O=$PWD/gpurun_out/r5calib && mkdir -p $O
+B=$PWD/tools/ubench/fetch_calib
+( cd /tmp && export TMPDIR=/tmp
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/f -o f -- $B > $O/f.log 2>&1
+  timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/w -o w -- $B > $O/w.log 2>&1 )
+python - <<'P' | tee $O/calib.txt
+import collections, csv, glob
+def agg(pat):
+    a = collections.defaultdict(list)
+    for path in glob.glob(pat, recursive=True):
+        for r in csv.DictReader(open(path)):
+            a[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    return a
+f, w = agg("gpurun_out/r5calib/f/**/f_counter_collection.csv"), agg("gpurun_out/r5calib/w/**/w_counter_collection.csv")
+B = 512 * 2 ** 20
+print("kernel            FETCH_SIZE*1024 / bytes   WRITE_SIZE*1024 / bytes   (512 MiB touched once per launch)")
+for k in sorted(set(f) | set(w)):
+    fr = sum(f.get(k, [0])) / max(1, len(f.get(k, [0]))) * 1024 / B
+    wr = sum(w.get(k, [0])) / max(1, len(w.get(k, [0]))) * 1024 / B
+    print(f"{k:18s} {fr:10.3f} {wr:24.3f}")
+P
+rm -rf $O/f $O/w
+}
+
 "$@"

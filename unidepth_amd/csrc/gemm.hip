@@ -795,12 +795,18 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   const half_t* W = (const half_t*)p.W;
 
   // tile list entry -> (m0, n0): XCD-aware (contiguous range of the list per XCD; gridDim.x is a multiple of 8 or == nblk, so
-  // t % 8 == blockIdx.x % 8 == the XCD) + group-M walk (8 row-tiles x all column tiles at a time share A and W panels in L2)
+  // t % 8 == blockIdx.x % 8 == the XCD) + group-M walk (8 row-tiles x all column tiles at a time share A and W panels in L2).
+  // A list that fits one round (tiles <= 256 CUs: proj / fc2 / patch embed at bs = 8, most decoder GEMMs) is walked row-major instead
+  // (groups of ONE row tile): an XCD's range of 29 tiles then covers 8-9 row tiles with all their column tiles, where the 8-row groups
+  // (32 tiles) straddled the ranges and every XCD touched ~11 row tiles, re-fetching their A rows through the fabric.  Measured on the
+  // proj / fc2 class (profiles/r05_tile_map_ab.txt): 188.2 -> 147.5 MB read per launch (modelled 141: A once + W per XCD + the fp32
+  // residual), step +0.3 %.  Giving every XCD whole row tiles (8 x 32 slots, the surplus workgroups exit) reads 141.8 MB but loads two
+  // XCDs with 32 tiles against 28 and cost 1 % of the step: not kept.
   auto decode = [&](int t, int& m0, int& n0) {
     const int q = nblk >> 3, r = nblk & 7;
     const int xcd = t & 7, idx = t >> 3;
     const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    constexpr int GM = 8;
+    const int GM = nblk <= 256 ? 1 : 8;
     const int gsz = GM * tiles_n;
     const int grp = bid / gsz;
     const int first_m = grp * GM;
