@@ -264,6 +264,13 @@ for arm in $ARMS; do rm -rf $O/f_$arm; done
 cat $O/tests_*.txt
 }
 
+# the default bench line alone (another box of the pool)
+benchonly() {
+O=gpurun_out/r5bench && mkdir -p $O
+timeout 900 python bench.py --dump-ops $O/ops_per_launch.tsv > $O/bench.json 2> $O/bench.err
+tail -2 $O/bench.err; cut -c1-330 $O/bench.json
+}
+
 # FETCH_SIZE / WRITE_SIZE against known byte counts in the access patterns of the large-tile GEMM (tools/ubench/fetch_calib.hip)
 calib() {
 O=$PWD/gpurun_out/r5calib && mkdir -p $O
