@@ -187,6 +187,42 @@ int ud_linear_f32(const UdLinearF32* desc, void* stream);
  * q [B*T, C], kv [B*T, 2C] = [K | V] heads-major, out [B*T, C]; H heads of width C/H. */
 int ud_attention_small_f32(const float* q, const float* kv, float* out, int B, int T, int H, int C, float scale, void* stream);
 
+/* ---- the whole camera head as ONE launch ------------------------------------------------------------------------
+ * CameraHead.forward (decoder.py:94-108: project MLP, two AttentionBlocks over the 4 camera tokens of an image, out_pinhole MLP) and the four
+ * camera_token_adapter Linears in front of it (decoder.py:34-45, 418-433) are ~26 dependent launches of the two fp32 kernels above, each a few
+ * microseconds of work behind ~10 us of launch and fill latency (0.38 ms per infer() at bs = 8, 7 % of a bs = 1 call).  Here the chain is a
+ * list of PHASES run by one persistent grid: phase = [LayerNorm of the input rows] -> out (+)= act(x W^T + bias + add) over a column slice per
+ * workgroup, or the T-token attention per (image, head); workgroups meet at a grid barrier (one agent-scope counter) where a phase reads what
+ * the previous one wrote.  Activations cross XCDs with system-scope (sc0 sc1) stores and loads -- the L2s of the 8 XCDs are not coherent with each
+ * other inside a kernel -- while the next phase's weight slab streams into LDS under the barrier.  Same arithmetic as the launches it replaces
+ * (fp32 FMA chains, two-pass LayerNorm, erf GELU); the summation order over k differs (32 interleaved slices per row, then a butterfly).
+ * Limits (ud_camera_head_f32 returns UD_ERR_UNSUPPORTED otherwise and the caller keeps the per-layer launches): linear phases need K % 128 == 0,
+ * ceil(N / workgroups) * K * 4 <= 32 KB, LayerNorm phases K <= 512; attention T <= 8, C / H <= 64; n_phases <= UD_CAM_MAX_PHASES. */
+#define UD_CAM_MAX_PHASES 24
+typedef struct UdCamPhase {
+  const float* x;        /* linear: input rows [M, K] (ldx).  attention: packed rows [q | k | v] (ldx), q at column 0, k at C, v at 2 C */
+  const float* W;        /* [N, K] row-major, dense (row stride K) */
+  const float* bias;     /* [N] or NULL */
+  const float* add;      /* [add_mod, ldadd] or NULL: out[m, n] += add[m % add_mod, n] for n < add_cols (latents_pos on the q columns) */
+  float* out;            /* [M, N] (ldc) */
+  int M, N, K, ldx, ldc, ldadd, add_mod, add_cols;
+  int kind;              /* 0 linear, 1 attention */
+  int ln;                /* 1: the input rows are layer-normalised first (statistics only: the affine is folded into W / bias by the caller) */
+  int act, accumulate;   /* UD_ACT_NONE / UD_ACT_GELU; accumulate: out += ... */
+  int sync;              /* 1: grid barrier after this phase (the next phase reads what this one wrote) */
+} UdCamPhase;
+typedef struct UdCameraHead {
+  UdCamPhase ph[UD_CAM_MAX_PHASES];
+  int n_phases;
+  int T, H, C;           /* attention phases: tokens per image, heads, width (head width C / H) */
+  float scale, eps;      /* softmax scale; LayerNorm eps */
+  unsigned* sync_ws;     /* 16 words, zero before the FIRST launch; every launch leaves words 0 and 1 zero again.  Word 2 != 0 afterwards: a
+                          * grid barrier timed out (~1 s: the grid was not co-resident) and the outputs are invalid */
+  int workgroups;        /* 0 = default (128) */
+} UdCameraHead;
+int ud_camera_head_f32(const UdCameraHead* desc, void* stream);
+int ud_camera_head_supported(const UdCameraHead* desc);   /* UD_OK if ud_camera_head_f32 would take this descriptor (host-side check, nothing is launched) */
+
 /* ---- fused multi-head attention forward, head_dim 64 (padded), no mask, fp16 in/out, fp32 softmax ----
  * O = softmax(Q K^T * scale) V per (image, head).  Replaces F.scaled_dot_product_attention at
  * metadinov2/attention.py:58 and layers/attention.py:136-138 (and xformers memory_efficient_attention :77).
@@ -408,6 +444,7 @@ int ud_program_add_layernorm(UdProgram*, const UdLayerNorm*);
 int ud_program_add_row_stats_finalize(UdProgram*, const float* partials, float* stats, int M, int slabs, int D, float eps);
 int ud_program_add_attention(UdProgram*, const UdAttention*);
 int ud_program_add_linear_f32(UdProgram*, const UdLinearF32*);
+int ud_program_add_camera_head(UdProgram*, const UdCameraHead*);
 int ud_program_add_attention_small_f32(UdProgram*, const float* q, const float* kv, float* out, int B, int T, int H, int C, float scale);
 int ud_program_add_preprocess(UdProgram*, const UdPreprocess*);
 int ud_program_add_fill_rows(UdProgram*, float* dst, const float* src, int n_img, int rows_per_img, int row_off, int D, int ld);
@@ -429,7 +466,7 @@ int ud_program_add_v1_op(UdProgram*, const UdV1Op*);
 /* run ops [first, last) on `stream`; returns 0 or the first failing op's error code.  Stateless: a recorded program is never modified by a replay */
 int ud_program_run(const UdProgram*, int first, int last, void* stream);
 
-/* library info; ud_struct_size(i): sizeof the i-th descriptor struct in declaration order (UdGemm = 0 ... UdLinearF32 = 8, UdDwConv7 = 9, UdV1Op = 10, UdKnn = 11, UdExtractPatches = 12) */
+/* library info; ud_struct_size(i): sizeof the i-th descriptor struct in declaration order (UdGemm = 0 ... UdLinearF32 = 8, UdDwConv7 = 9, UdV1Op = 10, UdKnn = 11, UdExtractPatches = 12, UdCameraHead = 13) */
 int ud_version(void);
 int ud_struct_size(int which);
 const char* ud_last_error(void);

@@ -510,7 +510,8 @@ def test_v2_plan_builder_dry_run_order_and_descriptors(monkeypatch):
     i0 = tags.index("dec.adapters(x4)")
     assert plan.dec_first == plan.enc_last == i0
     cam = tags[i0 + 1:tags.index("ray_embed") + 1]
-    assert cam.count("cam.adapter") == 4 and cam[-2:] == ["rays", "ray_embed"] and "camera_intrinsics" in cam and not any(t.startswith("dh.") for t in cam)
+    # the token adapters and the CameraHead are ONE launch (UdCameraHead); its descriptor is inside the kernel's limits for every backbone
+    assert cam.count("cam.head") == 1 and cam[-2:] == ["rays", "ray_embed"] and "camera_intrinsics" in cam and not any(t.startswith("dh.") for t in cam)
     assert tags[tags.index("ray_embed") + 1:tags.index("ray_embed") + 4] == ["layernorm", "dh.q(x4)", "dh.kv(x4)"]
 
 
@@ -523,6 +524,40 @@ def test_program_api_argument_checks_without_gpu():
     assert lib.ud_program_run(p, -1, 2, None) == -1 and b"bad range" in lib.ud_last_error()
     assert lib.ud_program_run(p, 0, 1, None) == -1
     assert lib.ud_program_run(p, 0, 0, None) == 0                                                    # empty range: nothing to do
+    lib.ud_program_destroy(p)
+
+
+def test_camera_head_cabi_limits_without_gpu():
+    """ud_camera_head_supported (host-side check of the one-launch camera head's limits, include/unidepth_hip.h UdCameraHead) and the
+    argument validation of ud_camera_head_f32: refused descriptors never reach a launch."""
+    import ctypes as C
+    from unidepth_amd import _lib
+    lib = _lib.lib
+    assert lib.ud_camera_head_supported(None) == -1 and lib.ud_camera_head_f32(None, None) == -1
+    x = torch.zeros(32, 2048); W = torch.zeros(2048, 2048); out = torch.zeros(32, 2048); ws = torch.zeros(16, dtype=torch.int32)
+
+    def desc(**kw):
+        d = _lib.UdCameraHead()
+        d.n_phases, d.T, d.H, d.C, d.scale, d.eps, d.sync_ws = 1, 4, 8, 512, 0.125, 1e-5, ws.data_ptr()
+        ph = dict(x=x.data_ptr(), W=W.data_ptr(), out=out.data_ptr(), M=32, N=512, K=512, ldx=512, ldc=512, kind=0, ln=1)
+        ph.update(kw)
+        for k, v in ph.items():
+            setattr(d.ph[0], k, v)
+        return d
+    assert lib.ud_camera_head_supported(C.byref(desc())) == 0
+    assert lib.ud_camera_head_supported(C.byref(desc(N=2048, ldc=2048))) == 0                      # 16 columns x 512 floats = 32 KB: the slab limit
+    assert lib.ud_camera_head_supported(C.byref(desc(N=2049, ldc=2052))) == -3 and b"limits" in lib.ud_last_error()
+    assert lib.ud_camera_head_supported(C.byref(desc(K=500, ldx=512))) == -3                 # K % 128
+    assert lib.ud_camera_head_supported(C.byref(desc(K=1024, ldx=1024))) == -3               # LayerNorm phase with K > 512
+    assert lib.ud_camera_head_supported(C.byref(desc(K=1024, ldx=1024, ln=0))) == 0
+    assert lib.ud_camera_head_supported(C.byref(desc(kind=1, ldx=1536))) == 0 and lib.ud_camera_head_supported(C.byref(desc(kind=1, ldx=1024))) == -3
+    assert lib.ud_camera_head_supported(C.byref(desc(x=None))) == -1
+    d = desc(); d.n_phases = 25
+    assert lib.ud_camera_head_supported(C.byref(d)) == -1
+    d = desc(); d.sync_ws = None
+    assert lib.ud_camera_head_f32(C.byref(d), None) == -1
+    p = lib.ud_program_create()
+    assert lib.ud_program_add_camera_head(p, C.byref(desc())) == 0 and lib.ud_program_size(p) == 1
     lib.ud_program_destroy(p)
 
 

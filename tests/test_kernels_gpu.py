@@ -981,6 +981,105 @@ def test_resize_ac_and_finalize_and_transpose(ops):
     assert torch.equal(outT, xin[:, :37, :70].permute(0, 2, 1))
 
 
+def _camera_head_case(ops, B, Cc, D, H, seed=0):
+    """Random weights of a CameraHead (decoder.py:48-114) + the 4 camera_token_adapter Linears (decoder.py:34-45) in the engine's folded layout
+    (LayerNorm affines inside the following Linear, LayerScale inside out / fc2), the phase list unidepthv2.py records for them, and the same
+    chain in torch fp64."""
+    T, Mc = 4, B * 4
+    g = [seed * 100]
+
+    def r(*shape, scale=1.0):
+        g[0] += 1
+        return rnd(*shape, scale=scale, seed=g[0])
+    cls = [r(B, D) for _ in range(4)]
+    W = {f"ad{j}": (r(Cc, D, scale=D ** -0.5), r(Cc, scale=0.1)) for j in range(4)}
+    for name, (n, k) in {"p1": (Cc, Cc), "p2": (Cc, Cc), "o1": (Cc, Cc), "o2": (1, Cc)}.items():
+        W[name] = (r(n, k, scale=k ** -0.5), r(n, scale=0.1))
+    for b in ("a", "b"):
+        W[b + "qkv"] = (r(3 * Cc, Cc, scale=Cc ** -0.5), r(3 * Cc, scale=0.1))
+        W[b + "out"] = (r(Cc, Cc, scale=Cc ** -0.5), None)
+        W[b + "f1"] = (r(4 * Cc, Cc, scale=Cc ** -0.5), r(4 * Cc, scale=0.1))
+        W[b + "f2"] = (r(Cc, 4 * Cc, scale=(4 * Cc) ** -0.5), r(Cc, scale=0.1))
+    pos = r(T, Cc)
+    z = lambda *sh: torch.zeros(*sh, device="cuda")
+    ct, ch, cqkv, cao, t, raw = z(Mc, Cc), z(Mc, 4 * Cc), z(Mc, 3 * Cc), z(Mc, Cc), z(Mc, Cc), z(Mc, 1)
+    sync = torch.zeros(16, dtype=torch.int32, device="cuda")
+
+    def lin(x, name, out, M, N, K, ldx, ldc, **kw):
+        d = dict(x=x, W=W[name][0], out=out, M=M, N=N, K=K, ldx=ldx, ldc=ldc, kind=0, sync=1)
+        if W[name][1] is not None:
+            d["bias"] = W[name][1]
+        d.update(kw)
+        return d
+    ph = [lin(cls[j], f"ad{j}", ct.data_ptr() + j * Cc * 4, B, Cc, D, D, 4 * Cc, sync=int(j == 3)) for j in range(4)]
+    ph += [lin(ct, "p1", ch, Mc, Cc, Cc, Cc, 4 * Cc, ln=1, act=ops.UD_ACT_GELU), lin(ch, "p2", t, Mc, Cc, Cc, 4 * Cc, Cc)]
+    for b in ("a", "b"):
+        ph += [lin(t, b + "qkv", cqkv, Mc, 3 * Cc, Cc, Cc, 3 * Cc, ln=1, add=pos, ldadd=Cc, add_mod=T, add_cols=Cc),
+               dict(x=cqkv, out=cao, M=Mc, ldx=3 * Cc, ldc=Cc, kind=1, sync=1),
+               lin(cao, b + "out", t, Mc, Cc, Cc, Cc, Cc, accumulate=1),
+               lin(t, b + "f1", ch, Mc, 4 * Cc, Cc, Cc, 4 * Cc, ln=1, act=ops.UD_ACT_GELU),
+               lin(ch, b + "f2", t, Mc, Cc, 4 * Cc, 4 * Cc, Cc, accumulate=1)]
+    ph += [lin(t, "o1", ch, Mc, Cc, Cc, Cc, 4 * Cc, ln=1, act=ops.UD_ACT_GELU), lin(ch, "o2", raw, Mc, 1, Cc, 4 * Cc, 1, sync=0)]
+    scale = (Cc // H) ** -0.5
+
+    def ref():
+        d = lambda v: v.double()
+        ln = lambda v: F.layer_norm(v, (v.shape[-1],), eps=1e-5)
+        aff = lambda v, name: v @ d(W[name][0]).t() + (d(W[name][1]) if W[name][1] is not None else 0.0)
+        x = torch.stack([aff(d(cls[j]), f"ad{j}") for j in range(4)], 1).reshape(Mc, Cc)           # row b * 4 + j
+        x = aff(F.gelu(aff(ln(x), "p1")), "p2")
+        for b in ("a", "b"):
+            qkv = aff(ln(x), b + "qkv")
+            q = (qkv[:, :Cc] + d(pos).repeat(B, 1)).view(B, T, H, -1).transpose(1, 2)
+            k = qkv[:, Cc:2 * Cc].reshape(B, T, H, -1).transpose(1, 2)
+            v = qkv[:, 2 * Cc:].reshape(B, T, H, -1).transpose(1, 2)
+            x = x + aff((torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v).transpose(1, 2).reshape(Mc, Cc), b + "out")
+            x = x + aff(F.gelu(aff(ln(x), b + "f1")), b + "f2")
+        return x, aff(F.gelu(aff(ln(x), "o1")), "o2")
+    return ph, (ct, ch, cqkv, cao, t, raw, sync), scale, ref, (cls, W, pos)
+
+
+@pytest.mark.parametrize("B,Cc,D,H,G", [(8, 512, 1024, 8, 0), (1, 256, 384, 4, 0), (16, 384, 768, 6, 0), (3, 256, 384, 4, 64), (32, 512, 1024, 8, 0),
+                                         (8, 512, 1024, 8, 256)])
+def test_camera_head_one_launch(ops, B, Cc, D, H, G):
+    """ud_camera_head_f32: the token adapters and the CameraHead as ONE persistent-grid launch (18 phases, 14 grid barriers) against the
+    same chain in torch fp64; a second launch on the same workspace (the kernel re-arms its barrier counters) gives the same bits, no
+    barrier timed out, and the summation order does not depend on the batch: image 0 alone reproduces its rows of the batch bit for bit."""
+    ph, (ct, ch, cqkv, cao, t, raw, sync), scale, ref, keep = _camera_head_case(ops, B, Cc, D, H)
+    desc = ops.camera_head_desc(ph, 4, H, Cc, scale, 1e-5, sync, G)
+    assert ops.camera_head_supported(desc)
+    ops.camera_head(desc)
+    torch.cuda.synchronize()
+    t1, raw1 = t.clone(), raw.clone()
+    assert sync[:3].tolist() == [0, 0, 0], sync.tolist()
+    xr, rr = ref()
+    assert rel(t1, xr) < 5e-6 and (raw1.double() - rr).abs().max().item() < 2e-5 * max(1.0, rr.abs().max().item())
+    t.zero_(); raw.zero_(); ch.fill_(7.0)
+    ops.camera_head(desc)
+    torch.cuda.synchronize()
+    assert torch.equal(t, t1) and torch.equal(raw, raw1) and sync[:3].tolist() == [0, 0, 0]
+    if B > 1:
+        ph0, bufs0, _, _, keep0 = _camera_head_case(ops, 1, Cc, D, H)
+        for a, b in zip(keep0[0], keep[0]):
+            a.copy_(b[:1])
+        assert all(torch.equal(keep0[1][n][0], keep[1][n][0]) for n in keep[1])            # same seeds: the same weights
+        d0 = ops.camera_head_desc(ph0, 4, H, Cc, scale, 1e-5, bufs0[6], G)
+        ops.camera_head(d0)
+        torch.cuda.synchronize()
+        assert torch.equal(bufs0[4], t1[:4]) and torch.equal(bufs0[5], raw1[:4])
+
+
+def test_camera_head_limits(ops):
+    """Descriptors outside the kernel's limits are refused (the plan builder then records the per-layer launches)."""
+    ph, bufs, scale, _, keep = _camera_head_case(ops, 2, 512, 1024, 8)
+    bad = [dict(q) for q in ph]
+    bad[4]["K"] = 500                                                    # K % 128
+    assert not ops.camera_head_supported(ops.camera_head_desc(bad, 4, 8, 512, scale, 1e-5, bufs[6]))
+    assert not ops.camera_head_supported(ops.camera_head_desc(ph, 4, 8, 512, scale, 1e-5, bufs[6], 32))      # 64 columns x 512 floats per workgroup
+    assert not ops.camera_head_supported(ops.camera_head_desc(ph, 9, 8, 512, scale, 1e-5, bufs[6]))           # T > 8
+    assert ops.camera_head_supported(ops.camera_head_desc(ph, 4, 8, 512, scale, 1e-5, bufs[6]))
+
+
 def test_camera_fp32_island(ops):
     """fp32 linear (small M), 4-token fp32 attention and LayerNorm with fp32 output: agree with torch fp32 to round-off."""
     import ctypes as C

@@ -264,6 +264,40 @@ for arm in $ARMS; do rm -rf $O/f_$arm; done
 cat $O/tests_*.txt
 }
 
+# the camera head as one launch (UdCameraHead): kernel tests, model tests, A/B against the per-layer launches (UNIDEPTH_CAMHEAD=0, a switch
+# that exists for this session only)
+call12() {
+O=$R/gpurun_out/r5c12 && mkdir -p $O
+timeout 300 python -m pytest tests/test_kernels_gpu.py -q -x -m gpu -k "camera_head" 2>&1 | grep -v "^$\|amdgpu.ids" | tail -15 > $O/tests_kernel.txt
+if ! grep -q "passed" $O/tests_kernel.txt || grep -q "failed" $O/tests_kernel.txt; then cat $O/tests_kernel.txt; echo "kernel tests failed: stopping"; return; fi
+timeout 900 python -m pytest tests/test_infer_gpu.py tests/test_parity_gpu.py -q -x -m gpu 2>&1 | grep -v "^$\|amdgpu.ids" | tail -6 > $O/tests_model.txt
+for rep in 1 2; do
+  for arm in 1 0; do
+    UNIDEPTH_CAMHEAD=$arm timeout 600 python bench.py --no-cpu-baseline --no-extra-configs --no-kernel-timing > $O/bench_${arm}_$rep.json 2> $O/bench_${arm}_$rep.err
+    UNIDEPTH_CAMHEAD=$arm timeout 600 python bench.py --batch 1 --no-cpu-baseline --no-extra-configs --no-kernel-timing > $O/bench1_${arm}_$rep.json 2>> $O/bench_${arm}_$rep.err
+  done
+done
+( cd /tmp && export TMPDIR=/tmp
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-extra-configs --inflight 1 > $O/trace.log 2>&1 )
+grep -h "camera_head\|linear_f32\|attention_small" $O/trace/*/t_kernel_stats.csv $O/trace/t_kernel_stats.csv 2>/dev/null | cut -c1-200 > $O/camera_kernels.txt
+rm -rf $O/trace
+python - <<'P' | tee $O/ab.txt
+import json
+O = "gpurun_out/r5c12"
+for arm in ("1", "0"):
+    for name in ("bench", "bench1"):
+        v = []
+        for rep in (1, 2):
+            try:
+                d = json.loads(open(f"{O}/{name}_{arm}_{rep}.json").read().strip().splitlines()[-1])
+                v.append((d["value"], d["p50_latency_ms"]))
+            except Exception as e:
+                v.append(("failed", str(e)[:80]))
+        print("one launch" if arm == "1" else "per layer ", "bs=8" if name == "bench" else "bs=1", "(images/s two in flight, p50 ms one call):", v)
+P
+cat $O/tests_kernel.txt $O/tests_model.txt $O/camera_kernels.txt
+}
+
 # the default bench line alone (another box of the pool)
 benchonly() {
 O=gpurun_out/r5bench && mkdir -p $O

@@ -48,6 +48,19 @@ class UdLinearF32(C.Structure):
                 ("ldw", i32), ("ldc", i32), ("ldadd", i32), ("add_mod", i32), ("act", i32), ("accumulate", i32)]
 
 
+class UdCamPhase(C.Structure):
+    _fields_ = [("x", fp), ("W", fp), ("bias", fp), ("add", fp), ("out", fp), ("M", i32), ("N", i32), ("K", i32), ("ldx", i32), ("ldc", i32),
+                ("ldadd", i32), ("add_mod", i32), ("add_cols", i32), ("kind", i32), ("ln", i32), ("act", i32), ("accumulate", i32), ("sync", i32)]
+
+
+UD_CAM_MAX_PHASES = 24
+
+
+class UdCameraHead(C.Structure):
+    _fields_ = [("ph", UdCamPhase * UD_CAM_MAX_PHASES), ("n_phases", i32), ("T", i32), ("H", i32), ("C", i32), ("scale", f32), ("eps", f32),
+                ("sync_ws", vp), ("workgroups", i32)]
+
+
 class UdDwConv7(C.Structure):
     _fields_ = [("x", fp), ("w", fp), ("bias", fp), ("y", fp), ("B", i32), ("H", i32), ("W", i32), ("C", i32), ("ldx", i32), ("ldy", i32)]
 
@@ -127,6 +140,9 @@ def _load():
         "ud_linear_f32": [P(UdLinearF32), vp],
         "ud_attention_small_f32": [vp, vp, vp, i32, i32, i32, i32, f32, vp],
         "ud_program_add_linear_f32": [vp, P(UdLinearF32)],
+        "ud_camera_head_f32": [P(UdCameraHead), vp],
+        "ud_camera_head_supported": [P(UdCameraHead)],
+        "ud_program_add_camera_head": [vp, P(UdCameraHead)],
         "ud_program_add_attention_small_f32": [vp, vp, vp, vp, i32, i32, i32, i32, f32],
         "ud_preprocess_patches": [P(UdPreprocess), vp],
         "ud_fill_rows_f32": [vp, vp, i32, i32, i32, i32, i32, vp],
@@ -180,7 +196,7 @@ def _load():
     lib.ud_program_create.restype = vp
     lib.ud_last_error.argtypes = []
     lib.ud_last_error.restype = C.c_char_p
-    for i, st in enumerate([UdGemm, UdLayerNorm, UdAttention, UdPreprocess, UdRayEmbed, UdUpsample2x, UdResizeAC, UdFinalize, UdLinearF32, UdDwConv7, UdV1Op, UdKnn, UdExtractPatches]):
+    for i, st in enumerate([UdGemm, UdLayerNorm, UdAttention, UdPreprocess, UdRayEmbed, UdUpsample2x, UdResizeAC, UdFinalize, UdLinearF32, UdDwConv7, UdV1Op, UdKnn, UdExtractPatches, UdCameraHead]):
         # a library whose descriptors differ from this mirror in ANY way is a hard error (A/B runs rebuild both arms from one tree:
         # an older .so would read the appended fields -- a_wrap, row_stats_* -- as garbage or not at all)
         if lib.ud_struct_size(i) != C.sizeof(st):

@@ -28,6 +28,7 @@ extern "C" int ud_struct_size(int which) {
     case 10: return (int)sizeof(UdV1Op);
     case 11: return (int)sizeof(UdKnn);
     case 12: return (int)sizeof(UdExtractPatches);
+    case 13: return (int)sizeof(UdCameraHead);
     default: return -1;
   }
 }

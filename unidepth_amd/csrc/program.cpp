@@ -12,7 +12,7 @@
 void ud_set_error(const char* msg);
 
 namespace {
-enum Kind { K_LIN32, K_ATTS, K_GEMM, K_LN, K_ATTN, K_PRE, K_FILL, K_CAM, K_RAYS, K_RAYS_CAM, K_EMBED, K_UP2, K_RESIZE, K_FINAL, K_T, K_DW7, K_LNP2, K_PATCH4, K_MAX, K_MEAN, K_V1, K_RSF };
+enum Kind { K_LIN32, K_ATTS, K_GEMM, K_LN, K_ATTN, K_PRE, K_FILL, K_CAM, K_RAYS, K_RAYS_CAM, K_EMBED, K_UP2, K_RESIZE, K_FINAL, K_T, K_DW7, K_LNP2, K_PATCH4, K_MAX, K_MEAN, K_V1, K_RSF, K_CAMHEAD };
 struct FillArgs { float* dst; const float* src; int n_img, rows_per_img, row_off, D, ld; };
 struct CamArgs { const float* raw; int raw_stride; float* intr4; float* K33; float* Kinv33; float* Kpost33; int B, Hn, Wn; float rf; int pad_l, pad_t; };
 struct RaysArgs { const float* Kinv33; float* rays; int nb, Hn, Wn, gt_mode; };
@@ -29,7 +29,7 @@ struct Op {
   union {
     UdGemm gemm; UdLayerNorm ln; UdAttention attn; UdPreprocess pre; FillArgs fill; CamArgs cam; RaysArgs rays; RaysCamArgs rays_cam;
     UdRayEmbed embed; UdUpsample2x up2; UdResizeAC resize; UdFinalize fin; TArgs t; UdLinearF32 lin32; AttSArgs atts;
-    UdDwConv7 dw7; UdV1Op v1; LnP2Args lnp2; Patch4Args patch4; MaxArgs mx; MeanArgs mean; RsfArgs rsf;
+    UdDwConv7 dw7; UdV1Op v1; int camhead; LnP2Args lnp2; Patch4Args patch4; MaxArgs mx; MeanArgs mean; RsfArgs rsf;
   };
   Op() {}
 };
@@ -37,6 +37,7 @@ struct Op {
 
 struct UdProgram {
   std::vector<Op> ops;
+  std::vector<UdCameraHead> camheads;      // 2.4 KB descriptors: kept beside the op list (an Op holds the index)
 };
 
 extern "C" {
@@ -102,6 +103,11 @@ int ud_program_add_spatial_mean(UdProgram* p, const float* x, float* out, int B,
 }
 
 int ud_program_add_v1_op(UdProgram* p, const UdV1Op* d) { ADD(K_V1, v1, *d) }
+int ud_program_add_camera_head(UdProgram* p, const UdCameraHead* d) {
+  if (!p || !d) return UD_ERR_BAD_ARG;
+  p->camheads.push_back(*d);
+  ADD(K_CAMHEAD, camhead, (int)p->camheads.size() - 1)
+}
 int ud_program_add_row_stats_finalize(UdProgram* p, const float* partials, float* stats, int M, int slabs, int D, float eps) {
   RsfArgs a = {partials, stats, M, slabs, D, eps};
   ADD(K_RSF, rsf, a)
@@ -129,6 +135,7 @@ int ud_program_run(const UdProgram* p, int first, int last, void* stream) {
       case K_FINAL: rc = ud_finalize_outputs(&op.fin, cur); break;
       case K_DW7: rc = ud_dwconv7_nhwc_f32(&op.dw7, cur); break;
       case K_V1: rc = ud_v1_op(&op.v1, cur); break;
+      case K_CAMHEAD: rc = ud_camera_head_f32(&p->camheads[op.camhead], cur); break;
       case K_LNP2: rc = ud_layernorm_patchify2(op.lnp2.x, op.lnp2.out, op.lnp2.B, op.lnp2.H, op.lnp2.W, op.lnp2.C, op.lnp2.ldo, op.lnp2.eps, cur); break;
       case K_PATCH4: rc = ud_patchify4_nchw(op.patch4.img, op.patch4.out, op.patch4.B, op.patch4.H, op.patch4.W, op.patch4.ldo, cur); break;
       case K_MAX: rc = ud_max_f32(op.mx.dst, op.mx.src, op.mx.n, op.mx.init, cur); break;

@@ -10,7 +10,7 @@ import torch
 from . import _lib
 from ._lib import (UD_A_CONV3_REFLECT, UD_A_CONV3_REFLECT_UP, UD_A_CONV3_ZERO, UD_A_DENSE, UD_ACT_GELU, UD_ACT_LRELU, UD_ACT_NONE,  # noqa: F401
                    UD_EPI_D2S, UD_EPI_F16, UD_EPI_F32, UD_EPI_HEAD, UD_EPI_QKV, UdAttention, UdFinalize, UdGemm,
-                   UdDwConv7, UdLayerNorm, UdLinearF32, UdPreprocess, UdRayEmbed, UdResizeAC, UdUpsample2x, check, lib)
+                   UdCameraHead, UdCamPhase, UdDwConv7, UdLayerNorm, UdLinearF32, UdPreprocess, UdRayEmbed, UdResizeAC, UdUpsample2x, check, lib)
 
 
 def ptr(t):
@@ -36,6 +36,27 @@ def mk(struct, **kw):
             v = (C.c_float * len(v))(*v)
         setattr(d, k, v)
     return d
+
+
+def camera_head_desc(phases, T, H, Cc, scale, eps, sync_ws, workgroups=0):
+    """UdCameraHead from a list of phase dicts (UdCamPhase fields; tensors become device pointers, an int is a raw address)."""
+    d = UdCameraHead()
+    assert len(phases) <= len(d.ph), "too many phases for UdCameraHead"
+    for i, ph in enumerate(phases):
+        for k, v in ph.items():
+            setattr(d.ph[i], k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    d.n_phases, d.T, d.H, d.C, d.scale, d.eps, d.workgroups = len(phases), T, H, Cc, scale, eps, workgroups
+    d.sync_ws = sync_ws.data_ptr() if isinstance(sync_ws, torch.Tensor) else sync_ws
+    return d
+
+
+def camera_head_supported(desc) -> bool:
+    """Inside the limits of the one-launch camera head (include/unidepth_hip.h UdCameraHead)?  Host-side check, nothing is launched."""
+    return lib.ud_camera_head_supported(C.byref(desc)) == 0
+
+
+def camera_head(desc):
+    check(lib.ud_camera_head_f32(C.byref(desc), cur_stream()), "ud_camera_head_f32")
 
 
 def v1_desc(kind, a=None, b=None, c=None, out=None, out2=None, i=(), f=()):
@@ -167,6 +188,11 @@ class Program:
     def linear_f32(self, **kw):
         self._k(kw, "camera_f32", 2.0 * kw["M"] * kw["N"] * kw["K"], 4.0 * kw["N"] * kw["K"])
         return check(lib.ud_program_add_linear_f32(self.h, C.byref(mk(UdLinearF32, **kw))))
+
+    def camera_head(self, desc, keep=(), flops=0.0, nbytes=0.0):
+        self.keep.extend(keep)
+        self.meta.append(("camera_f32", "cam.head", float(flops), float(nbytes)))
+        return check(lib.ud_program_add_camera_head(self.h, C.byref(desc)))
 
     def attention_small_f32(self, q, kv, out, B, T, H, Cc, scale):
         self.keep += [q, kv, out]

@@ -234,42 +234,73 @@ class _Plan:
             for j in range(4):
                 tap(f"input_adapter.{j}", lambda j=j: feat_all[j].view(B, hwp, C)[:, :hw].clone())
         feature_branch_head()
-        for j in range(4):
-            P.linear_f32(x=clsn[j], W=w[f"dec.camadapter.{j}.w"], bias=w[f"dec.camadapter.{j}.b"], out=ct.data_ptr() + j * C * 4,
-                         M=B, N=C, K=D, ldx=D, ldw=D, ldc=4 * C, tag="cam.adapter")
-        # ---- camera head (decoder.py:48-114) on the 4 camera tokens per image: an fp32 island (UdLinearF32 explains why)
+        # ---- camera token adapters + camera head (decoder.py:34-45,48-114) on the 4 camera tokens per image: an fp32 island (UdLinearF32
+        # explains why).  ONE launch (UdCameraHead: a persistent grid walks the ~18 dependent layers as phases between grid barriers) where
+        # the kernel's limits allow it, otherwise the per-layer launches it replaces (same arithmetic, ~26 launches).
         Mc = B * 4
-        cn = z(Mc, C, dtype=f32); ch = z(Mc, 4 * C, dtype=f32); cq = z(Mc, C, dtype=f32); ckv = z(Mc, 2 * C, dtype=f32)
-        cao = z(Mc, C, dtype=f32); t = z(Mc, C, dtype=f32); raw = z(Mc, 1, dtype=f32)
+        ch = z(Mc, 4 * C, dtype=f32); cqkv = z(Mc, 3 * C, dtype=f32); cao = z(Mc, C, dtype=f32); t = z(Mc, C, dtype=f32); raw = z(Mc, 1, dtype=f32)
         scale_d = meta["hd"] ** -0.5
+        self.cam_sync = z(16, dtype=torch.int32)
+
+        def lin(x, pre, out, M, N, K, ldx, ldc, **kw):
+            d = dict(x=x, W=w[pre + ".w"], out=out, M=M, N=N, K=K, ldx=ldx, ldc=ldc, kind=0, sync=1)
+            if kw.pop("bias", True):
+                d["bias"] = w[pre + ".b"]
+            d.update(kw)
+            return d
+
+        phases = [lin(clsn[j], f"dec.camadapter.{j}", ct.data_ptr() + j * C * 4, B, C, D, D, 4 * C, sync=int(j == 3)) for j in range(4)]
+
+        def mlp_phases(pre, src, dst, accumulate, n_out=C):
+            nh = w[pre + "fc1.w"].shape[0]
+            return [lin(src, pre + "fc1", ch, Mc, nh, C, C, 4 * C, ln=1, act=UD_ACT_GELU),
+                    lin(ch, pre + "fc2", dst, Mc, n_out, nh, 4 * C, n_out if n_out == 1 else C, accumulate=accumulate)]
+
+        phases += mlp_phases("cam.project.", ct, t, 0)
+        for blk in ("cam.agg1.", "cam.agg2."):
+            phases += [lin(t, blk + "qkv", cqkv, Mc, 3 * C, C, C, 3 * C, ln=1, add=w["cam.pos"], ldadd=C, add_mod=4, add_cols=C),   # norm_attnx / norm_attnctx share statistics
+                       dict(x=cqkv, out=cao, M=Mc, ldx=3 * C, ldc=C, kind=1, sync=1),
+                       lin(cao, blk + "out", t, Mc, C, C, C, C, accumulate=1, bias=False)]
+            phases += mlp_phases(blk, t, t, 1)
+        phases += mlp_phases("cam.out.", t, raw, 0, n_out=1)
+        phases[-1]["sync"] = 0
+        head = ops.camera_head_desc(phases, 4, Hd, C, scale_d, 1e-5, self.cam_sync)
+        if ops.camera_head_supported(head):
+            nw = sum(ph["N"] * ph["K"] for ph in phases if ph["kind"] == 0)
+            P.camera_head(head, keep=[*clsn, ct, ch, cqkv, cao, t, raw, self.cam_sync], flops=2.0 * Mc * nw, nbytes=4.0 * nw)
+        else:
+            cn = z(Mc, C, dtype=f32); cq = z(Mc, C, dtype=f32); ckv = z(Mc, 2 * C, dtype=f32)
+            for j in range(4):
+                P.linear_f32(x=clsn[j], W=w[f"dec.camadapter.{j}.w"], bias=w[f"dec.camadapter.{j}.b"], out=ct.data_ptr() + j * C * 4,
+                             M=B, N=C, K=D, ldx=D, ldw=D, ldc=4 * C, tag="cam.adapter")
+
+            def ln32(src, dst, rows):
+                P.layernorm(x=src, y=dst, rows=rows, D=C, ldx=C, ldy=C, eps=1e-5, rows_per_img=rows, in_rows_per_img=rows,
+                            out_rows_per_img=rows, out_f32=1)
+
+            def lin32(xb, pre, out, n, k, ldx, ldc, act=UD_ACT_NONE, accumulate=0, bias=True, **kw):
+                P.linear_f32(x=xb, W=w[pre + ".w"], out=out, M=Mc, N=n, K=k, ldx=ldx, ldw=k, ldc=ldc, act=act, accumulate=accumulate,
+                             tag="cam." + pre, **({"bias": w[pre + ".b"]} if bias else {}), **kw)
+
+            def mlp32(pre, stream, out, accumulate, n_out=C):
+                ln32(stream, cn, Mc)
+                nh = w[pre + "fc1.w"].shape[0]
+                lin32(cn, pre + "fc1", ch, nh, C, C, nh, act=UD_ACT_GELU)
+                lin32(ch, pre + "fc2", out, n_out, nh, nh, n_out if n_out == 1 else C, accumulate=accumulate)
+
+            mlp32("cam.project.", ct, t, 0)
+            for blk in ("cam.agg1.", "cam.agg2."):
+                ln32(t, cn, Mc)                                                   # norm_attnx and norm_attnctx share statistics
+                lin32(cn, blk + "q", cq, C, C, C, C, add=w["cam.pos"], ldadd=C, add_mod=4)
+                lin32(cn, blk + "kv", ckv, 2 * C, C, C, 2 * C)
+                P.attention_small_f32(cq, ckv, cao, B, 4, Hd, C, scale_d)
+                lin32(cao, blk + "out", t, C, C, C, C, accumulate=1, bias=False)
+                mlp32(blk, t, t, 1)
+            mlp32("cam.out.", t, raw, 0, n_out=1)
 
         def ln(src, dst, rows, dim=C):
             P.layernorm(x=src, y=dst, rows=rows, D=dim, ldx=dim, ldy=dim, eps=1e-5, rows_per_img=rows, in_rows_per_img=rows,
                         out_rows_per_img=rows)
-
-        def ln32(src, dst, rows):
-            P.layernorm(x=src, y=dst, rows=rows, D=C, ldx=C, ldy=C, eps=1e-5, rows_per_img=rows, in_rows_per_img=rows,
-                        out_rows_per_img=rows, out_f32=1)
-
-        def lin32(xb, pre, out, n, k, ldx, ldc, act=UD_ACT_NONE, accumulate=0, bias=True, **kw):
-            P.linear_f32(x=xb, W=w[pre + ".w"], out=out, M=Mc, N=n, K=k, ldx=ldx, ldw=k, ldc=ldc, act=act, accumulate=accumulate,
-                         tag="cam." + pre, **({"bias": w[pre + ".b"]} if bias else {}), **kw)
-
-        def mlp32(pre, stream, out, accumulate, n_out=C):
-            ln32(stream, cn, Mc)
-            nh = w[pre + "fc1.w"].shape[0]
-            lin32(cn, pre + "fc1", ch, nh, C, C, nh, act=UD_ACT_GELU)
-            lin32(ch, pre + "fc2", out, n_out, nh, nh, n_out if n_out == 1 else C, accumulate=accumulate)
-
-        mlp32("cam.project.", ct, t, 0)
-        for blk in ("cam.agg1.", "cam.agg2."):
-            ln32(t, cn, Mc)                                                   # norm_attnx and norm_attnctx share statistics
-            lin32(cn, blk + "q", cq, C, C, C, C, add=w["cam.pos"], ldadd=C, add_mod=4)
-            lin32(cn, blk + "kv", ckv, 2 * C, C, C, 2 * C)
-            P.attention_small_f32(cq, ckv, cao, B, 4, Hd, C, scale_d)
-            lin32(cao, blk + "out", t, C, C, C, C, accumulate=1, bias=False)
-            mlp32(blk, t, t, 1)
-        mlp32("cam.out.", t, raw, 0, n_out=1)
 
         def mlp(pre, stream, rows, nrm, hidbuf, out=None, accumulate=1, out2=None, act2=UD_ACT_NONE, n_out=C, ldc=C):
             ln(stream, nrm, rows)

@@ -175,6 +175,8 @@ def pack(config: dict, sd: dict, device) -> dict:
         wkv, bkv = _fold_ln(f[src + "kv.weight"], None, f[src + "norm_attnctx.weight"], f[src + "norm_attnctx.bias"])
         put32(dst + "kv.w", wkv); put32(dst + "kv.b", bkv)
         put32(dst + "out.w", f[src + "out.weight"] * f[src + "ls1.gamma"][:, None])
+        # one [q | k | v] projection for the one-launch camera head (UdCameraHead: both read the same normalised rows)
+        put32(dst + "qkv.w", torch.cat([wq, wkv], 0)); put32(dst + "qkv.b", torch.cat([bq, bkv], 0))
         mlp32(src + "mlp.", dst, ls=f[src + "ls2.gamma"])
 
     cl = pd + "camera_layer."
