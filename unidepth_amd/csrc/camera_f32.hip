@@ -127,8 +127,8 @@ __global__ __launch_bounds__(64) void attention_small_kernel(const float* q, con
 // 256 threads: lane & 31 = K slice (float4 groups q = 32 i + slice of a row: 512 B contiguous per row and instruction), (lane >> 5) + 2 wave =
 // row group rq: a thread owns rows rq + 8 j (j < 4) of a 32-row block, so one weight fragment read from LDS feeds four rows.  A workgroup
 // owns ceil(N / G) output columns of a phase; their weights (a contiguous slab of W) were copied into LDS by global_load_lds during the
-// previous phase.  Per output: four rows x 4 FMAs per fragment in k order inside the slice, then a 32-lane butterfly -- a fixed summation
-// order that does not depend on the row's position, the batch size or the grid size.
+// previous phase.  Per output: four rows x 4 FMAs per fragment in k order inside the slice, then a fixed reduction tree over the 32 slices -- a
+// summation order that does not depend on the row's position, the batch size or the grid size.
 // ================================================================================================================
 constexpr int CH_SLAB = 32 * 1024;             // bytes of one weight slab
 constexpr int CH_LDS = 96 * 1024;              // two slabs; more than half a CU's LDS, so a CU holds one of these workgroups
@@ -144,12 +144,6 @@ __device__ __forceinline__ float ch_ld1(ud_rsrc_t r, unsigned byte_off) {
 __device__ __forceinline__ void ch_st1(ud_rsrc_t r, unsigned byte_off, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)byte_off, 0, CH_SYS);
 }
-__device__ __forceinline__ float ch_sum32(float v) {          // over the 32 lanes of a half wave (lane bit 5 untouched)
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-
 __device__ __forceinline__ void ch_sum32x4(float (&v)[4]) {     // four independent sums: the shuffles of a step are in flight together
 #pragma unroll
   for (int o = 16; o > 0; o >>= 1) {
