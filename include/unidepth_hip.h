@@ -381,10 +381,13 @@ int ud_spatial_mean_f32(const float* x, float* out, int B, int HW, int C, int ld
  *  VIT_TAP       UniDepthV1 on a DINOv2 backbone: out = init ? v : max(out, v), v = patch tokens + class token of the block whose residual
  *                stream is a [B*Np, D] (row 0 of an image = class token): unidepthv1.py:324-328 + decoder.py:366-373 max_stack; out2
  *                (optional) = the raw class tokens [B, D].  i = B, Np, hw, D, init
+ *  OUT_CONV3     out[pixel, 0] = exp(clamp(conv3x3(x)[pixel] + f[0], -10, 10)) for ONE output channel, zero padding, everything fp32: the multi-scale
+ *                outputs out8 / out4 / out2 (unidepthv1/decoder.py:185-187 nn.Conv2d(C, 1, 3, padding = 1), :250-298).  a = x NHWC [B, H, W, C],
+ *                b = w [9, C] (tap = ky * 3 + kx), out [B * H * W, ldo].  i = B, H, W, C (% 4 == 0), ldo
  *  PREPROCESS    V1 network image (unidepthv1.py:305-321,50-56): [/255], ImageNet normalise, antialiased resize to (h, w), zero pad to (Hn, Wn).
  *                i = B, H, W, h, w, Hn, Wn, pad_l, pad_t, is_u8, div255, normalize */
 enum { UD_V1_RESIZE_AA = 1, UD_V1_SH_EMBED = 2, UD_V1_SOFTMAX = 3, UD_V1_ATTN_FEWQ = 4, UD_V1_HEAD_MIX = 5, UD_V1_ADD = 8, UD_V1_COPY_ROWS = 9,
-       UD_V1_CAMERA = 11, UD_V1_POINTS = 12, UD_V1_MEAN3 = 13, UD_V1_PREPROCESS = 14, UD_V1_VIT_TAP = 15, UD_V1_RESIZE_AC_SPLIT = 17 };
+       UD_V1_CAMERA = 11, UD_V1_POINTS = 12, UD_V1_MEAN3 = 13, UD_V1_PREPROCESS = 14, UD_V1_VIT_TAP = 15, UD_V1_RESIZE_AC_SPLIT = 17, UD_V1_OUT_CONV3 = 18 };
 typedef struct UdV1Op {
   int kind;
   const void* a; const void* b; void* c; void* out; void* out2;

@@ -339,7 +339,7 @@ def test_v1_three_term_product_layout_removes_the_activation_rounding():
     assert ((r[:, :, 0] + r[:, :, 2]) - want).abs().max() < 2 ** -20 * want.abs().max()
     pk = U._padk16(U._conv3_rows_3(torch.randn(8, 64, 3, 3, generator=g)), split=False)
     assert U._wk(pk, 0, 64) == dict(K=pk.shape[1], ldw=pk.shape[1], Cin=192, a_wrap=128)
-    # the packed decoder: three-term layout on up*.up.0 / up*.up.2 / out*, two-term elsewhere
+    # the packed decoder: three-term layout on up*.up.0 / up*.up.2, two-term elsewhere
     from oracle import synth_v1
     assert U.ASPLIT
     cfg = synth_v1.load_config_v1()
@@ -349,8 +349,13 @@ def test_v1_three_term_product_layout_removes_the_activation_rounding():
         assert wd[f"{nm}.up0.w"].shape == (d // 2, 3 * d) and U._wk(wd[f"{nm}.up0.w"], d)["a_wrap"] == 2 * d
         assert U._wk(wd[f"{nm}.up2.w"], 0, d // 2) == dict(K=27 * (d // 2), ldw=27 * (d // 2), Cin=3 * (d // 2), a_wrap=d)
         assert U._wk(wd[f"{nm}.0.fc2.w"], 4 * d)["a_wrap"] == 4 * d                         # the CvnxtBlocks in front keep two terms
+    sd = synth_v1.make_synthetic_checkpoint_v1(cfg, 211)
     for nm, d in (("out8", C // 2), ("out4", C // 4), ("out2", C // 8)):
-        assert U._wk(wd[f"{nm}.w"], 0, d)["Cin"] == 3 * d
+        # the three one-channel output convs are an fp32 stencil (UD_V1_OUT_CONV3): weights [tap = ky * 3 + kx, c], the bias on the host
+        wt = sd[f"pixel_decoder.depth_layer.{nm}.weight"]
+        assert wd[f"{nm}.cw"].shape == (9, d) and wd[f"{nm}.cw"].dtype == torch.float32
+        assert torch.equal(wd[f"{nm}.cw"][4], wt[0, :, 1, 1].float()) and torch.equal(wd[f"{nm}.cw"][2], wt[0, :, 0, 2].float())
+        assert wd[f"host.{nm}.bias"] == float(sd[f"pixel_decoder.depth_layer.{nm}.bias"][0]) and f"{nm}.w" not in wd
 
 
 def test_v1_every_gemm_weight_is_two_terms_by_default():
@@ -476,7 +481,7 @@ def test_v1_plan_builder_dry_run_validates_every_gemm_descriptor(monkeypatch):
     bad = [r for r in seen if r[0] != -2]                     # -2 = UD_ERR_LAUNCH (include/unidepth_hip.h)
     assert not bad, bad[:3]                                    # UD_ERR_BAD_ARG would mean a descriptor the kernels refuse
     three = [r for r in seen if r[5] and (3 * r[5] == 2 * r[4] or (r[6] and 3 * r[5] == 2 * r[6]))]
-    assert len(three) == 9, three                              # up{8,4,2}.up.0, up{8,4,2}.up.2, out{8,4,2}
+    assert len(three) == 6, three                              # up{8,4,2}.up.0, up{8,4,2}.up.2 (out{8,4,2} are an fp32 stencil since round 5)
 
 
 def test_v2_plan_builder_dry_run_order_and_descriptors(monkeypatch):

@@ -23,6 +23,28 @@ def rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
+@pytest.mark.parametrize("B,H,W,C", [(2, 60, 80, 256), (1, 17, 45, 64), (3, 8, 32, 128), (1, 5, 3, 20), (2, 33, 70, 96)])
+def test_out_conv3_stencil(ops, B, H, W, C):
+    """UD_V1_OUT_CONV3: nn.Conv2d(C, 1, 3, padding=1) + exp(clamp(., -10, 10)) (unidepthv1/decoder.py:185-187,296-298) as an fp32 stencil over the
+    NHWC map: against torch fp64 to fp32 round-off -- tiles that cross the right / bottom border, channel counts that are not a multiple of
+    the 32-channel chunk, and the clamp."""
+    from unidepth_amd import _lib as L
+    g = torch.Generator().manual_seed(C + H)
+    x = (torch.randn(B, H, W, C, generator=g) * 1.5).cuda()
+    w = (torch.randn(1, C, 3, 3, generator=g) * (9 * C) ** -0.5).cuda()
+    bias = 0.37
+    if C == 64:
+        x[0, 3, 4] = 40.0; x[0, 9, 20] = -40.0                 # drive a few outputs into the clamp on both sides
+    o = torch.full((B * H * W, 4), -7.0, device="cuda")
+    ops.v1_op(L.UD_V1_OUT_CONV3, a=x, b=w[0].permute(1, 2, 0).reshape(9, C).contiguous(), out=o, i=(B, H, W, C, 4), f=(bias,))
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1)[:, 0] + bias
+    ref = ref.clamp(-10.0, 10.0).exp().reshape(-1)
+    got = o[:, 0].double()
+    assert ((got - ref).abs() / ref).max().item() < 2e-5, ((got - ref).abs() / ref).max().item()
+    assert bool((o[:, 1:] == -7.0).all())                       # only column 0 is written
+
+
 @pytest.mark.parametrize("B,H,W,C", [(2, 13, 21, 192), (1, 7, 9, 1536), (1, 30, 8, 384), (1, 3, 50, 64)])
 def test_dwconv7(ops, B, H, W, C):
     import ctypes

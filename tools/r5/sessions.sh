@@ -298,6 +298,20 @@ P
 cat $O/tests_kernel.txt $O/tests_model.txt $O/camera_kernels.txt
 }
 
+# UniDepthV1: the one-channel output convs as an fp32 stencil (UD_V1_OUT_CONV3): kernel test, V1 tests, parity sweep (V1 cases), bench + trace
+call13() {
+O=$R/gpurun_out/r5c13 && mkdir -p $O
+timeout 300 python -m pytest tests/test_v1_gpu.py -q -x -m gpu -k "out_conv3" 2>&1 | grep -v "^$\|amdgpu.ids" | tail -8 > $O/tests_kernel.txt
+if ! grep -q "passed" $O/tests_kernel.txt || grep -q "failed" $O/tests_kernel.txt; then cat $O/tests_kernel.txt; echo "kernel tests failed: stopping"; return; fi
+timeout 900 python -m pytest tests/test_v1_gpu.py -q -x -m gpu 2>&1 | grep -v "^$\|amdgpu.ids" | tail -6 > $O/tests_v1.txt
+timeout 900 python -m pytest tests/test_parity_sweep_gpu.py -q -s -m gpu -k "v1" 2>&1 | grep -v "^$\|amdgpu.ids" | tail -60 > $O/sweep_v1.txt
+( cd /tmp && export TMPDIR=/tmp
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/v1trace -o v -- python $R/tools/bench_v1.py 16 --no-cpu > $O/v1_breakdown.txt 2>&1 )
+cp $O/v1trace/*/v_kernel_stats.csv $O/v1_kernel_stats.csv 2>/dev/null || cp $O/v1trace/v_kernel_stats.csv $O/v1_kernel_stats.csv 2>/dev/null
+rm -rf $O/v1trace
+cat $O/tests_kernel.txt $O/tests_v1.txt; tail -25 $O/sweep_v1.txt; grep -v "^W2\|^E2\|^I2" $O/v1_breakdown.txt | cut -c1-200 | head -40
+}
+
 # the default bench line alone (another box of the pool)
 benchonly() {
 O=gpurun_out/r5bench && mkdir -p $O

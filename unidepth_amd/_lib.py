@@ -83,6 +83,7 @@ class UdExtractPatches(C.Structure):
 (UD_V1_ADD, UD_V1_COPY_ROWS) = (8, 9)
 (UD_V1_CAMERA, UD_V1_POINTS, UD_V1_MEAN3, UD_V1_PREPROCESS, UD_V1_VIT_TAP) = range(11, 16)
 UD_V1_RESIZE_AC_SPLIT = 17
+UD_V1_OUT_CONV3 = 18
 UD_ACT_CLAMPEXP = 3
 
 

@@ -587,6 +587,67 @@ inline unsigned grid1(long long total, int cap = 256 * 32) {
   return (unsigned)(g < 1 ? 1 : g);
 }
 
+
+// 3x3 convolution to ONE output channel, zero padding, then exp(clamp(., -10, 10)): the multi-scale outputs out8 / out4 / out2 of UniDepthV1
+// (unidepthv1/decoder.py:185-187 nn.Conv2d(C, 1, 3, padding=1), :250-298).  With one output channel there is nothing for a matrix tile to do (the
+// MFMA form ran three launches at 14 TFLOP/s-equivalent on 32-column tiles, behind a pass that split the fp32 maps into fp16 [hi | lo] pairs):
+// this is a stencil over the fp32 map itself -- exact fp32 products, HBM-bound (every input pixel is read ~1.3 times).
+// A workgroup owns 8 x 32 output pixels (one per thread); per chunk of 32 channels the 10 x 34 halo tile is staged in LDS (128 B per pixel,
+// rows padded by 16 B so the b128 reads of 8 neighbouring pixels cover the 32 banks) beside the chunk's 9 x 32 weights.
+constexpr int OC_TH = 8, OC_TW = 32, OC_CC = 32;
+constexpr int OC_HW = OC_TW + 2;
+constexpr int OC_HP = (OC_TH + 2) * OC_HW;
+constexpr int OC_LD = OC_CC + 4;
+__global__ __launch_bounds__(256) void out_conv3_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ out, int H, int W, int C, int ldo,
+                                                         float bias, int tiles_x, int tiles_y) {
+  __shared__ __attribute__((aligned(16))) float xs[OC_HP * OC_LD];
+  __shared__ __attribute__((aligned(16))) float ws[9 * OC_CC];
+  const int tid = threadIdx.x;
+  int t = blockIdx.x;
+  const int tx = t % tiles_x; t /= tiles_x;
+  const int ty = t % tiles_y;
+  const int b = t / tiles_y;
+  const int y0 = ty * OC_TH, x0 = tx * OC_TW;
+  const int py = tid >> 5, px = tid & 31;
+  const float* xb = x + (size_t)b * H * W * C;
+  float acc = 0.f;
+  for (int c0 = 0; c0 < C; c0 += OC_CC) {
+    __syncthreads();                                           // the previous chunk has been consumed
+    for (int idx = tid; idx < OC_HP * 8; idx += 256) {
+      const int pix = idx >> 3, piece = idx & 7;
+      const int hy = pix / OC_HW, hx = pix - hy * OC_HW;
+      const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+      const int c = c0 + piece * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gy >= 0 && gy < H && gx >= 0 && gx < W && c < C) v = *(const f32x4*)(xb + ((size_t)gy * W + gx) * C + c);
+      *(f32x4*)(xs + pix * OC_LD + piece * 4) = v;
+    }
+    if (tid < 72) {
+      const int tap = tid >> 3, piece = tid & 7;
+      const int c = c0 + piece * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (c < C) v = *(const f32x4*)(w + (size_t)tap * C + c);
+      *(f32x4*)(ws + tap * OC_CC + piece * 4) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const float* xp = xs + ((py + dy) * OC_HW + px + dx) * OC_LD;
+        const float* wp = ws + (dy * 3 + dx) * OC_CC;
+#pragma unroll
+        for (int c4 = 0; c4 < OC_CC / 4; ++c4) {
+          const f32x4 xv = *(const f32x4*)(xp + c4 * 4);
+          const f32x4 wv = *(const f32x4*)(wp + c4 * 4);
+          acc = fmaf(xv[0], wv[0], acc); acc = fmaf(xv[1], wv[1], acc); acc = fmaf(xv[2], wv[2], acc); acc = fmaf(xv[3], wv[3], acc);
+        }
+      }
+  }
+  const int gy = y0 + py, gx = x0 + px;
+  if (gy < H && gx < W) out[((size_t)b * H * W + (size_t)gy * W + gx) * ldo] = ud_clampexp(acc + bias);
+}
+
 }  // namespace
 
 // UniDepthV1 on a DINOv2 backbone: what the decoder consumes of block i is max over the blocks of its level of (patch tokens + class token)
@@ -699,6 +760,15 @@ extern "C" int ud_v1_op(const UdV1Op* desc, void* stream) {
       hipLaunchKernelGGL(resize_ac_split_kernel, dim3(grid1((long long)i[0] * i[3] * i[4] * (i[5] >> 2))), dim3(256), 0, s, (const float*)d.a, (half_t*)d.out, i[0], i[1], i[2],
                          i[3], i[4], i[5]);
       UD_CHECK_LAUNCH("ud_v1_op(resize_ac_split) launch");
+      return UD_OK;
+    }
+    case UD_V1_OUT_CONV3: {      // a = x fp32 NHWC [B, H, W, C]; b = w fp32 [9, C] (tap = ky * 3 + kx); out fp32 [B*H*W, ldo] (column 0 written); i = B, H, W, C, ldo; f[0] = bias
+      if (!d.a || !d.b || !d.out || i[0] <= 0 || i[1] <= 0 || i[2] <= 0 || i[3] <= 0 || (i[3] & 3) || i[4] <= 0) break;
+      const int tiles_x = (i[2] + OC_TW - 1) / OC_TW, tiles_y = (i[1] + OC_TH - 1) / OC_TH;
+      if ((long long)i[0] * tiles_x * tiles_y > 0x7fffffffLL) break;
+      hipLaunchKernelGGL(out_conv3_kernel, dim3(i[0] * tiles_x * tiles_y), dim3(256), 0, s, (const float*)d.a, (const float*)d.b, (float*)d.out, i[1], i[2], i[3], i[4],
+                         d.f[0], tiles_x, tiles_y);
+      UD_CHECK_LAUNCH("ud_v1_op(out_conv3) launch");
       return UD_OK;
     }
     case UD_V1_COPY_ROWS: {      // a = src fp32 [n_img*T, D]; out rows (img*rows_per_img + row_off + t), stride ld; i = n_img, T, rows_per_img, row_off, D, ld, to_f16
