@@ -358,7 +358,7 @@ int ud_spatial_mean_f32(const float* x, float* out, int B, int HW, int C, int ld
  *  SH_EMBED      rays [nb,3,Hn,Wn] -> antialiased resize to (h, w), F.normalize, 81 real spherical harmonics (utils/sht.py:833 rsh_cart_8),
  *                LayerNorm statistics (eps f[0]) -> fp16 [nb*rows_per_img, ldo >= 128] (decoder.py:205-222).  i = nb, Hn, Wn, h, w, ldo, rows_per_img
  *  SOFTMAX       out[r, :N] = softmax(f[0] * a[r, :N]) rows of fp32 scores -> fp16 (or fp32), pad columns N..ldo zero (the softmax inside
- *                F.scaled_dot_product_attention for single-head width-512 attention, layers/attention.py:136; Nystrom kernels).
+ *                F.scaled_dot_product_attention for single-head width-512 attention, layers/attention.py:136).
  *                i = rows & 0x7fffffff, N, ldi, ldo, out_f32, rows >> 31
  *  ATTN_FEWQ     T <= 8 queries against Nk keys, ONE head of width D (camera head `aggregate`, decoder.py:94, layers/attention.py:81-165):
  *                a = q fp32 [B*T, D], b = kv fp16 [B*Nk, 2D] = [K | V], out fp32 [B*T, D].  i = B, T, Nk, D; f[0] = scale
