@@ -217,7 +217,7 @@ typedef struct UdCameraHead {
   int T, H, C;           /* attention phases: tokens per image, heads, width (head width C / H) */
   float scale, eps;      /* softmax scale; LayerNorm eps */
   unsigned* sync_ws;     /* 16 words, zero before the FIRST launch; every launch leaves words 0 and 1 zero again.  Word 2 != 0 afterwards: a
-                          * grid barrier timed out (~1 s: the grid was not co-resident) and the outputs are invalid */
+                          * grid barrier timed out (seconds: the grid was not co-resident) and the outputs are invalid */
   int workgroups;        /* 0 = default (128) */
 } UdCameraHead;
 int ud_camera_head_f32(const UdCameraHead* desc, void* stream);

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64) void attention_small_kernel(const float* q, con
 // ================================================================================================================
 constexpr int CH_SLAB = 32 * 1024;             // bytes of one weight slab
 constexpr int CH_LDS = 96 * 1024;              // two slabs; more than half a CU's LDS, so a CU holds one of these workgroups
-constexpr unsigned CH_SPIN_LIMIT = 1u << 22;   // x s_sleep(4) ~ 1 s
+constexpr unsigned CH_SPIN_LIMIT = 1u << 22;   // polls of the barrier counter (s_sleep + one uncached load each: several seconds) before a workgroup gives up
 
 constexpr int CH_SYS = 17;                     // buffer cache policy sc0 | sc1: system scope (write-through / L2-bypassing)
 __device__ __forceinline__ f32x4 ch_ld4(ud_rsrc_t r, unsigned byte_off) {
