@@ -518,6 +518,14 @@ def test_v2_plan_builder_dry_run_order_and_descriptors(monkeypatch):
     # the token adapters and the CameraHead are ONE launch (UdCameraHead); its descriptor is inside the kernel's limits for every backbone
     assert cam.count("cam.head") == 1 and cam[-2:] == ["rays", "ray_embed"] and "camera_intrinsics" in cam and not any(t.startswith("dh.") for t in cam)
     assert tags[tags.index("ray_embed") + 1:tags.index("ray_embed") + 4] == ["layernorm", "dh.q(x4)", "dh.kv(x4)"]
+    # outside the one-launch kernel's limits the same layers are recorded one by one (4 adapters, 14 Linears, 6 LayerNorms, 2 attentions: 26 launches)
+    monkeypatch.setattr(ops, "camera_head_supported", lambda d: False)
+    m.clear_plans()
+    plan2 = m._plan(1, 462, 616, 0, True, True)
+    tags2 = [t[1] for t in plan2.prog.meta]
+    cam2 = tags2[tags2.index("dec.adapters(x4)") + 1:tags2.index("ray_embed") + 1]
+    assert "cam.head" not in cam2 and cam2.count("cam.adapter") == 4 and cam2.count("attention_small") == 2
+    assert sum(t.startswith("cam.cam.") for t in cam2) == 14 and len(plan2.prog) == len(plan.prog) + 25
 
 
 def test_program_api_argument_checks_without_gpu():
