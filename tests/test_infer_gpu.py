@@ -231,3 +231,28 @@ def test_interrupted_replay_leaves_no_state_behind(engine_cls):
     torch.cuda.synchronize()
     for k in out0:
         assert torch.equal(out0[k], out1[k]), k
+
+
+@pytest.mark.parametrize("arch,B,H,W", [("vits14", 2, 240, 320), ("vitl14", 3, 518, 518)])
+def test_camera_branch_one_launch_and_per_layer_forms_agree(engine_cls, monkeypatch, arch, B, H, W):
+    """The token adapters + CameraHead run as ONE launch (ud_camera_head_f32) where the kernel's limits allow it and as the 26 per-layer
+    launches it replaces otherwise: the same fp32 arithmetic in another summation order.  Both forms of one model agree to fp32 round-off on
+    the intrinsics (1e-5); depth, behind the ray embedding's 2^k pi bands and a sensitised decoder in fp16, moves by a few 1e-4 with them (well
+    inside the 1e-3 bar).  The one-launch form leaves its barrier words zero."""
+    from unidepth_amd import ops
+    cfg = synth.load_config(arch)
+    model = engine_cls(cfg).load_state_dict(synth.make_synthetic_checkpoint(cfg, 41)).to("cuda").eval()
+    rgb = torch.randint(0, 256, (B, 3, H, W), dtype=torch.uint8, generator=torch.Generator().manual_seed(9)).cuda()
+    one = {k: v.clone() for k, v in model.infer(rgb).items()}
+    torch.cuda.synchronize()
+    plan = next(reversed(model._plans.values()))
+    assert [m[1] for m in plan.prog.meta].count("cam.head") == 1 and plan.cam_sync[:3].tolist() == [0, 0, 0]
+    monkeypatch.setattr(ops, "camera_head_supported", lambda d: False)
+    model.clear_plans()
+    per = model.infer(rgb)
+    torch.cuda.synchronize()
+    plan = next(reversed(model._plans.values()))
+    assert "cam.head" not in [m[1] for m in plan.prog.meta]
+    k1, k2 = one["intrinsics"].double(), per["intrinsics"].double()
+    assert ((k1 - k2).abs() / k2.abs().clamp_min(1.0)).max().item() < 1e-5
+    assert _arel(one["depth"].float().cpu(), per["depth"].float().cpu()) < 1e-3
