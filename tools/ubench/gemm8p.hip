@@ -1,0 +1,304 @@
+// K-loop experiment for round 6 (never part of the product): the PING-PONG form of the large-tile GEMM.
+// 64*MQ x 256 output tile (MQ = 4: 256 rows, MQ = 3: 192 rows), 8 waves = 2 (m) x 4 (n), v_mfma_f32_16x16x32_f16, K-tile 64, two K-tile
+// buffers in LDS.  A K-tile is walked as FOUR phases, one quadrant (MQ x 2 MFMA tiles x 2 k-steps = 4 MQ MFMAs) of the wave's
+// 32 MQ x 64 sub-tile each; a phase = { fragment reads + a slice of the operand DMA ; s_barrier ; the quadrant's MFMAs under s_setprio 1 ;
+// s_barrier }.  The waves of m-row 1 run ONE barrier behind those of m-row 0 (STAGGER), so on every SIMD one wave is inside its MFMA
+// cluster while its partner issues fragment reads / DMA: the matrix pipe never waits for an LDS round trip and never sees two MFMA
+// streams competing (MI355X_MICROARCH "Two waves per SIMD"; cdna_hip_programming T3 / T4 / T5).
+//   DMA schedule (counted vmcnt, never 0 in the loop): K-tile kt, buffer b = kt & 1:
+//     P1: A(kt+1) blocks 0,1 -> b^1   P2: A(kt+1) blocks 2(,3) -> b^1   P3: W(kt+2) blocks 0,1 -> b   P4: W(kt+2) blocks 2,3 -> b ; vmcnt(4)
+//   i.e. the activation operand runs one K-tile ahead, the weight operand two (its 4 loads stay in flight across the K-tile boundary).
+//   WAR: A(b^1) was last read in P3 of kt-1 (two barriers before P1's issue); W(b) is last read in P2 of kt, whose reads are retired
+//   (lgkmcnt(0)) BEFORE that phase's first barrier.  RAW: a wave waits for its own DMA (vmcnt) before a barrier every reader passes.
+// Operands: A [M, K], W [N, K] fp16 row-major (K contiguous); C [M, N] fp16 = A W^T.  LDS image [row][64 halves], 16-byte chunks
+// XOR-swizzled by (row >> 1) & 7 on the SOURCE address (the product's), operands copied by buffer_load ... lds.
+// build: hipcc --offload-arch=gfx950 -O3 -o gemm8p gemm8p.hip ; run on the GPU box: ./gemm8p M N K [const]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+typedef _Float16 half_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
+typedef __attribute__((ext_vector_type(8))) _Float16 half8;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void bufl16(rsrc_t r, unsigned voff, int soff, void* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)voff, soff, 0, 0);
+}
+__device__ __forceinline__ unsigned pack2(float x, float y) {
+  f32x2 v; v[0] = x; v[1] = y;
+  const half2v h = __builtin_convertvector(v, half2v);
+  return __builtin_bit_cast(unsigned, h);
+}
+__device__ __forceinline__ void pair16(unsigned& a, unsigned& b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  a = r[0]; b = r[1];
+}
+
+template <int I> struct IntTag { static constexpr int value = I; };
+
+#define BAR()                                \
+  do {                                       \
+    __builtin_amdgcn_sched_barrier(0);       \
+    __builtin_amdgcn_s_barrier();            \
+    __builtin_amdgcn_sched_barrier(0);       \
+  } while (0)
+
+// MQ: m-tiles (16 rows) per quadrant; STAGGER: m-row 1 one barrier behind m-row 0; PRIO: s_setprio 1 around the MFMA clusters
+template <int MQ, bool STAGGER, bool PRIO>
+__global__ __launch_bounds__(512) void gemm8p_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, half_t* __restrict__ C, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = 64 * MQ;
+  constexpr int A_BYTES = BM * 128;
+  constexpr int BUFB = A_BYTES + 32768;
+  constexpr int A_LD = BM / 64;                 // DMA instructions per thread per K-tile of A (64 rows each)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wv >> 2, wc = wv & 3;
+  const int nk = K >> 6;
+  const int tiles_n = N >> 8, tiles_m = (M + BM - 1) / BM;
+  const int nblk = tiles_m * tiles_n;
+  const rsrc_t rA = make_rsrc(A, (unsigned)((size_t)M * K * 2)), rW = make_rsrc(W, (unsigned)((size_t)N * K * 2));
+  const int lrow = tid >> 3;
+  const int csrc = (tid & 7) ^ ((lrow >> 1) & 7);
+
+  // fragment read offsets
+  const int fswz = (lane & 15) >> 1;
+  const int c0 = ((lane >> 4) ^ fswz) << 4, c1 = ((4 + (lane >> 4)) ^ fswz) << 4;
+  const int a_off = (wr * (BM / 2) + (lane & 15)) * 128;
+  const int b_off = A_BYTES + (wc * 64 + (lane & 15)) * 128;
+
+  for (int t = blockIdx.x; t < nblk; t += gridDim.x) {
+    // XCD-aware tile map: block b runs on XCD b % 8; every XCD gets a contiguous range of the row-major tile list
+    int m0, n0;
+    {
+      const int q = nblk >> 3, r = nblk & 7;
+      const int xcd = t & 7, idx = t >> 3;
+      const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+      m0 = (bid / tiles_n) * BM;
+      n0 = (bid % tiles_n) << 8;
+    }
+    unsigned va[A_LD], vb[4];                    // rows past M re-read the last row (their outputs are never stored)
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+      int m = m0 + lrow + 64 * j;
+      m = m < M ? m : M - 1;
+      va[j] = ((unsigned)m * (unsigned)K + csrc * 8) * 2u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vb[j] = ((unsigned)(n0 + lrow + 64 * j) * (unsigned)K + csrc * 8) * 2u;
+    auto issueA = [&](int kt, int buf, int j0, int j1) {
+      char* sb = smem + buf * BUFB + wv * 1024;
+#pragma unroll
+      for (int j = 0; j < A_LD; ++j)
+        if (j >= j0 && j < j1) bufl16(rA, va[j], kt * 128, sb + j * 8192);
+    };
+    auto issueB = [&](int kt, int buf, int j0, int j1) {
+      char* sb = smem + buf * BUFB + A_BYTES + wv * 1024;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j >= j0 && j < j1) bufl16(rW, vb[j], kt * 128, sb + j * 8192);
+    };
+
+    f32x4 acc[2 * MQ][4];
+#pragma unroll
+    for (int i = 0; i < 2 * MQ; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    half8 a[MQ][2], b0[2][2], b1[2][2];
+
+    // prologue: A(0), W(0) -> buffer 0, W(1) -> buffer 1 (stays in flight)
+    issueA(0, 0, 0, A_LD);
+    issueB(0, 0, 0, 4);
+    if (nk > 1) {
+      issueB(1, 1, 0, 4);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    BAR();
+    if constexpr (STAGGER) {
+      if (wr == 1) BAR();
+    }
+
+#define MFMA_QUAD(MQI, NQI, BF)                                                                                            \
+  do {                                                                                                                     \
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);                                                                     \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < MQ; ++i)                        \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[(MQI) * MQ + i][(NQI) * 2 + j] =                                 \
+            __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[j][ks], a[i][ks], acc[(MQI) * MQ + i][(NQI) * 2 + j], 0, 0, 0);      \
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);                                                                     \
+  } while (0)
+
+    auto ktile = [&](auto BUFT, int kt) {
+      constexpr int buf = decltype(BUFT)::value;
+      const char* sb = smem + buf * BUFB;
+      const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
+      // ---- P1: quadrant (0, 0)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        b0[j][0] = *(const half8*)(sb + b_off + j * 2048 + c0);
+        b0[j][1] = *(const half8*)(sb + b_off + j * 2048 + c1);
+      }
+#pragma unroll
+      for (int i = 0; i < MQ; ++i) {
+        a[i][0] = *(const half8*)(sb + a_off + i * 2048 + c0);
+        a[i][1] = *(const half8*)(sb + a_off + i * 2048 + c1);
+      }
+      if (n1) issueA(kt + 1, buf ^ 1, 0, 2);
+      BAR();
+      MFMA_QUAD(0, 0, b0);
+      BAR();
+      // ---- P2: quadrant (0, 1); the W reads of this buffer end here: retired before the barrier (P3 re-stages the W region)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        b1[j][0] = *(const half8*)(sb + b_off + (2 + j) * 2048 + c0);
+        b1[j][1] = *(const half8*)(sb + b_off + (2 + j) * 2048 + c1);
+      }
+      if (n1) issueA(kt + 1, buf ^ 1, 2, A_LD);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b1[0][0]), "+v"(b1[0][1]), "+v"(b1[1][0]), "+v"(b1[1][1])::"memory");
+      BAR();
+      MFMA_QUAD(0, 1, b1);
+      BAR();
+      // ---- P3: quadrant (1, 1)
+#pragma unroll
+      for (int i = 0; i < MQ; ++i) {
+        a[i][0] = *(const half8*)(sb + a_off + (MQ + i) * 2048 + c0);
+        a[i][1] = *(const half8*)(sb + a_off + (MQ + i) * 2048 + c1);
+      }
+      if (n2) issueB(kt + 2, buf, 0, 2);
+      BAR();
+      MFMA_QUAD(1, 1, b1);
+      BAR();
+      // ---- P4: quadrant (1, 0); next K-tile's operands landed (own DMA) before the barrier every reader passes
+      if (n2) {
+        issueB(kt + 2, buf, 2, 4);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      BAR();
+      MFMA_QUAD(1, 0, b0);
+      BAR();
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+      ktile(IntTag<0>{}, kt);
+      ktile(IntTag<1>{}, kt + 1);
+    }
+#undef MFMA_QUAD
+    if constexpr (STAGGER) {
+      if (wr == 0) BAR();
+    }
+
+    // ---- epilogue: lane owns row mbase + 16 i + (lane & 15), columns nbase + 16 j + 4 q .. + 3 (q = lane >> 4); v_permlane16_swap of
+    // the packed dwords of column tiles j / j+1 leaves 8 consecutive columns per lane: 16-byte stores
+    const int frow = lane & 15, fq = lane >> 4;
+    const int mbase = m0 + wr * (BM / 2), nbase = n0 + wc * 64;
+    half_t* o = C + (size_t)(mbase + frow) * N + nbase + 16 * (fq & 1) + 8 * (fq >> 1);
+#pragma unroll
+    for (int i = 0; i < 2 * MQ; ++i) {
+      unsigned w[4][2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        w[j][0] = pack2(acc[i][j][0], acc[i][j][1]);
+        w[j][1] = pack2(acc[i][j][2], acc[i][j][3]);
+      }
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        pair16(w[2 * jp][0], w[2 * jp + 1][0]);
+        pair16(w[2 * jp][1], w[2 * jp + 1][1]);
+        u32x4 s;
+        s[0] = w[2 * jp][0]; s[1] = w[2 * jp][1]; s[2] = w[2 * jp + 1][0]; s[3] = w[2 * jp + 1][1];
+        if (mbase + i * 16 + frow < M) *(u32x4*)(o + (size_t)(i * 16) * N + jp * 32) = s;
+      }
+    }
+    // the next tile's prologue overwrites both buffers: every wave must be past its last fragment read
+    BAR();
+  }
+}
+
+__global__ void ref_kernel(const half_t* A, const half_t* W, const int* mi, const int* ni, float* out, int K, int cnt) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= cnt) return;
+  double s = 0;
+  for (int k = 0; k < K; ++k) s += (double)(float)A[(size_t)mi[t] * K + k] * (double)(float)W[(size_t)ni[t] * K + k];
+  out[t] = (float)s;
+}
+
+struct Ctx {
+  const half_t* dA; const half_t* dW; half_t* dC; int M, N, K;
+  std::vector<int> mi, ni; int *dmi, *dni; float* dref;
+};
+
+template <int MQ, bool STAGGER, bool PRIO>
+double run(Ctx& c, int rounds) {
+  auto kern = gemm8p_kernel<MQ, STAGGER, PRIO>;
+  constexpr int LDS = 2 * (64 * MQ * 128 + 32768);
+  hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  const int BM = 64 * MQ;
+  const int tiles = ((c.M + BM - 1) / BM) * (c.N >> 8);
+  const int grid = tiles < 256 ? tiles : 256;
+  auto launch = [&]() { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, 0, c.dA, c.dW, c.dC, c.M, c.N, c.K); };
+  hipMemset(c.dC, 0, (size_t)c.M * c.N * 2);
+  launch();
+  if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); exit(1); }
+  std::vector<half_t> out((size_t)c.M * c.N);
+  std::vector<float> ref(c.mi.size());
+  hipMemcpy(out.data(), c.dC, out.size() * 2, hipMemcpyDeviceToHost);
+  hipLaunchKernelGGL(ref_kernel, dim3((c.mi.size() + 63) / 64), dim3(64), 0, 0, c.dA, c.dW, c.dmi, c.dni, c.dref, c.K, (int)c.mi.size());
+  hipMemcpy(ref.data(), c.dref, ref.size() * 4, hipMemcpyDeviceToHost);
+  double maxerr = 0;
+  for (size_t t = 0; t < c.mi.size(); ++t) maxerr = fmax(maxerr, fabs((float)out[(size_t)c.mi[t] * c.N + c.ni[t]] - ref[t]) / (fabs(ref[t]) + 1.0));
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  double best = 1e30, sum = 0;
+  for (int r = 0; r < rounds; ++r) {
+    hipEventRecord(e0); for (int i = 0; i < 10; ++i) launch(); hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    best = fmin(best, ms * 100.0); sum += ms * 100.0;
+  }
+  const double us = sum / rounds;
+  printf("gemm8p MQ %d stagger %d prio %d: M %d N %d K %d, %d tiles on %d workgroups: mean %.1f us (%.0f TFLOP/s), best %.1f us (%.0f), max rel err %.2e %s\n", MQ,
+         (int)STAGGER, (int)PRIO, c.M, c.N, c.K, tiles, grid, us, 2.0 * c.M * c.N * c.K / us / 1e6, best, 2.0 * c.M * c.N * c.K / best / 1e6, maxerr,
+         maxerr < 2e-3 ? "ok" : "WRONG");
+  return us;
+}
+
+int main(int argc, char** argv) {
+  int M = 4096, N = 4096, K = 4096;
+  if (argc >= 4) { M = atoi(argv[1]); N = atoi(argv[2]); K = atoi(argv[3]); }
+  const int fill = argc >= 5 ? atoi(argv[4]) : 0;      // 0: uniform [-1, 1) x uniform [-1, 1) K^-1/2-ish; 1: constant
+  if ((N & 255) || (K & 127)) { printf("need N %% 256 == 0, K %% 128 == 0\n"); return 1; }
+  std::vector<half_t> hA((size_t)M * K), hW((size_t)N * K);
+  unsigned s = 12345;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.0f - 1.0f; };
+  for (auto& v : hA) v = fill ? (half_t)0.25f : (half_t)rnd();
+  for (auto& v : hW) v = fill ? (half_t)0.03125f : (half_t)(rnd() * 0.05f);
+  printf("operands: %s\n", fill ? "constant" : "uniform random, full sign / mantissa toggling");
+  Ctx c; c.M = M; c.N = N; c.K = K;
+  half_t *dA, *dW, *dC;
+  hipMalloc(&dA, hA.size() * 2); hipMalloc(&dW, hW.size() * 2); hipMalloc(&dC, (size_t)M * N * 2);
+  hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice); hipMemcpy(dW, hW.data(), hW.size() * 2, hipMemcpyHostToDevice);
+  c.dA = dA; c.dW = dW; c.dC = dC;
+  for (int t = 0; t < 4096; ++t) { s = s * 1664525u + 1013904223u; c.mi.push_back((s >> 4) % M); s = s * 1664525u + 1013904223u; c.ni.push_back((s >> 4) % N); }
+  // rows at tile seams and the last rows, explicitly
+  for (int t = 0; t < 64; ++t) { c.mi.push_back(M - 1 - t); c.ni.push_back((t * 67) % N); }
+  hipMalloc(&c.dmi, c.mi.size() * 4); hipMalloc(&c.dni, c.ni.size() * 4); hipMalloc(&c.dref, c.mi.size() * 4);
+  hipMemcpy(c.dmi, c.mi.data(), c.mi.size() * 4, hipMemcpyHostToDevice); hipMemcpy(c.dni, c.ni.data(), c.ni.size() * 4, hipMemcpyHostToDevice);
+  const int R = 3;
+  for (int rep = 0; rep < 2; ++rep) {            // interleaved rounds
+    run<4, true, true>(c, R);
+    run<4, true, false>(c, R);
+    run<4, false, true>(c, R);
+    run<4, false, false>(c, R);
+    run<3, true, true>(c, R);
+    run<3, false, false>(c, R);
+  }
+  return 0;
+}
