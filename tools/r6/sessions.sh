@@ -26,4 +26,17 @@ timeout 300 python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-extra-c
 cat $O/gemm8p.txt $O/product_plain.txt $O/gemm4w.txt $O/bench.txt; tail -3 $O/err.txt
 }
 
+# round 6, GPU call 2: the same A/B in ONE process (the product's kernel through its C-ABI from the micro-benchmark, arms interleaved: call 1
+# showed the same product kernel 9 % apart between two places of one python loop -- clock ramp); --inflight 1 / 2 / 3 / 4 on the bench line
+call2() {
+O=gpurun_out/r6c2 && mkdir -p $O
+for s in "4096 4096 4096" "11008 1024 1024" "11008 1024 4096" "11008 3072 1024" "11008 4096 1024"; do
+  UD_LIB=$R/unidepth_amd/libunidepth_hip.so timeout 120 tools/ubench/gemm8p $s 2>&1 | grep -v amdgpu.ids >> $O/gemm8p_vs_product.txt
+done
+for r in 1 2; do for inf in 2 3 4; do
+  timeout 300 python bench.py --steps 24 --warmup 4 --inflight $inf --no-cpu-baseline --no-extra-configs --no-kernel-timing 2>$O/err.txt | line "inflight=$inf" >> $O/inflight.txt
+done; done
+cat $O/gemm8p_vs_product.txt $O/inflight.txt; tail -3 $O/err.txt
+}
+
 "$@"

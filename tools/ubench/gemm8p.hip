@@ -18,6 +18,9 @@
 #include <cstdlib>
 #include <vector>
 #include <cmath>
+#include <cstring>
+#include <dlfcn.h>
+#include "../../include/unidepth_hip.h"
 typedef _Float16 half_t;
 typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
 typedef __attribute__((ext_vector_type(8))) _Float16 half8;
@@ -270,6 +273,36 @@ double run(Ctx& c, int rounds) {
   return us;
 }
 
+// the product's large-tile kernel on the same problem (plain fp16 epilogue) through its C-ABI, in THIS process: interleaved A/B
+typedef int (*gemm_fn)(const UdGemm*, void*);
+double run_product(Ctx& c, gemm_fn fn, int hint, const float* dbias, int rounds) {
+  UdGemm d; memset(&d, 0, sizeof d);
+  d.A = c.dA; d.W = c.dW; d.bias = dbias; d.out = c.dC; d.M = c.M; d.N = c.N; d.K = c.K; d.lda = c.K; d.ldw = c.K; d.ldc = c.N;
+  d.epi = UD_EPI_F16; d.tile_hint = hint;
+  auto launch = [&]() { return fn(&d, nullptr); };
+  hipMemset(c.dC, 0, (size_t)c.M * c.N * 2);
+  if (launch() != UD_OK) { printf("product hint %d: refused\n", hint); return 0; }
+  hipDeviceSynchronize();
+  std::vector<half_t> out((size_t)c.M * c.N);
+  std::vector<float> ref(c.mi.size());
+  hipMemcpy(out.data(), c.dC, out.size() * 2, hipMemcpyDeviceToHost);
+  hipLaunchKernelGGL(ref_kernel, dim3((c.mi.size() + 63) / 64), dim3(64), 0, 0, c.dA, c.dW, c.dmi, c.dni, c.dref, c.K, (int)c.mi.size());
+  hipMemcpy(ref.data(), c.dref, ref.size() * 4, hipMemcpyDeviceToHost);
+  double maxerr = 0;
+  for (size_t t = 0; t < c.mi.size(); ++t) maxerr = fmax(maxerr, fabs((float)out[(size_t)c.mi[t] * c.N + c.ni[t]] - ref[t]) / (fabs(ref[t]) + 1.0));
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  double best = 1e30, sum = 0;
+  for (int r = 0; r < rounds; ++r) {
+    hipEventRecord(e0); for (int i = 0; i < 10; ++i) launch(); hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    best = fmin(best, ms * 100.0); sum += ms * 100.0;
+  }
+  const double us = sum / rounds;
+  printf("product tile_hint %d                : M %d N %d K %d: mean %.1f us (%.0f TFLOP/s), best %.1f us (%.0f), max rel err %.2e\n", hint, c.M, c.N, c.K, us,
+         2.0 * c.M * c.N * c.K / us / 1e6, best, 2.0 * c.M * c.N * c.K / best / 1e6, maxerr);
+  return us;
+}
+
 int main(int argc, char** argv) {
   int M = 4096, N = 4096, K = 4096;
   if (argc >= 4) { M = atoi(argv[1]); N = atoi(argv[2]); K = atoi(argv[3]); }
@@ -291,14 +324,25 @@ int main(int argc, char** argv) {
   for (int t = 0; t < 64; ++t) { c.mi.push_back(M - 1 - t); c.ni.push_back((t * 67) % N); }
   hipMalloc(&c.dmi, c.mi.size() * 4); hipMalloc(&c.dni, c.ni.size() * 4); hipMalloc(&c.dref, c.mi.size() * 4);
   hipMemcpy(c.dmi, c.mi.data(), c.mi.size() * 4, hipMemcpyHostToDevice); hipMemcpy(c.dni, c.ni.data(), c.ni.size() * 4, hipMemcpyHostToDevice);
+  gemm_fn prod = nullptr;
+  if (const char* lp = getenv("UD_LIB")) {
+    void* h = dlopen(lp, RTLD_NOW);
+    if (h) prod = (gemm_fn)dlsym(h, "ud_gemm_f16");
+    if (!prod) printf("cannot load ud_gemm_f16 from %s: %s\n", lp, dlerror());
+  }
+  float* dbias; hipMalloc(&dbias, N * 4); hipMemset(dbias, 0, N * 4);
   const int R = 3;
-  for (int rep = 0; rep < 2; ++rep) {            // interleaved rounds
-    run<4, true, true>(c, R);
-    run<4, true, false>(c, R);
-    run<4, false, true>(c, R);
-    run<4, false, false>(c, R);
+  for (int rep = 0; rep < 3; ++rep) {            // interleaved rounds
     run<3, true, true>(c, R);
-    run<3, false, false>(c, R);
+    if (prod) run_product(c, prod, 3, dbias, R);
+    run<4, true, true>(c, R);
+    if (prod) run_product(c, prod, 2, dbias, R);
+    if (prod) run_product(c, prod, 8, dbias, R);
+    if (rep == 0) {
+      run<4, false, false>(c, R);
+      run<3, false, false>(c, R);
+      run<3, true, false>(c, R);
+    }
   }
   return 0;
 }
