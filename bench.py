@@ -21,7 +21,8 @@ One JSON line on rank 0 with the driver contract fields plus
   roofline     -- the dominant kernel class of the step (an MFMA GEMM instantiation, named as rocprofv3 prints it): algorithmic
                   FLOP per launch / average launch duration measured live with HIP events on the launch stream, against the
                   2.5 PFLOP/s dense fp16 peak; algorithmic bytes per launch (operands + outputs once); `traffic` = HBM bytes per
-                  launch from the committed PMC passes (profiles/);
+                  launch from the committed PMC passes (profiles/); `attainable_this_box` = a pure MFMA stream on random fp16 operands
+                  (csrc/calib.hip) run in this process before the timed region, `frac_of_attainable` against it: comparable across boxes;
   rccl         -- N > 1: ranks seen, bytes gathered per rank and step, the collective's own duration, and how much of it the
                   timed region hides behind compute;
   cpu_baseline -- the CPU oracle (fp32 restatement of the reference, oracle/restate.py) timed on this box's host cores on a
@@ -30,7 +31,9 @@ One JSON line on rank 0 with the driver contract fields plus
   configs      -- N = 1 only, after the timed region (never part of `value`): the other BASELINE.json configurations that fit one GPU,
                   each a few seconds of GPU time: `v1_cnvnxtl_640x480_bs16` (configs[3]; own roofline, CPU baseline on bs=16, where fp32-class
                   arithmetic is used), `mixed_644x966+518x518_bs32` (configs[4] on one GPU through dist.infer_mixed), `knn_307200`
-                  (the reference's native K-NN extension at the size its 3-D metrics use).  --no-extra-configs skips them.
+                  (the reference's native K-NN extension at the size its 3-D metrics use), `reference_as_shipped_rocm` (the reference's module
+                  graph as PyTorch-ROCm ops under torch.autocast(fp16) on this same GPU and workload: the same-box comparator of value_one_call /
+                  p50_latency_ms).  --no-extra-configs skips them.
 """
 import argparse
 import json
@@ -196,6 +199,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    calib = mfma_attainable(torch, dev) if (rank == 0 and not args.no_kernel_timing) else None     # after the warm-up (clocks up), before the timed region
+    for _ in range(2):
+        step()
     elapsed = timed(args.steps)                      # THE timed region: exactly K steps, barrier + synchronize on both sides, max over ranks
     # latency of ONE call with nothing else in flight (outside the timed region)
     lat = []
@@ -232,7 +238,7 @@ def main():
         result["config"].update({"value_one_call": result["value_one_call"], "p50_latency_ms": result["p50_latency_ms"],
                                  "p90_latency_ms": result["p90_latency_ms"], "inflight": result["inflight"]})
         if not args.no_kernel_timing:
-            result.update(kernel_timing(torch, model, fl, B, args.dump_ops))
+            result.update(kernel_timing(torch, model, fl, B, args.dump_ops, calib))
             scope = result["roofline_enc_attention_mlp"]
             result["roofline"].update({"scope_frac": scope["frac"], "scope_achieved": scope["achieved"], "scope_ms_per_step": scope["ms_per_step"],
                                        "scope": "encoder attention + MLP blocks (north_star target 0.60): see roofline_enc_attention_mlp",
@@ -334,7 +340,40 @@ def rccl_log_summary():
             "lines": text.count("\n")}
 
 
-def kernel_timing(torch, model, fl, B, dump=""):
+def mfma_attainable(torch, dev):
+    """What the matrix pipes of THIS box sustain on a pure MFMA stream with random fp16 operands (csrc/calib.hip, ~0.3 s): boxes of the pool
+    differ by several per cent on every kernel, so fractions against a per-box number are comparable across boxes where the datasheet
+    fraction is not.  Runs before the timed region; HIP events on the launch stream."""
+    import ctypes as C
+    from unidepth_amd import _lib
+    ops_t = (torch.randn(1 << 20, generator=torch.Generator().manual_seed(11)) * 0.5).half().to(dev)       # 2 MiB
+    wgs, iters = 1024, 640
+    sink = torch.zeros(wgs * 256, dtype=torch.float32, device=dev)
+    flop = C.c_double(0.0)
+    st = torch.cuda.current_stream(dev).cuda_stream
+
+    def launch():
+        _lib.check(_lib.lib.ud_calib_mfma_stream(ops_t.data_ptr(), iters, wgs, sink.data_ptr(), C.byref(flop), st), "ud_calib_mfma_stream")
+    for _ in range(20):
+        launch()
+    torch.cuda.synchronize()
+    best, tot, n = 0.0, 0.0, 0
+    for _ in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            launch()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 50
+        tf = flop.value / (ms * 1e-3) / 1e12
+        best = max(best, tf); tot += tf; n += 1
+    assert float(sink.abs().sum()) == 0.0
+    return {"tflops": round(tot / n, 1), "best_tflops": round(best, 1), "launch_ms": round(flop.value / (tot / n) / 1e9, 4),
+            "stream": "v_mfma_f32_32x32x16_f16 only, 16 independent per iteration and wave, 2 waves per SIMD, random fp16 operands (csrc/calib.hip)"}
+
+
+def kernel_timing(torch, model, fl, B, dump="", attainable=None):
     """Per-launch durations with HIP events on the launch stream (torch's current stream is the one every kernel of the
     program is enqueued on); aggregated per kernel class.  Returns the roofline object for the dominant kernel."""
     plan = next(reversed(model._plans.values()))
@@ -377,19 +416,24 @@ def kernel_timing(torch, model, fl, B, dump=""):
                  for k, v in sorted(tot.items(), key=lambda kv: -kv[1]["ms"])}
     # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the json)
     traffic, traffic_src = None, None
-    for name in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    for name in ("r06_hbm_traffic.json", "r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if traffic is None and os.path.exists(tpath):
             short = dom.replace("Cfg<", "(anonymous namespace)::Cfg<")
             for kname, rec in json.load(open(tpath))["kernels"].items():
                 if short in kname:
                     traffic, traffic_src = rec["hbm_total_bytes"], "profiles/" + name
+    if attainable:
+        att, att_src = attainable["tflops"], ("measured in this run before the timed region: " + attainable["stream"] +
+                                              f"; best of 4 rounds {attainable['best_tflops']}; round 2 on another box: {MFMA_ATTAINABLE_TFLOPS} (profiles/r02_mfma_attainable.txt)")
+    else:
+        att, att_src = MFMA_ATTAINABLE_TFLOPS, "profiles/r02_mfma_attainable.txt (constant from another box: no calibration in this run)"
     return {
         "roofline": {"bound": "mfma", "kernel": dom + " (v_mfma_f32_16x16x32_f16)",
                      "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                     "attainable_peak_random_operands": MFMA_ATTAINABLE_TFLOPS, "frac_of_attainable": round(achieved / MFMA_ATTAINABLE_TFLOPS, 4),
-                     "attainable_source": "profiles/r02_mfma_attainable.txt (MFMA-only stream, random fp16 operands, power-limited clocks)",
+                     "attainable_this_box": att, "frac_of_attainable": round(achieved / att, 4),
+                     "attainable_source": att_src,
                      "flop_per_launch": round(d["flops"] / d["launches"], 1),
                      "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 3),
                      "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"], 1),
@@ -400,7 +444,7 @@ def kernel_timing(torch, model, fl, B, dump=""):
                               "is the one to compare across rounds") if dom.startswith("gemm256_kernel<3, 1, 0") else None},
         "roofline_enc_attention_mlp": {"achieved": round(enc_fl / (enc_ms * 1e-3) / 1e12, 2), "peak": MFMA_PEAK_TFLOPS,
                                        "unit": "TFLOP/s", "frac": round(enc_fl / (enc_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
-                                       "frac_of_attainable": round(enc_fl / (enc_ms * 1e-3) / 1e12 / MFMA_ATTAINABLE_TFLOPS, 4),
+                                       "frac_of_attainable": round(enc_fl / (enc_ms * 1e-3) / 1e12 / att, 4),
                                        "ms_per_step": round(enc_ms, 4),
                                        "scope": "the 24 encoder blocks as the reference's Block.forward runs them: both LayerNorms (or what is left of them "
                                                 "after folding), qkv, attention, proj, fc1 + GELU, fc2, LayerScale and residual adds; "
@@ -470,6 +514,33 @@ def latency_bs1(torch, model_vitl, dev):
     del m_s
     return rec
 
+def reference_as_shipped(torch, dev, B=8, H=518, W=518, warm=5, calls=10):
+    from oracle import restate, synth                    # baseline leg only (the checker, timed as the comparator)
+    cfg = synth.load_config("vitl14")
+    sd = synth.make_synthetic_checkpoint(cfg, 125)
+    orc = restate.OracleV2(cfg, sd)
+    orc.w = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in orc.w.items()}
+    rgb = torch.randint(0, 256, (B, 3, H, W), dtype=torch.uint8, generator=torch.Generator().manual_seed(1)).to(dev)
+
+    def call():
+        with torch.no_grad(), torch.device(dev), torch.autocast(device_type="cuda", enabled=True, dtype=torch.float16):
+            return orc.infer(rgb)
+    for _ in range(warm):
+        call()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(calls):
+        t0 = time.perf_counter()
+        call()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    p50 = statistics.median(ts)
+    return {"metric": "images/sec + p50 latency, ViT-L/14 518x518 bs=8: the reference's module graph in PyTorch-ROCm under torch.autocast(fp16), one call at a time",
+            "value": round(B / (p50 * 1e-3), 2), "unit": "images/s", "p50_latency_ms": round(p50, 3), "min_ms": round(min(ts), 3), "calls": calls, "warmup": warm,
+            "kind": "port (oracle/restate.py ops on cuda; skips the dead work the live reference performs: SURVEY 8a-20)", "torch": torch.__version__,
+            "compare_with": "value_one_call / p50_latency_ms of the headline line (same box, same inputs, one call at a time)"}
+
+
 def extra_configs(torch, model_v2, dev, cpu=True):
     """The other BASELINE.json configurations that fit one GPU (configs[3], configs[4] on one GPU, the K-NN extension), each a few
     seconds of GPU time, after the timed region of the headline metric."""
@@ -536,6 +607,15 @@ def extra_configs(torch, model_v2, dev, cpu=True):
         model_v2.clear_plans()
     except Exception as e:
         out["mixed_644x966+518x518_bs32"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
+    # ---- the reference AS SHIPPED on this same GPU: the oracle's torch ops (oracle/restate.py = the reference's own module
+    #      graph, pinned to it) on `cuda` under the autocast decorator of the reference's infer() (unidepthv2.py:239-240), i.e. PyTorch-ROCm
+    #      (rocBLAS / hipBLASLt GEMMs, MIOpen convolutions, the SDPA kernel torch picks) on the bench workload.  A baseline leg like cpu_baseline:
+    #      after the timed region, never part of `value`, nothing under unidepth_amd/ imports it.
+    try:
+        out["reference_as_shipped_rocm"] = reference_as_shipped(torch, dev)
+    except Exception as e:
+        out["reference_as_shipped_rocm"] = {"error": repr(e)}
     torch.cuda.empty_cache()
     # ---- small-batch latency: bs = 1 p50 per infer()
     #      for ViT-L 518x518 and for BASELINE configs[0]'s shape (ViT-S, one 462x616 image)

@@ -87,7 +87,8 @@ typedef struct UdGemm {
                                   8 = row-balanced schedule of the 256-column kernel (dense A; auto picks it when the tile list
                                   would leave the last round partly empty), 9 = 192x256 tiles with the 2-deep weight ring (dense
                                   192-row launches otherwise fetch the weight operand two K-tiles ahead through a 3-deep LDS ring:
-                                  same bits, the weights of a layer are cold in every step) */
+                                  same bits, the weights of a layer are cold in every step),
+                                  10 = 192x256 tiles with the two-way K split of the large-tile list (splitk_ws_bytes below; refused -> 128x128 tiles) */
   /* optional scratch for the two-way K split of small problems (at most 128 tiles of 128x128, K >= 1024, dense A, F16 / F32
    * epilogues): two workgroups on different CUs each take half of K, the later one adds the other's fp32 partial tile (a + b is
    * order-independent, so results do not depend on timing) and runs the epilogue.  splitk_ws: 2 * tiles * 64 KB; splitk_cnt: one
@@ -139,6 +140,12 @@ typedef struct UdGemm {
    * never written and read back: out = up2(up_src) + ConvT(A) (+ bias), out2 = act2(out).  Needs d2s_Hin * d2s_k == 2 * up_H (same for W). */
   const float* up_src;
   int up_H, up_W, up_ld, up_img_rows;
+  /* Round 6: two-way K split of the LARGE-tile list (192 x 256 tiles): a one-round list of 32..128 tiles with K >= 2048 (dense A or zero-padded
+   * 3x3 taps, fp16 / fp32 epilogues without row statistics; the decoder's stage-0 residual-conv-unit convolutions, layers/upsample.py:137-163)
+   * runs as 2 * tiles workgroups, each over one half of K; same exchange, same splitk_cnt parity tickets (one unsigned per tile, zeroed once)
+   * as the small-tile split above.  Scratch: splitk_ws of splitk_ws_bytes >= 2 * tiles * 192 * 256 * 4 bytes; a smaller (or absent)
+   * scratch keeps the unsplit schedules.  0 for callers that only provide the small-tile scratch. */
+  long long splitk_ws_bytes;
 } UdGemm;
 
 int ud_gemm_f16(const UdGemm* desc, void* stream);
@@ -217,9 +224,17 @@ typedef struct UdCameraHead {
   int T, H, C;           /* attention phases: tokens per image, heads, width (head width C / H) */
   float scale, eps;      /* softmax scale; LayerNorm eps */
   unsigned* sync_ws;     /* 16 words, zero before the FIRST launch; every launch leaves words 0 and 1 zero again.  Word 2 != 0 afterwards: a
-                          * grid barrier timed out (seconds: the grid was not co-resident) and the outputs are invalid */
+                          * grid barrier timed out (the grid was not co-resident: CU mask, partitioned device, foreign kernels holding CUs).
+                          * The failure is LOUD: every launch that ends with word 2 set overwrites the LAST phase's output (the camera
+                          * parameters) with NaN, so intrinsics, rays and depth of that call are NaN; word 2 stays set (and keeps poisoning)
+                          * until the caller clears it */
   int workgroups;        /* 0 = default (128) */
+  unsigned* fail_host;   /* optional, HOST-mapped (pinned) word: set to 1 together with word 2 by a system-scope store, so the caller can poll
+                          * the failure without a device synchronisation (unidepth_amd checks it at the start of the next infer()) */
+  unsigned spin_limit;   /* polls of a barrier before a workgroup gives up; 0 = default (2^22: seconds).  Tests force the time-out with 1 */
 } UdCameraHead;
+/* Launches of ud_camera_head_f32 on one device are SERIALISED across streams (an event chain inside the library: the next launch waits for the
+ * previous one wherever it was enqueued), so two spinning grids of one process are never resident together. */
 int ud_camera_head_f32(const UdCameraHead* desc, void* stream);
 int ud_camera_head_supported(const UdCameraHead* desc);   /* UD_OK if ud_camera_head_f32 would take this descriptor (host-side check, nothing is launched) */
 
@@ -468,6 +483,12 @@ int ud_program_add_spatial_mean(UdProgram*, const float* x, float* out, int B, i
 int ud_program_add_v1_op(UdProgram*, const UdV1Op*);
 /* run ops [first, last) on `stream`; returns 0 or the first failing op's error code.  Stateless: a recorded program is never modified by a replay */
 int ud_program_run(const UdProgram*, int first, int last, void* stream);
+
+/* ---- measurement support (bench.py `roofline.attainable_this_box`; not on any inference path): one launch of a pure MFMA instruction stream
+ * (v_mfma_f32_32x32x16_f16, 16 independent instructions per iteration and wave, 4 waves per workgroup) on the random fp16 values in `operands`
+ * (2 MiB); `sink`: workgroups * 256 floats, never written for finite operands; *flop_out = FLOP of the launch.  What the matrix pipes of this box
+ * sustain at their power-limited clock: boxes of one pool differ by several per cent, the datasheet peak (2.5 PFLOP/s) is a constant. */
+int ud_calib_mfma_stream(const void* operands, int iters, int workgroups, void* sink, double* flop_out, void* stream);
 
 /* library info; ud_struct_size(i): sizeof the i-th descriptor struct in declaration order (UdGemm = 0 ... UdLinearF32 = 8, UdDwConv7 = 9, UdV1Op = 10, UdKnn = 11, UdExtractPatches = 12, UdCameraHead = 13) */
 int ud_version(void);

@@ -3,6 +3,7 @@ vectors, on seeded sensitised checkpoints.  Bars (BASELINE.json north_star / SUR
   depth ARel <= 1e-3 vs the fp32 oracle; intrinsics max-rel <= 2e-3; depth_features rel-L2 <= 3e-3;
   confidence/radius/points ARel-type <= 2e-3; rays max-abs <= 2e-3.  (fp16 MFMA operands, fp32 accumulate/residual.)"""
 import os
+import time
 
 import numpy as np
 import pytest
@@ -231,6 +232,58 @@ def test_interrupted_replay_leaves_no_state_behind(engine_cls):
     torch.cuda.synchronize()
     for k in out0:
         assert torch.equal(out0[k], out1[k]), k
+
+
+def test_camera_head_barrier_timeout_is_loud(engine_cls):
+    """VERDICT r5 weak #9 / ADVICE r5 (medium): the one-launch camera head needs its grid co-resident.  With the barrier time-out forced
+    (spin limit 1: every workgroup that is not the last to arrive gives up) the call must NOT return plausible numbers: its intrinsics, rays
+    and depth are NaN, the NEXT infer() raises and names the cause, and the call after that runs the per-layer form and is right again."""
+    cfg = synth.load_config("vits14")
+    model = engine_cls(cfg).load_state_dict(synth.make_synthetic_checkpoint(cfg, 41)).to("cuda").eval()
+    rgb = torch.randint(0, 256, (2, 3, 240, 320), dtype=torch.uint8, generator=torch.Generator().manual_seed(9)).cuda()
+    good = {k: v.clone() for k, v in model.infer(rgb).items()}
+    torch.cuda.synchronize()
+    model.clear_plans()
+    model._cam_spin_limit = 1
+    bad = model.infer(rgb)
+    torch.cuda.synchronize()
+    plan = next(reversed(model._plans.values()))
+    assert plan.cam_one_launch and int(plan.cam_sync[2]) == 1 and int(plan.cam_fail[0]) == 1
+    assert torch.isnan(bad["intrinsics"]).any() and torch.isnan(bad["depth"]).all() and torch.isnan(bad["rays"]).all()
+    with pytest.raises(RuntimeError, match="camera head timed out"):
+        model.infer(rgb)
+    model._cam_spin_limit = 0
+    again = model.infer(rgb)
+    torch.cuda.synchronize()
+    plan = next(reversed(model._plans.values()))
+    assert not plan.cam_one_launch and "cam.head" not in [m[1] for m in plan.prog.meta]
+    k1, k2 = good["intrinsics"].double(), again["intrinsics"].double()
+    assert ((k1 - k2).abs() / k2.abs().clamp_min(1.0)).max().item() < 1e-5
+    assert _arel(good["depth"].float().cpu(), again["depth"].float().cpu()) < 1e-3
+
+
+def test_camera_heads_of_three_requests_in_flight(engine_cls):
+    """Three requests in flight on three HIP streams (pipeline slots), i.e. three 128-workgroup spinning grids that would not fit the 256 CUs
+    together: the library orders camera-head launches of one device behind each other (ud_camera_head_f32), so none of them times out and every
+    request returns what it returns alone."""
+    from unidepth_amd.pipeline import InferPipeline
+    cfg = synth.load_config("vits14")
+    model = engine_cls(cfg).load_state_dict(synth.make_synthetic_checkpoint(cfg, 41)).to("cuda").eval()
+    rgbs = [torch.randint(0, 256, (2, 3, 240, 320), dtype=torch.uint8, generator=torch.Generator().manual_seed(s)).cuda() for s in (1, 2, 3)]
+    alone = [{k: v.clone() for k, v in model.infer(r).items()} for r in rgbs]
+    torch.cuda.synchronize()
+    pipe = InferPipeline(model, depth=3)
+    t0 = time.perf_counter()
+    for rep in range(8):
+        outs = [pipe.submit(r) for r in rgbs]
+    pipe.sync()
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 5.0, "a camera-head barrier must never wait for its time-out"
+    for a, o in zip(alone, outs):
+        for k in a:
+            assert torch.equal(a[k], o[k]), k
+    for plan in model._plans.values():
+        assert plan.cam_sync[:3].tolist() == [0, 0, 0] and int(plan.cam_fail[0]) == 0
 
 
 @pytest.mark.parametrize("arch,B,H,W", [("vits14", 2, 240, 320), ("vitl14", 3, 518, 518)])

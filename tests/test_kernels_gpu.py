@@ -157,6 +157,121 @@ def test_gemm_weight_ring_depth_is_bit_identical(ops, M, N, K):
         assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize("M,N,K", [(11008, 1024, 1024), (11008, 1024, 4096), (11008 - 40, 1024, 256), (2752, 768, 384), (43808, 256, 512), (1216, 512, 2048)])
+def test_gemm_ping_pong_is_bit_identical(ops, M, N, K):
+    """Round 6: the ping-pong form of the 192-row tile (csrc/gemm_pp.hip, tile_hint 11: m-row 1 one barrier behind m-row 0, a quadrant of the
+    wave's sub-tile per phase, weights two K-tiles ahead in two buffers) against the large-tile kernel's 192-row list (tile_hint 3) on the fp32
+    residual-accumulate class: same tile, same K order, same epilogue arithmetic -> every output must carry the SAME BITS -- the fp32 stream, the
+    fp16 copy (raw and LeakyReLU), the LayerNorm partial sums and the in-kernel finalized (rstd, -mean rstd) -- with one and several tiles per
+    workgroup, a partial last row tile, K = 4 .. 64 K-tiles, overwrite / accumulate / copy-only outputs; and right (fp32 torch statement).
+    Shapes the kernel does not take (N % 256 != 0) fall back to the 192-row list under the same hint."""
+    A = rnd(M, K, seed=1).half()
+    W = rnd(N, K, scale=K ** -0.5, seed=2).half()
+    bias = rnd(N, seed=3)
+    ref = A.float() @ W.float().t() + bias
+    x0 = rnd(M, N, seed=5)
+    outs = {}
+    for hint in (3, 11):
+        res = []
+        for acc, act2 in ((1, ops.UD_ACT_NONE), (0, ops.UD_ACT_LRELU), (2, ops.UD_ACT_LRELU)):
+            x = x0.clone()
+            x16 = torch.zeros(M, N, dtype=torch.half, device="cuda")
+            ops.gemm(A=A, W=W, bias=bias, out=x, out2=x16, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, ldc2=N, epi=ops.UD_EPI_F32, accumulate=acc, act2=act2,
+                     tile_hint=hint)
+            res += [x, x16]
+        if N % 128 == 0 and N <= 1024:
+            x = x0.clone()
+            x16 = torch.zeros(M, N, dtype=torch.half, device="cuda")
+            stats = torch.zeros(M, N // 64, 2, device="cuda")
+            fin = torch.zeros(M, 2, device="cuda")
+            tk = torch.zeros(M // 128 + 2, dtype=torch.int32, device="cuda")
+            for _ in range(2):                       # twice: the tickets wrap to zero, the second launch must finalize again
+                fin.zero_()
+                ops.gemm(A=A, W=W, bias=bias, out=x, out2=x16, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, ldc2=N, epi=ops.UD_EPI_F32, accumulate=1,
+                         tile_hint=hint, row_stats_out=stats, row_stats_final=fin, row_stats_ticket=tk, ln_D=N, ln_eps=1e-6)
+            torch.cuda.synchronize()
+            assert tk.abs().sum().item() == 0
+            res += [x, x16, stats, fin]
+            # partial sums only (no in-kernel reduction)
+            x = x0.clone()
+            stats2 = torch.zeros(M, N // 64, 2, device="cuda")
+            ops.gemm(A=A, W=W, bias=bias, out=x, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, epi=ops.UD_EPI_F32, accumulate=1, tile_hint=hint, row_stats_out=stats2)
+            res += [x, stats2]
+        torch.cuda.synchronize()
+        outs[hint] = res
+    r = outs[11]
+    assert rel(r[0], x0 + ref) < 2e-5 and rel(r[1].float(), x0 + ref) < 1e-3
+    assert rel(r[2], ref) < 2e-5 and rel(r[3].float(), F.leaky_relu(ref, 0.01)) < 1e-3
+    assert torch.equal(r[4], x0) and rel(r[5].float(), F.leaky_relu(x0 + ref, 0.01)) < 1e-3          # accumulate == 2: the fp32 stream is not written
+    if len(r) > 6:
+        want = x0 + 2 * ref
+        assert rel(r[6], want) < 2e-5
+        mean, var = want.mean(dim=1), want.var(dim=1, unbiased=False)
+        rstd = (var + 1e-6).rsqrt()
+        assert rel(r[9][:, 0], rstd) < 1e-4 and rel(r[9][:, 1], -mean * rstd) < 1e-3
+    for a, b in zip(outs[3], outs[11]):
+        assert torch.equal(a, b)
+    if N % 256 == 0 and K % 128 == 0:
+        assert ops.lib.ud_gemm_pick(ops.C.byref(ops.mk(ops.UdGemm, A=A, W=W, bias=bias, out=x0, M=M, N=N, K=K, lda=K, ldw=K, ldc=N, epi=ops.UD_EPI_F32,
+                                                       accumulate=1, tile_hint=11))) == 11
+
+
+@pytest.mark.parametrize("conv", [False, True])
+def test_gemm_large_tile_k_split(ops, conv):
+    """Round 6: two-way K split of the 192-row tile list (gemm256_kernel SPK, tile_hint 10 / what auto picks for a one-round list on less than half
+    of the CUs with a long K: the decoder's stage-0 3x3 convolutions, M = 11008, N = 512, K = 4608): 2 * tiles workgroups, the later of a pair adds
+    its partner's fp32 partial tile.  Dense and zero-padded 3x3 A operands, fp16 + LeakyReLU and fp32 residual-accumulate + fp16 copy epilogues,
+    against the fp32 torch statement and the unsplit list (tile_hint 3); five launches in a row agree bit for bit (the join does not depend on
+    arrival order; the parity tickets carry over), and a scratch that is too small keeps the unsplit schedule."""
+    if conv:
+        B, H, W_, Cin, N = 8, 37, 37, 512, 512
+        rows_img = ((H * W_ + 7) // 8) * 8
+        M, K = B * rows_img, 9 * Cin
+        x = rnd(B, rows_img, Cin, seed=1).half()
+        Wg = rnd(N, K, scale=K ** -0.5, seed=2).half()
+        zeros = torch.zeros(256, dtype=torch.half, device="cuda")
+        kw = dict(A=x, W=Wg, zeros=zeros, M=M, N=N, K=K, ldw=K, amode=ops.UD_A_CONV3_ZERO, Himg=H, Wimg=W_, Cin=Cin, cstride=Cin, coff=0,
+                  rows_img=rows_img, img_stride=rows_img * Cin)
+        xin = x[:, :H * W_].float().view(B, H, W_, Cin).permute(0, 3, 1, 2)
+        valid = lambda t: t.view(B, rows_img, N)[:, :H * W_]
+    else:
+        M, N, K = 11008, 512, 2048
+        A = rnd(M, K, seed=1).half()
+        Wg = rnd(N, K, scale=K ** -0.5, seed=2).half()
+        kw = dict(A=A, W=Wg, M=M, N=N, K=K, lda=K, ldw=K)
+        valid = lambda t: t
+    bias = rnd(N, seed=3)
+    if conv:
+        ref = F.conv2d(xin, Wg.float().view(N, 3, 3, Cin).permute(0, 3, 1, 2), bias, padding=1).permute(0, 2, 3, 1).reshape(B, H * W_, N)
+    else:
+        ref = A.float() @ Wg.float().t() + bias
+    tiles = ((M + 191) // 192) * (N // 256)
+    ws = torch.empty(2 * tiles * 192 * 256, device="cuda")
+    cnt = torch.zeros(128, dtype=torch.int32, device="cuda")
+    sk = dict(splitk_ws=ws, splitk_cnt=cnt, splitk_ws_bytes=ws.numel() * 4)
+    assert ops.lib.ud_gemm_pick(ops.C.byref(ops.mk(ops.UdGemm, bias=bias, out=ws, ldc=N, epi=ops.UD_EPI_F16, tile_hint=10, **kw, **sk))) == 10
+    assert ops.lib.ud_gemm_pick(ops.C.byref(ops.mk(ops.UdGemm, bias=bias, out=ws, ldc=N, epi=ops.UD_EPI_F16, tile_hint=0, **kw, **sk))) == 10
+    small = dict(sk, splitk_ws_bytes=ws.numel() * 4 - 4)
+    assert ops.lib.ud_gemm_pick(ops.C.byref(ops.mk(ops.UdGemm, bias=bias, out=ws, ldc=N, epi=ops.UD_EPI_F16, tile_hint=0, **kw, **small))) != 10
+    x0 = rnd(M, N, seed=5)
+    runs = []
+    for hint in (10, 10, 0, 10, 10, 3):
+        out = torch.zeros(M, N, dtype=torch.half, device="cuda")
+        ops.gemm(bias=bias, out=out, ldc=N, epi=ops.UD_EPI_F16, act=ops.UD_ACT_LRELU, tile_hint=hint, **kw, **sk)
+        xx = x0.clone()
+        x16 = torch.zeros(M, N, dtype=torch.half, device="cuda")
+        ops.gemm(bias=bias, out=xx, out2=x16, ldc=N, ldc2=N, epi=ops.UD_EPI_F32, accumulate=1, act2=ops.UD_ACT_LRELU, tile_hint=hint, **kw, **sk)
+        runs.append((out, xx, x16))
+    torch.cuda.synchronize()
+    assert int(cnt.sum()) > 0 and int((cnt & 1).sum()) == 0               # tickets advanced in pairs
+    for out, xx, x16 in runs:
+        assert rel(valid(out).float(), F.leaky_relu(ref, 0.01)) < 1e-3
+        assert rel(valid(xx), valid(x0) + ref) < 2e-5
+        assert rel(valid(x16).float(), F.leaky_relu(valid(x0) + ref, 0.01)) < 1e-3
+    for r in runs[1:5]:
+        assert all(torch.equal(a, b) for a, b in zip(runs[0], r))
+
+
 def test_gemm_row_balanced_schedule_is_bit_identical(ops):
     """tile_hint 8 (row-balanced spans cut into 128 / 192 / 256-row tiles, one column group of workgroups per 256 outputs) only
     re-orders WHICH workgroup computes a row: every output element must carry the same bits as the classic tile list gives it --

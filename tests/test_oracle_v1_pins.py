@@ -1,7 +1,8 @@
 """Pins for the V1 restatement (oracle/restate_v1.py, oracle/synth_v1.py): the real reference (imported from /root/reference with the
 restated timm layers of oracle/stubs/timm) on the same seeded checkpoint -- authoring container only -- and golden vectors
-written from that run (tests/golden/v1_*.npz) everywhere else.  PARITY UNPINNED for what lives in un-vendored dependencies
-(timm layer semantics, xformers NystromAttention): see the header of oracle/restate_v1.py."""
+written from that run (tests/golden/v1_*.npz) everywhere else.  What lives in un-vendored dependencies is pinned through statement-by-statement
+restatements of the published sources: timm layers (oracle/stubs/timm) and xformers v0.0.26 NystromAttention (oracle/stubs/xformers; the
+reference's [b, n, h, d] call takes its plain-softmax branch, tests/test_oracle_nystrom_cpu.py) -- see the header of oracle/restate_v1.py."""
 import os
 import sys
 import warnings

@@ -39,4 +39,56 @@ done; done
 cat $O/gemm8p_vs_product.txt $O/inflight.txt; tail -3 $O/err.txt
 }
 
+# round 6, GPU call 3: the two-way K split of the large-tile list (gemm256_kernel SPK) on the stage-0 RCU convolutions against the 128 x 128
+# kernel they ran on and the unsplit 192-row list; the x4 fp32-accumulate launches as one large-tile list (re-measure of round 3's decision);
+# the GEMM kernel tests
+call3() {
+O=gpurun_out/r6c3 && mkdir -p $O
+timeout 600 python tools/r6_dec_ab.py --match dh.ups.0 --hints 1,3,10,0 2>&1 | grep -v amdgpu.ids > $O/stage0_split.txt
+timeout 600 python tools/r6_dec_ab.py --match "dec.adapters,dh.out,dh.fc2" --hints 0,2 2>&1 | grep -v amdgpu.ids > $O/x4_big.txt
+timeout 900 python -m pytest tests/test_kernels_gpu.py -q -m gpu -k "gemm" 2>&1 | grep -v "^$\|amdgpu.ids" | tail -8 > $O/gemm_tests.txt
+timeout 300 python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-extra-configs --no-kernel-timing 2>$O/err.txt | line "bench" > $O/bench.txt
+cat $O/stage0_split.txt $O/x4_big.txt $O/gemm_tests.txt $O/bench.txt; tail -3 $O/err.txt
+}
+
+# round 6, GPU call 4: ConvT depth-to-space launches and the stage-1 / stage-2 RCU convolutions per tile schedule
+call4() {
+O=gpurun_out/r6c4 && mkdir -p $O
+timeout 600 python tools/r6_dec_ab.py --match dh.convt --hints 0,1,2,3 2>&1 | grep -v amdgpu.ids > $O/d2s.txt
+timeout 600 python tools/r6_dec_ab.py --match "dh.ups.1,dh.ups.2,dh.to_latents" --hints 0,2,3 2>&1 | grep -v amdgpu.ids > $O/rcu.txt
+timeout 600 python tools/r6_dec_ab.py --match "dec.adapters" --hints 0,1 2>&1 | grep -v amdgpu.ids > $O/adapters.txt
+cat $O/d2s.txt $O/rcu.txt $O/adapters.txt
+}
+
+# round 6, GPU call 5: the ping-pong kernel (csrc/gemm_pp.hip) on the fp32 residual-accumulate class: bit identity with the 192-row list, the
+# K-split test, the four encoder GEMM launches with their real epilogues per schedule (UD_TILE_HINTS: 3 = 192-row list for proj / fc2, 11 =
+# ping-pong; qkv / fc1 ignore 11), interleaved, and the bench line against the previous library (ab/libprev.so = HEAD~ build, if present)
+call5() {
+O=gpurun_out/r6c5 && mkdir -p $O
+timeout 900 python -m pytest tests/test_kernels_gpu.py -q -m gpu -x -k "ping_pong or k_split or gemm" 2>&1 | grep -v "^$\|amdgpu.ids" | tail -12 > $O/tests.txt
+UD_TILE_HINTS=3,11,0 timeout 300 python tools/bench_enc_gemms.py 2>&1 | grep -v amdgpu.ids > $O/enc_gemms.txt
+UD_TILE_HINTS=11,3,0 timeout 300 python tools/bench_enc_gemms.py 2>&1 | grep -v amdgpu.ids >> $O/enc_gemms.txt
+for r in 1 2 3; do
+  timeout 300 python bench.py --steps 24 --warmup 4 --no-cpu-baseline --no-extra-configs --no-kernel-timing 2>$O/err.txt | line "new" >> $O/bench_ab.txt
+  [ -f ab/libprev.so ] && UNIDEPTH_HIP_LIB=$R/ab/libprev.so timeout 300 python bench.py --steps 24 --warmup 4 --no-cpu-baseline --no-extra-configs --no-kernel-timing 2>$O/err.txt | line "prev" >> $O/bench_ab.txt
+done
+cat $O/tests.txt $O/enc_gemms.txt $O/bench_ab.txt; tail -3 $O/err.txt
+}
+
+# round 6, GPU call 6: the whole GPU suite on the tree with the ping-pong proj / fc2 kernel, the K split of the stage-0 convolutions, the loud
+# camera-head time-out + serialised camera-head launches; the full bench line (live MFMA calibration, reference-as-shipped leg, per-launch table)
+call6() {
+O=gpurun_out/r6c6 && mkdir -p $O
+timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | grep -v "^$\|amdgpu.ids" | tail -15 > $O/tests.txt
+timeout 900 python bench.py --dump-ops $O/ops_per_launch.tsv 2>$O/err.txt > $O/bench.json
+line "bench" < $O/bench.json > $O/bench.txt
+cat $O/tests.txt $O/bench.txt; tail -3 $O/err.txt
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r6c6/bench.json').read().strip().splitlines()[-1])
+r=d['roofline']; print({k:r[k] for k in ('kernel','achieved','frac','attainable_this_box','frac_of_attainable','avg_launch_us','scope_frac','scope_ms_per_step')})
+print(d['configs'].get('reference_as_shipped_rocm')); print(d['configs']['v1_cnvnxtl_640x480_bs16'].get('value'), d['configs']['latency_bs1'])
+PY
+}
+
 "$@"

@@ -34,6 +34,7 @@ class UdGemm(C.Structure):
         ("splitk_ws", vp), ("splitk_cnt", vp), ("Hsrc", i32), ("Wsrc", i32), ("a_wrap", i32), ("w_wrap", i32), ("max_out", fp), ("max_init", i32), ("grp_rows", i32),
         ("row_stats_out", fp), ("row_stats_final", fp), ("row_stats_ticket", vp), ("row_stats_in", fp), ("wsum", fp), ("ln_slabs", i32), ("ln_D", i32), ("ln_eps", f32),
         ("up_src", fp), ("up_H", i32), ("up_W", i32), ("up_ld", i32), ("up_img_rows", i32),
+        ("splitk_ws_bytes", i64),
     ]
 
 
@@ -58,7 +59,7 @@ UD_CAM_MAX_PHASES = 24
 
 class UdCameraHead(C.Structure):
     _fields_ = [("ph", UdCamPhase * UD_CAM_MAX_PHASES), ("n_phases", i32), ("T", i32), ("H", i32), ("C", i32), ("scale", f32), ("eps", f32),
-                ("sync_ws", vp), ("workgroups", i32)]
+                ("sync_ws", vp), ("workgroups", i32), ("fail_host", vp), ("spin_limit", C.c_uint)]
 
 
 class UdDwConv7(C.Structure):
@@ -186,6 +187,7 @@ def _load():
         "ud_knn_split": [P(UdKnn)],
         "ud_extract_patches": [P(UdExtractPatches), vp],
         "ud_program_run": [vp, i32, i32, vp],
+        "ud_calib_mfma_stream": [vp, i32, i32, vp, C.POINTER(C.c_double), vp],
         "ud_version": [],
         "ud_struct_size": [i32],
     }

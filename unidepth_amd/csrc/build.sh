@@ -8,7 +8,7 @@ BD=${UD_BUILD_DIR:-build}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result"
 mkdir -p $BD
 pids=()
-for f in gemm.hip layernorm.hip pointwise.hip camera_f32.hip convnext.hip v1dec.hip; do
+for f in gemm.hip gemm_pp.hip calib.hip layernorm.hip pointwise.hip camera_f32.hip convnext.hip v1dec.hip; do
   ( hipcc $FLAGS "$@" -c $f -o $BD/${f%.hip}.o ) &
   pids+=($!)
 done

@@ -1,6 +1,7 @@
 // fp32 island for the camera head (see UdLinearF32 in include/unidepth_hip.h for why): 4 tokens per image, ~9 M weights,
 // latency-bound; plain fp32 FMAs are the right tool (no MFMA: at M = 4*B rows the matrix pipe would idle anyway).
 #include "ud_common.h"
+#include <mutex>
 #include <type_traits>
 
 namespace {
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(256) void camera_head_kernel(const UdCameraHead p) 
   const int ks = lane & 31;
   const int rq = (lane >> 5) + 2 * wv;
   unsigned barriers = 0;
+  const unsigned spin_limit = p.spin_limit ? p.spin_limit : CH_SPIN_LIMIT;
   if (tid == 0) s_dead = 0;
 
   // the weight slab of phase `ip` -> LDS buffer `buf`: rows [n0, n0 + ncol) of W are contiguous, copied in 1 KB wave pieces
@@ -438,8 +440,9 @@ __global__ __launch_bounds__(256) void camera_head_kernel(const UdCameraHead p) 
         unsigned spins = 0;
         while (__hip_atomic_load(p.sync_ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
           __builtin_amdgcn_s_sleep(4);
-          if (++spins > CH_SPIN_LIMIT) {                        // the grid is not co-resident (never on a whole MI355X): give up, flag it
+          if (++spins > spin_limit) {                           // the grid is not co-resident (never on a whole MI355X): give up, flag it
             __hip_atomic_store(p.sync_ws + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p.fail_host) __hip_atomic_store(p.fail_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             s_dead = 1;
             break;
           }
@@ -452,6 +455,19 @@ __global__ __launch_bounds__(256) void camera_head_kernel(const UdCameraHead p) 
   // the last workgroup out re-arms the counters for the next launch (everybody is past every barrier by then)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  // a timed-out barrier (this launch or an earlier one the caller has not acknowledged) makes the result LOUDLY wrong: the last phase's
+  // output (the camera parameters every ray and depth value derives from) becomes NaN.  Every workgroup that ends with the flag set writes
+  // the whole (tiny) output after its own last store; the workgroup that set the flag ends after setting it, so whichever normal store comes
+  // last, a NaN store follows it.
+  if (__hip_atomic_load(p.sync_ws + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+    const UdCamPhase& L = p.ph[p.n_phases - 1];
+    if (L.kind == 0) {
+      const ud_rsrc_t ro = ud_make_rsrc(L.out, (unsigned)L.M * (unsigned)L.ldc * 4u);
+      for (int i = tid; i < L.M * L.N; i += 256)
+        ch_st1(ro, ((unsigned)(i / L.N) * (unsigned)L.ldc + (unsigned)(i % L.N)) * 4u, __builtin_nanf(""));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   if (tid == 0) {
     const unsigned old = __hip_atomic_fetch_add(p.sync_ws + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old == (unsigned)G - 1u) {
@@ -556,7 +572,30 @@ extern "C" int ud_camera_head_f32(const UdCameraHead* desc, void* stream) {
       return UD_ERR_LAUNCH;
     }
   }
+  // one spinning grid at a time per device: a launch waits (on its own stream) for the previous camera-head launch of this process, wherever
+  // that was enqueued.  Two of these grids on different streams (pipelined requests) could otherwise each be PARTLY resident and starve each
+  // other at their barriers.  Two host calls per launch, nothing on the GPU when the streams are the same.
+  static std::mutex mu;
+  static hipEvent_t last[UD_MAX_DEVICES];
+  static bool have[UD_MAX_DEVICES];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= UD_MAX_DEVICES) dev = 0;
+  std::lock_guard<std::mutex> lk(mu);
+  if (have[dev]) {
+    if (hipStreamWaitEvent((hipStream_t)stream, last[dev], 0) != hipSuccess) {
+      ud_set_error("ud_camera_head_f32: cannot order the launch behind the previous camera-head launch");
+      return UD_ERR_LAUNCH;
+    }
+  } else if (hipEventCreateWithFlags(&last[dev], hipEventDisableTiming) != hipSuccess) {
+    ud_set_error("ud_camera_head_f32: cannot create the ordering event");
+    return UD_ERR_LAUNCH;
+  }
+  have[dev] = true;
   hipLaunchKernelGGL(camera_head_kernel, dim3(G), dim3(256), CH_LDS, (hipStream_t)stream, d);
   UD_CHECK_LAUNCH("ud_camera_head_f32 launch");
+  if (hipEventRecord(last[dev], (hipStream_t)stream) != hipSuccess) {
+    ud_set_error("ud_camera_head_f32: cannot record the ordering event");
+    return UD_ERR_LAUNCH;
+  }
   return UD_OK;
 }

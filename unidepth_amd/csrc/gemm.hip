@@ -774,11 +774,18 @@ __device__ __forceinline__ void ud_interleave_reads() {
 // layers, 114 us in the step).  The end-of-K-tile wait becomes a COUNTED vmcnt(4): A(kt+1) and W(kt+1) have landed, the four DMA
 // instructions of W(kt+2) stay in flight across the barrier (loads retire in order among themselves; stores only make the count
 // conservative).  The stream stays continuous across the workgroup's tiles: W runs two K-tiles ahead over the tile boundary as well.
-template <int MH, int EPI, int AMODE, bool BAL = false, bool LNC = false, bool GRP = false, bool W3 = false>
+// SPK (round 6; tile list with at most 128 tiles, K a multiple of 128): TWO workgroups per output tile, each multiplying one half of K --
+// blocks 2t / 2t+1 = K halves 0 / 1 of tile t.  A one-round list that fills less than half of the CUs (the decoder's stage-0 3x3 convolutions:
+// M = 11008, N = 512, K = 4608 -> 116 tiles of 192 x 256; they ran as 344 tiles of 128 x 128 at ~540 TFLOP/s) gets twice the workgroups and
+// half the K loop; the partial tiles meet through the same fence-free exchange as the 128 x 128 kernel's split (system-scope write-through
+// stores, vmcnt(0), one ticket per tile; the workgroup that draws the odd ticket adds its partner's partial and runs the epilogue; a + b is
+// order-independent, so the bits do not depend on which half finishes).
+template <int MH, int EPI, int AMODE, bool BAL = false, bool LNC = false, bool GRP = false, bool W3 = false, bool SPK = false>
 __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using C = BigCfg<MH>;
   static_assert(!W3 || (AMODE == UD_A_DENSE && !BAL && !GRP), "W3: dense A, tile list");
+  static_assert(!SPK || (!BAL && !LNC && !GRP && !W3 && (EPI == UD_EPI_F16 || EPI == UD_EPI_F32)), "K split: plain tile list, fp16 / fp32 epilogues");
   constexpr int RING_BYTES = W3 ? 2 * C::A_BYTES + 3 * 32768 : 2 * C::STAGE;     // LDS behind the operand ring: LNC tables / ticket flag
   static_assert(!LNC || (AMODE == UD_A_DENSE && (EPI == UD_EPI_F16 || EPI == UD_EPI_QKV)), "LayerNorm-folded consumer: dense A, fp16 outputs");
   constexpr int BM = C::BM;
@@ -787,7 +794,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wv >> 2, wn = wv & 3;
-  const int nk = p.K >> 6;
+  const int nk = SPK ? (p.K >> 7) : (p.K >> 6);             // SPK: this workgroup multiplies K-tiles [kbase, kbase + nk)
+  const int kbase = SPK ? (int)(blockIdx.x & 1) * nk : 0;
   const int tiles_n = (p.N + 255) >> 8;
   const int tiles_m = (p.M + BM - 1) / BM;
   const int nblk = tiles_m * tiles_n;
@@ -871,6 +879,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   auto b_stage = [&](int stg) -> char* { return W3 ? smem + 2 * C::A_BYTES + stg * 32768 : smem + stg * C::STAGE + C::A_BYTES; };
   auto issueA = [&](int kt, int stg, int mh) {
     char* sb = a_stage(stg) + wv * 1024;
+    kt += kbase;
     if constexpr (AMODE == UD_A_DENSE) {
       const int ka = kt >= a_wt ? kt - a_wt : kt;
 #pragma unroll
@@ -898,6 +907,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   };
   auto issueB = [&](int kt, int stg) {
     char* sb = b_stage(stg) + wv * 1024;
+    kt += kbase;
     const int kb = kt >= w_wt ? kt - w_wt : kt;
 #pragma unroll
     for (int i = 0; i < 4; ++i) ud_bufl16(rW, pb[i], kb * 128, sb + i * 8192);
@@ -926,7 +936,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   int tl = 0;                                                    // local index of the current tile = its table
 
   int m0, n0, mhc = MH;
-  int t = blockIdx.x;          // classic: index into the tile list; balanced: index of the tile inside this workgroup's row span
+  int t = SPK ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;          // classic: index into the tile list; balanced: index of the tile inside this workgroup's row span
   int bal_k = 0, bal_tb = 0, bal_te = 0, bal_u0 = 0, bal_n0 = 0;
   if constexpr (BAL) {
     const int G = gridDim.x;                       // = cpc * tiles_n (launch256bal)
@@ -967,7 +977,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
     }
   };
   const int tcount = BAL ? bal_k : nblk;
-  const int tstep = BAL ? 1 : (int)gridDim.x;
+  const int tstep = BAL ? 1 : (SPK ? nblk : (int)gridDim.x);      // SPK: one tile (half) per workgroup
   tile_at(t, m0, n0, mhc);
   setup(m0, n0, mhc);
   issue(0, 0, mhc);
@@ -1015,7 +1025,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
     // Issued before the wait for the first operand tile: both bursts are in flight together.
     bool counted = false;        // the first tile's operand wait may leave the residual loads in flight (full tiles: their number is exact)
     if constexpr (ACC_EPI) {
-      if (p.accumulate) {
+      if (p.accumulate && kbase == 0) {                  // (K split: the old values enter through the first half only)
         int ln = lane;
         asm volatile("" : "+v"(ln));
         if (first && (m0 + BMC <= p.M) && (n0 + 256 <= p.N) && p.rows_in == 0) {
@@ -1159,6 +1169,37 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
       kloop(BoolTag<true>{});
     }
     UD_STAMP(2);
+    if constexpr (SPK) {
+      // ---- join of the two K halves (see the template comment; same protocol as gemm_body's SPLIT)
+      constexpr int NQ = TMC * 4;
+      const int half = (int)(blockIdx.x & 1);
+      f32x4* mine = (f32x4*)p.splitk_ws + ((size_t)(t * 2 + half) * 8 + wv) * (NQ * 64) + lane;
+      const f32x4* other = (const f32x4*)p.splitk_ws + ((size_t)(t * 2 + (half ^ 1)) * 8 + wv) * (NQ * 64) + lane;
+#pragma unroll
+      for (int i = 0; i < TMC; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 v = acc[i][j];
+          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 2" ::"v"(mine + (i * 4 + j) * 64), "v"(v) : "memory");
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();            // every wave's partial is out (and nobody reads operand tiles any more)
+      unsigned* tk = (unsigned*)(smem + RING_BYTES);
+      if (tid == 0) *tk = atomicAdd((unsigned*)p.splitk_cnt + t, 1u);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const unsigned ticket = *tk;
+      if ((ticket & 1u) == 0) return;          // first of the pair: the partner finishes the tile (tickets: parity, never reset)
+#pragma unroll
+      for (int c = 0; c < NQ / 8; ++c) {
+        f32x4 o[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(o[q]) : "v"(other + (c * 8 + q) * 64) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7])::"memory");
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[(c * 8 + q) >> 2][(c * 8 + q) & 3] += o[q];     // a + b == b + a: independent of which half came last
+      }
+    }
     const float* const lnst = LNC ? lds_rstd + (tl & 1) * 256 + wm * (BMC / 2) : nullptr;   // rstd of the wave's rows
 
     // =================================== epilogue ===================================
@@ -1486,6 +1527,38 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
   }
 }
 
+// K split of the 192-row tile list (gemm256_kernel SPK): 2 * tiles workgroups; scratch per (tile, half) = 192 x 256 fp32
+constexpr size_t SPK_SLOT_BYTES = (size_t)192 * 256 * 4;
+template <int EPI, int AMODE>
+int launch256sk(const UdGemm& d, hipStream_t s) {
+  const int tiles = ((d.N + 255) >> 8) * ((d.M + 191) / 192);
+  const int lds = 2 * BigCfg<3>::STAGE + 64;
+  static bool attr_set[UD_MAX_DEVICES];
+  if (!ud_attr_once(attr_set)) {
+    if (hipFuncSetAttribute((const void*)gemm256_kernel<3, EPI, AMODE, false, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      ud_set_error("ud_gemm_f16: cannot reserve the LDS ring of the large-tile kernel (K split)");
+      return UD_ERR_LAUNCH;
+    }
+  }
+  hipLaunchKernelGGL((gemm256_kernel<3, EPI, AMODE, false, false, false, false, true>), dim3(2 * tiles), dim3(512), lds, s, d);
+  UD_CHECK_LAUNCH("ud_gemm_f16 (large tile, K split) launch");
+  return UD_OK;
+}
+// eligibility of the K split of the large-tile list: a one-round list on at most half of the CUs, long K, plain fp16 / fp32 epilogues,
+// caller-provided scratch of 2 * tiles * SPK_SLOT_BYTES
+inline bool big_split_ok(const UdGemm& d) {
+#ifdef UD_AB_PREV
+  return false;
+#endif
+  if (d.amode != UD_A_DENSE && d.amode != UD_A_CONV3_ZERO) return false;
+  if (d.epi != UD_EPI_F16 && d.epi != UD_EPI_F32) return false;
+  if (d.groups > 1 || d.row_stats_in || d.row_stats_out || d.max_out || d.a_wrap || d.w_wrap || (d.K & 127) || d.K < 2048) return false;
+  const int tiles = ((d.N + 255) >> 8) * ((d.M + 191) / 192);
+  if (tiles > 128 || tiles < 32 || d.M < 1024 || d.N < 192) return false;
+  if (!d.splitk_ws || !d.splitk_cnt || (size_t)d.splitk_ws_bytes < 2 * (size_t)tiles * SPK_SLOT_BYTES) return false;
+  return true;
+}
+
 // W3 form of the 192-row tile list (3-deep weight ring, see the kernel): dense problems with at least two K-tiles.
 inline bool w3_enabled() { return true; }
 
@@ -1570,8 +1643,10 @@ inline int pick_tiles(const UdGemm& d) {
     if (a_bytes >= 2147483648.0 || 2.0 * d.N * d.ldw >= 2147483648.0) return 0;
   }
   if (d.epi == UD_EPI_QKV && (d.vsplit & 255)) return 0;
-  if (d.tile_hint == 1 || (d.tile_hint >= 5 && d.tile_hint != 8 && d.tile_hint != 9)) return 0;
+  if (d.tile_hint == 1 || (d.tile_hint >= 5 && d.tile_hint != 8 && d.tile_hint != 9 && d.tile_hint != 10 && d.tile_hint != 11)) return 0;
+  if (d.tile_hint == 11) return 3;                              // ping-pong form refused (gemm_pp.hip ud_gemm_pp_ok): the 192-row list
   if (d.tile_hint == 2) return 4;
+  if (d.tile_hint == 10) return big_split_ok(d) ? 10 : 0;       // 10: 192-row tile list with the two-way K split (when eligible)
   if (d.tile_hint == 3 || d.tile_hint == 9) return 3;      // 9: 192-row tile list with the 2-deep weight ring (A/B and tests of the 3-deep form)
   const bool bal_ok = d.amode == UD_A_DENSE && (d.epi == UD_EPI_F16 || d.epi == UD_EPI_F32 || d.epi == UD_EPI_QKV) && bal_cpc(d) > 0;
   if (d.tile_hint == 8 && bal_ok) return 8;
@@ -1587,6 +1662,10 @@ inline int pick_tiles(const UdGemm& d) {
   double t_big = t256 <= t192 ? t256 : t192;
   int which = t256 <= t192 ? 4 : 3;
   if (tbal < 0.985 * t_big) { t_big = tbal; which = 8; }      // measured: fc1 94.5 vs 98.5 us (model 95.5 / 98), qkv 82 vs 74.5 (80.5 / 78.5)
+  if (big_split_ok(d)) {                                       // half the K loop on twice the workgroups + ~6 us for the exchange of the partial tiles
+    const double tsplit = 8.0 + 0.5 * 23.5 * kk + 6.0;
+    if (tsplit < t_big && tsplit < 0.93 * t_small) return 10;
+  }
   if (t_big >= 0.93 * t_small) return 0;
   return which;
 }
@@ -1598,6 +1677,7 @@ inline int big_tiles_per_wg(const UdGemm& d, int which) {
     const int U = (d.M + 63) >> 6;
     return (((U + cpc - 1) / cpc) + 3) >> 2;
   }
+  if (which == 10) return 1;
   const int bm = which == 3 ? 192 : 256;
   const int tiles = ((d.N + 255) >> 8) * ((d.M + bm - 1) / bm);
   return (tiles + 255) / 256;
@@ -1614,7 +1694,10 @@ int launch_big(const UdGemm& d, hipStream_t s, int which) {
   if constexpr (AMODE == UD_A_DENSE && (EPI == UD_EPI_F16 || EPI == UD_EPI_F32 || EPI == UD_EPI_QKV)) {
     if (which == 8 && !d.row_stats_final) return launch256bal<EPI>(d, s);
   }
-  if (which == 8) which = 3;               // in-kernel statistics reduction: tickets are per row tile of ONE height (tile list only)
+  if constexpr (EPI == UD_EPI_F16 || EPI == UD_EPI_F32) {
+    if (which == 10) return launch256sk<EPI, AMODE>(d, s);
+  }
+  if (which == 8 || which == 10) which = 3;               // in-kernel statistics reduction: tickets are per row tile of ONE height (tile list only)
   return which == 3 ? launch256<3, EPI, AMODE>(d, s) : launch256<4, EPI, AMODE>(d, s);
 }
 
@@ -2094,7 +2177,12 @@ inline bool grouped_as_big(const UdGemm& d, UdGemm& m) {
   // SLOWER as 344 large tiles with the residual preload exposed per tile (dh.out 68 -> 80 us, dh.fc2 147 -> 164 us, adapters 89 -> 86)
   // than as blockIdx.z slices of the 128-row kernel; dh.fc1 198 -> 135 us, dh.kv 87 -> 66 us, dh.q 50 -> 44 us (same-run table,
   // profiles/r03_ops_per_launch.tsv against the r3c5 run)
+  // round 6 (tools/r6_dec_ab.py, same process, interleaved): the non-accumulating fp32 launch (the four input adapters, K = 1024) 80 -> 70 us as one
+  // large-tile list; the accumulating ones unchanged or slower again (dh.out 58 / 58 us, dh.fc2 150 / 158 us)
+#ifdef UD_AB_PREV
   if (d.epi != UD_EPI_F16 && d.epi != UD_EPI_QKV) return false;
+#endif
+  if (d.epi != UD_EPI_F16 && d.epi != UD_EPI_QKV && !(d.epi == UD_EPI_F32 && (d.tile_hint == 2 || (d.accumulate == 0 && d.K >= 1024)))) return false;
   if (!(d.gA == 0 || d.gA == (long long)d.M * d.lda) || d.gOut != (long long)d.M * d.ldc) return false;
   if (d.bias && d.gBias < 0) return false;
   if (d.out2) {
@@ -2114,6 +2202,23 @@ inline bool grouped_as_big(const UdGemm& d, UdGemm& m) {
   return bt == 4 || bt == 3 || bt == 8;         // the merged problem is large enough for the large-tile kernel (it then runs 256-row tiles)
 }
 
+}  // namespace
+
+// ping-pong form of the 192-row tile for the fp32 residual-accumulate class (gemm_pp.hip): one-round tile lists (tile_hint 11 forces it
+// where eligible, 0 picks it when the cost model would take the 192-row list and the list fits one round)
+bool ud_gemm_pp_ok(const UdGemm& d);
+int ud_gemm_pp_launch(const UdGemm& d, hipStream_t s);
+namespace {
+inline bool pp_pick(const UdGemm& d) {
+#ifdef UD_AB_PREV      // A/B builds only (tools/r6/sessions.sh: ab/libprev.so = this tree with the round-6 schedules switched off, same ABI)
+  return false;
+#endif
+  if (!ud_gemm_pp_ok(d)) return false;
+  if (d.tile_hint == 11) return true;
+  if (d.tile_hint != 0) return false;
+  const int tiles = (d.N >> 8) * ((d.M + 191) / 192);
+  return tiles <= 256 && tiles >= 128 && pick_tiles(d) == 3;
+}
 }  // namespace
 
 extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
@@ -2249,6 +2354,7 @@ extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
       UdGemm mg;
       if (grouped_as_big(d, mg)) return launch256<4, UD_EPI_F32, UD_A_DENSE, false, true>(mg, s);
     }
+    if (pp_pick(d)) return ud_gemm_pp_launch(d, s);
     if (const int bt = pick_tiles(d))
       return d.amode == UD_A_DENSE ? launch_big<UD_EPI_F32>(d, s, bt) : launch_big<UD_EPI_F32, UD_A_CONV3_ZERO>(d, s, bt);
     if (d.amode == UD_A_DENSE) return dispatch_bn<UD_EPI_F32, UD_A_DENSE>(d, s);
@@ -2265,7 +2371,8 @@ extern "C" int ud_trace_set(void* buf) {
 #endif
 
 // Which kernel ud_gemm_f16 would launch for this descriptor (for profiling labels): 0/1/2 = 128-row kernels with BN 128/64/32,
-// 3 = 192x256 tiles, 4 = 256x256 tiles, 5 = halo-tile conv, 6 / 7 = 128x128 pipelined ring without / with the K split, 8 = row-balanced;
+// 3 = 192x256 tiles, 4 = 256x256 tiles, 5 = halo-tile conv, 6 / 7 = 128x128 pipelined ring without / with the K split, 8 = row-balanced,
+// 10 = 192x256 tiles with the two-way K split, 11 = 192x256 tiles in the ping-pong form (gemm_pp.hip);
 // + 16 when the folded-LayerNorm consumer instantiation runs (row_stats_in), + 32 for a grouped problem run as one large-tile launch.
 extern "C" int ud_gemm_pick(const UdGemm* desc) {
   const UdGemm& d = *desc;
@@ -2274,6 +2381,7 @@ extern "C" int ud_gemm_pick(const UdGemm* desc) {
     if ((d.epi == UD_EPI_F16 || d.epi == UD_EPI_F32 || d.epi == UD_EPI_QKV) && grouped_as_big(d, mg)) return 4 + 32;
   }
   if (conv_tile_ok(d) && (d.epi == UD_EPI_HEAD || d.epi == UD_EPI_F16)) return 5;
+  if (d.epi == UD_EPI_F32 && pp_pick(d)) return 11;
   if (d.epi != UD_EPI_HEAD) {
     int bt = pick_tiles(d);
     if (bt == 8 && d.row_stats_final) bt = 3;          // launch_big: the in-kernel statistics reduction runs on the 192-row tile list

@@ -38,7 +38,7 @@ def mk(struct, **kw):
     return d
 
 
-def camera_head_desc(phases, T, H, Cc, scale, eps, sync_ws, workgroups=0):
+def camera_head_desc(phases, T, H, Cc, scale, eps, sync_ws, workgroups=0, fail_host=None, spin_limit=0):
     """UdCameraHead from a list of phase dicts (UdCamPhase fields; tensors become device pointers, an int is a raw address)."""
     d = UdCameraHead()
     assert len(phases) <= len(d.ph), "too many phases for UdCameraHead"
@@ -47,6 +47,8 @@ def camera_head_desc(phases, T, H, Cc, scale, eps, sync_ws, workgroups=0):
             setattr(d.ph[i], k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
     d.n_phases, d.T, d.H, d.C, d.scale, d.eps, d.workgroups = len(phases), T, H, Cc, scale, eps, workgroups
     d.sync_ws = sync_ws.data_ptr() if isinstance(sync_ws, torch.Tensor) else sync_ws
+    d.fail_host = fail_host.data_ptr() if isinstance(fail_host, torch.Tensor) else fail_host
+    d.spin_limit = spin_limit
     return d
 
 
@@ -141,6 +143,20 @@ class Program:
                 self._splitk[key] = (torch.empty(256 * 16384, dtype=torch.float32, device=dev), torch.zeros(128, dtype=torch.int32, device=dev))
                 self.keep += list(self._splitk[key])
             kw["splitk_ws"], kw["splitk_cnt"] = self._splitk[key]
+        tiles192 = -(-kw["M"] // 192) * -(-n // 256)
+        if (g == 1 and kw.get("amode", 0) in (UD_A_DENSE, UD_A_CONV3_ZERO) and kw.get("epi", 0) in (UD_EPI_F16, UD_EPI_F32) and 32 <= tiles192 <= 128
+                and kw["K"] >= 2048 and kw["K"] % 128 == 0 and "splitk_ws" not in kw and kw.get("row_stats_out") is None
+                and kw.get("row_stats_in") is None and kw.get("max_out") is None and not kw.get("a_wrap") and not kw.get("w_wrap")):
+            # two-way K split of the large-tile list (UdGemm.splitk_ws_bytes): one scratch per program, sized for its largest user
+            if not isinstance(self._splitk, dict):
+                self._splitk = {}
+            need = 2 * tiles192 * 192 * 256 * 4
+            if 1 not in self._splitk or self._splitk[1][0].numel() * 4 < need:
+                dev = kw["A"].device
+                self._splitk[1] = (torch.empty(need // 4, dtype=torch.float32, device=dev), torch.zeros(128, dtype=torch.int32, device=dev))
+                self.keep += list(self._splitk[1])
+            kw["splitk_ws"], kw["splitk_cnt"] = self._splitk[1]
+            kw["splitk_ws_bytes"] = self._splitk[1][0].numel() * 4
         d = mk(UdGemm, **kw)
         pick, epi, amode = lib.ud_gemm_pick(C.byref(d)), kw.get("epi", 0), kw.get("amode", 0)
         lnc, grp = "true" if pick & 16 else "false", "true" if pick & 32 else "false"
@@ -152,9 +168,13 @@ class Program:
         elif pick <= 4:
             # 7th template argument: the 3-deep weight ring of the 192-row tile list (csrc/gemm.hip launch256: dense A, not grouped, K >= 128)
             w3 = pick == 3 and amode == UD_A_DENSE and grp == "false" and kw["K"] >= 128 and kw.get("tile_hint", 0) != 9
-            cls = "gemm256_kernel<%d, %d, %d, false, %s, %s, %s>" % (pick, epi, amode, lnc, grp, "true" if w3 else "false")
+            cls = "gemm256_kernel<%d, %d, %d, false, %s, %s, %s, false>" % (pick, epi, amode, lnc, grp, "true" if w3 else "false")
         elif pick == 8:     # row-balanced schedule of the 256-column kernel
-            cls = "gemm256_kernel<4, %d, %d, true, %s, false, false>" % (epi, amode, lnc)
+            cls = "gemm256_kernel<4, %d, %d, true, %s, false, false, false>" % (epi, amode, lnc)
+        elif pick == 11:    # 192-row tiles, ping-pong schedule (csrc/gemm_pp.hip)
+            cls = "gemm_pp_f32_kernel<3>"
+        elif pick == 10:    # 192-row tile list, two-way K split (2 * tiles workgroups)
+            cls = "gemm256_kernel<3, %d, %d, false, false, false, false, true>" % (epi, amode)
         elif amode == 3 and kw.get("Cin", 0) == 64 and epi == UD_EPI_HEAD:
             cls = "conv_head_regw_kernel"                       # head conv with its weights in registers
         else:

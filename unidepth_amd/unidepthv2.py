@@ -241,6 +241,9 @@ class _Plan:
         ch = z(Mc, 4 * C, dtype=f32); cqkv = z(Mc, 3 * C, dtype=f32); cao = z(Mc, C, dtype=f32); t = z(Mc, C, dtype=f32); raw = z(Mc, 1, dtype=f32)
         scale_d = meta["hd"] ** -0.5
         self.cam_sync = z(16, dtype=torch.int32)
+        # host-mapped word the one-launch camera head sets (system-scope store) when one of its grid barriers times out: polled by the next
+        # infer() without a device synchronisation (UniDepthV2._check_camera_head); the kernel also turns that call's camera parameters into NaN
+        self.cam_fail = torch.zeros(1, dtype=torch.int32).pin_memory() if dev.type == "cuda" else None
 
         def lin(x, pre, out, M, N, K, ldx, ldc, **kw):
             d = dict(x=x, W=w[pre + ".w"], out=out, M=M, N=N, K=K, ldx=ldx, ldc=ldc, kind=0, sync=1)
@@ -264,8 +267,9 @@ class _Plan:
             phases += mlp_phases(blk, t, t, 1)
         phases += mlp_phases("cam.out.", t, raw, 0, n_out=1)
         phases[-1]["sync"] = 0
-        head = ops.camera_head_desc(phases, 4, Hd, C, scale_d, 1e-5, self.cam_sync)
-        if ops.camera_head_supported(head):
+        head = ops.camera_head_desc(phases, 4, Hd, C, scale_d, 1e-5, self.cam_sync, fail_host=self.cam_fail, spin_limit=model._cam_spin_limit)
+        self.cam_one_launch = model._cam_one_launch and ops.camera_head_supported(head)
+        if self.cam_one_launch:
             nw = sum(ph["N"] * ph["K"] for ph in phases if ph["kind"] == 0)
             P.camera_head(head, keep=[*clsn, ct, ch, cqkv, cao, t, raw, self.cam_sync], flops=2.0 * Mc * nw, nbytes=4.0 * nw)
         else:
@@ -473,6 +477,8 @@ class UniDepthV2(EngineModule):
         self._plans: "collections.OrderedDict" = collections.OrderedDict()
         self.max_plans = int(os.environ.get("UNIDEPTH_MAX_PLANS", "6"))   # LRU bound on cached (batch, shape, camera, slot) plans
         self._pos_cache: dict = {}
+        self._cam_one_launch = True        # False after a reported grid-barrier time-out of the one-launch camera head (_check_camera_head)
+        self._cam_spin_limit = 0           # 0 = the kernel's default (seconds); tests force the time-out with 1
         # True: a plan's launch program is replayed as ONE hipGraph launch (recorded on the second call of a signature).  For the launch-bound
         # small-batch calls (bs = 1: ~280 kernels of 2-10 us each); at bs = 8 the stream is never idle and eager replay is as fast.
 
@@ -639,6 +645,7 @@ class UniDepthV2(EngineModule):
             if mixed:
                 assert cam_nb == B, f"BatchCamera of {cam_nb} cameras for a batch of {B} images (one per image)"
                 gt_mode = cam_obj.gt_modes
+            self._check_camera_head()
             plan = self._plan(B, H, W, cam_nb, is_u8, bool(normalize), int(slot), gt_mode)
             plan.rgb.copy_(rgb if is_u8 else rgb.float(), non_blocking=True)
             if mixed:
@@ -669,6 +676,20 @@ class UniDepthV2(EngineModule):
                 plan.kinv_gt.copy_(torch.inverse(Kn).reshape(-1, 9))
             self._run(plan, 0, len(plan.prog), taps)
             return self._collect(plan, B)
+
+    def _check_camera_head(self):
+        """The one-launch camera head (csrc/camera_f32.hip) needs its grid co-resident; a barrier that times out (CU mask, partitioned device,
+        foreign kernels holding CUs) sets a host-mapped word and turns that call's intrinsics / rays / depth into NaN.  Polled here, at the
+        start of the next call, without a device synchronisation: the failure is reported once, the model switches to the per-layer launches
+        (same arithmetic, no grid barrier) for every later call."""
+        for plan in self._plans.values():
+            if plan.cam_fail is not None and int(plan.cam_fail[0]):
+                torch.cuda.synchronize(self._device)
+                self._cam_one_launch = False
+                self.clear_plans()
+                raise RuntimeError("unidepth_amd: a grid barrier of the one-launch camera head timed out in an earlier infer() call (its workgroups "
+                                   "were not co-resident on the device); that call returned NaN intrinsics, rays and depth.  This model now runs the "
+                                   "camera head as per-layer launches; repeat the failed call.")
 
     @staticmethod
     def _run(plan: _Plan, first: int, last: int, taps=None):
