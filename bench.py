@@ -151,13 +151,35 @@ def main():
     from unidepth_amd.pipeline import InferPipeline
     pipe = InferPipeline(model, depth=max(1, args.inflight))
 
+    # N > 1 over RCCL: the exchange step runs through the C-ABI entry (ud_rccl_allgather_outputs, the library's own communicator; torch.distributed
+    # only carries its unique id) when EVERY rank could create that communicator, otherwise through torch.distributed's RCCL group.  Which one ran
+    # is reported in the `rccl` block.
+    exchange_route = {"cabi": False, "note": "torch.distributed"}
+    if world > 1 and backend == "nccl" and not os.environ.get("UD_BENCH_TORCH_EXCHANGE"):
+        from unidepth_amd import dist as ud_dist
+        try:
+            ud_dist.init_cabi_exchange()
+            mine_ok, why = 1, ""
+        except Exception as e:                                   # e.g. librccl missing: every rank must take the same route
+            mine_ok, why = 0, repr(e)[:200]
+        flag = torch.tensor([mine_ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()):
+            exchange_route.update(cabi=True, note="C-ABI ud_rccl_allgather_outputs (library communicator; torch.distributed = bootstrap only)")
+        else:
+            if mine_ok:
+                ud_dist.finalize_cabi_exchange()
+            exchange_route["note"] = "torch.distributed (C-ABI communicator not created on every rank" + (": " + why if why else "") + ")"
+
     def gather(out, algo=None):
         # one exchange step: requested outputs packed per image, ONE message per peer (xGMI is point-to-point: few, larger messages);
         # "collective" = RCCL all_gather_into_tensor, "direct" = all-pairs send / recv group (unidepth_amd/dist.py explains the choice)
-        from unidepth_amd.dist import all_gather_direct
+        from unidepth_amd.dist import _cabi_allgather, all_gather_direct
         packed = torch.cat([out[k].reshape(B, -1) for k in gather_keys], dim=1)
         gathered = torch.empty((world * B, packed.shape[1]), dtype=packed.dtype, device=dev)
-        if (algo or args.gather_algo) == "direct":
+        if exchange_route["cabi"]:                                   # the library's own communicator (ud_rccl_allgather_outputs)
+            _cabi_allgather(gathered, packed.contiguous(), (algo or args.gather_algo) == "direct")
+        elif (algo or args.gather_algo) == "direct":
             all_gather_direct(gathered, packed)
         elif backend == "nccl":
             dist.all_gather_into_tensor(gathered, packed)
@@ -231,6 +253,7 @@ def main():
 
     if world > 1:
         result["rccl"] = rccl_report(torch, dist, model, rgb, gather, timed, args, world, rank, dev, backend, B, ms_per_step)
+        result["rccl"]["exchange_route"] = exchange_route["note"]
     if rank == 0:
         fl = flops_per_image()
         result["model_tflops_per_s"] = round(value * fl["total"] / 1e12 / world, 2)
@@ -252,6 +275,8 @@ def main():
         print(json.dumps(result))
     if world > 1:
         dist.barrier()
+        if exchange_route["cabi"]:
+            ud_dist.finalize_cabi_exchange()
         dist.destroy_process_group()
 
 

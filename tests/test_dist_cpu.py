@@ -107,6 +107,70 @@ def test_data_parallel_local_shards_equal_global_batch_gloo(world, B):
     assert sorted(res) == [(r, True) for r in range(world)]
 
 
+def _worker_cabi(rank, world, port, B, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ctypes as C
+    from unidepth_amd import _lib
+    from unidepth_amd import dist as dmod
+    g = torch.Generator().manual_seed(0)
+    rgb = torch.randint(0, 256, (B, 3, 6, 5), dtype=torch.uint8, generator=g)
+    keys = ("depth", "intrinsics", "confidence")
+    ref = {a: dmod.infer_data_parallel(_FakeModel(), rgb, keys=keys, gather_algo=a) for a in ("collective", "direct")}     # torch.distributed route
+    # the library's communicator, with RCCL replaced by stand-ins on this GPU-less box: the unique id must reach every rank through the
+    # torch.distributed bootstrap, and the exchange must be called once per gather with this rank's padded block
+    seen = {"uid": None, "init": None, "calls": []}
+
+    def fake_unique_id(buf):
+        C.memmove(buf, bytes(range(128)), 128)
+        return 0
+
+    def fake_init(uid, w, r):
+        seen["uid"], seen["init"] = bytes(uid[:128]) if isinstance(uid, (bytes, bytearray)) else bytes(C.string_at(uid, 128)), (w, r)
+        return 0
+
+    def fake_allgather(buf, mine, direct):
+        seen["calls"].append((mine.numel() * mine.element_size(), bool(direct), mine.is_contiguous()))
+        dist.all_gather(list(buf.chunk(world)), mine)
+
+    _lib.lib.ud_rccl_unique_id, _lib.lib.ud_rccl_init, _lib.lib.ud_rccl_finalize = fake_unique_id, fake_init, lambda: 0
+    dmod._cabi_allgather, dmod._on_device = fake_allgather, lambda t: True
+    assert not dmod.cabi_exchange_ready()
+    dmod.init_cabi_exchange()
+    ok = dmod.cabi_exchange_ready() and seen["uid"] == bytes(range(128)) and seen["init"] == (world, rank)
+    for a in ("collective", "direct"):
+        seen["calls"].clear()
+        out = dmod.infer_data_parallel(_FakeModel(), rgb, keys=keys, gather_algo=a)
+        ok = ok and all(torch.equal(out[k], ref[a][k]) for k in keys) and out["depth"].shape[0] == B
+        per = -(-B // world)
+        row_bytes = (6 * 5 + 9 + 6 * 5) * 4                  # depth + intrinsics + confidence packed per image, fp32
+        ok = ok and seen["calls"] == [(per * row_bytes, a == "direct", True)]
+    dmod.finalize_cabi_exchange()
+    ok = ok and not dmod.cabi_exchange_ready()
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,B", [(2, 8), (2, 5), (3, 7)])
+def test_data_parallel_cabi_exchange_route_equals_torch_route_gloo(world, B):
+    """with the library's communicator initialised (dist.init_cabi_exchange: torch.distributed carries only the unique id)
+    the gathers go through ud_rccl_allgather_outputs -- ONE call per exchange step with this rank's padded packed block -- and return the
+    same bits as the torch.distributed route, for both exchange forms, even and uneven shards.  (RCCL itself is replaced by a gloo stand-in
+    here; the real entry runs in tests/test_rccl_gpu.py.)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_cabi, args=(r, world, port, B, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(r, True) for r in range(world)]
+
+
 def test_shard_bounds():
     from unidepth_amd.dist import shard_bounds
     assert shard_bounds(64, 8) == [(i * 8, i * 8 + 8) for i in range(8)]

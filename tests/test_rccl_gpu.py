@@ -75,3 +75,34 @@ def test_cabi_allgather_single_rank_communicator():
     finally:
         assert L.ud_rccl_finalize() == 0
     assert L.ud_rccl_allgather_outputs(src.data_ptr(), src.data_ptr(), 16, 0, None) != 0   # no communicator any more
+
+
+def test_dist_module_routes_gathers_through_the_cabi_communicator():
+    """unidepth_amd.dist with the library's communicator (init_cabi_exchange: torch.distributed, here a one-rank gloo group, only carries the
+    unique id): all_gather_batch of device tensors goes through ud_rccl_allgather_outputs for both exchange forms and returns its input; after
+    finalize_cabi_exchange the torch.distributed route is back.  The two-rank form of the same call runs in test_bench_two_ranks_rccl."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import socket
+    import torch.distributed as dist
+    from unidepth_amd import dist as ud_dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        calls = []
+        real = ud_dist._cabi_allgather
+        ud_dist._cabi_allgather = lambda buf, mine, direct: (calls.append(bool(direct)), real(buf, mine, direct))[1]
+        ud_dist.init_cabi_exchange()
+        assert ud_dist.cabi_exchange_ready()
+        x = torch.randn(5, 37, device="cuda")
+        for algo in ("collective", "direct"):
+            y = ud_dist.all_gather_batch(x, [5], algo=algo)
+            torch.cuda.synchronize()
+            assert torch.equal(x, y)
+        assert calls == [False, True]
+        ud_dist.finalize_cabi_exchange()
+        assert not ud_dist.cabi_exchange_ready()
+        ud_dist._cabi_allgather = real
+    finally:
+        ud_dist.finalize_cabi_exchange()
+        dist.destroy_process_group()

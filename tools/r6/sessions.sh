@@ -91,4 +91,21 @@ print(d['configs'].get('reference_as_shipped_rocm')); print(d['configs']['v1_cnv
 PY
 }
 
+# round 6, GPU call 7: the camera-head failure tests, the C-ABI exchange route, the software-pipelined depth-to-space epilogue (D2S kernel tests, the
+# three ConvT launches new / previous library, same box), cost of the camera-head ordering events (cam.head row of the per-launch table, new / prev),
+# bench A/B (ab/libprev.so = this tree built with -DUD_AB_PREV: round-6 schedules and the ordering events off, D2S epilogue as before is NOT part of it)
+call7() {
+O=gpurun_out/r6c7 && mkdir -p $O
+timeout 900 python -m pytest tests/test_infer_gpu.py tests/test_rccl_gpu.py tests/test_kernels_gpu.py -q -m gpu -x -k "camera or cabi or dist_module or d2s or ping_pong or k_split" 2>&1 | grep -v "^$\|amdgpu.ids" | tail -12 > $O/tests.txt
+timeout 600 python tools/r6_dec_ab.py --match dh.convt --hints 0 --rounds 6 2>&1 | grep -v amdgpu.ids > $O/d2s_new.txt
+[ -f ab/libd2sprev.so ] && UNIDEPTH_HIP_LIB=$R/ab/libd2sprev.so timeout 600 python tools/r6_dec_ab.py --match dh.convt --hints 0 --rounds 6 2>&1 | grep -v amdgpu.ids > $O/d2s_prev.txt
+for r in 1 2; do
+  timeout 300 python bench.py --steps 24 --warmup 4 --no-cpu-baseline --no-extra-configs --dump-ops $O/ops_new$r.tsv 2>$O/err.txt | line "new" >> $O/bench_ab.txt
+  [ -f ab/libd2sprev.so ] && UNIDEPTH_HIP_LIB=$R/ab/libd2sprev.so timeout 300 python bench.py --steps 24 --warmup 4 --no-cpu-baseline --no-extra-configs --dump-ops $O/ops_d2sprev$r.tsv 2>$O/err.txt | line "d2sprev" >> $O/bench_ab.txt
+  [ -f ab/libprev.so ] && UNIDEPTH_HIP_LIB=$R/ab/libprev.so timeout 300 python bench.py --steps 24 --warmup 4 --no-cpu-baseline --no-extra-configs --dump-ops $O/ops_prev$r.tsv 2>$O/err.txt | line "prev" >> $O/bench_ab.txt
+done
+grep -h "cam.head\|convt" $O/ops_*.tsv | cut -f3,4 > $O/rows.txt
+cat $O/tests.txt $O/d2s_new.txt $O/d2s_prev.txt $O/bench_ab.txt; tail -3 $O/err.txt; paste - - - - < $O/rows.txt | head -8
+}
+
 "$@"

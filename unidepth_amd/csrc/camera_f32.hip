@@ -575,6 +575,11 @@ extern "C" int ud_camera_head_f32(const UdCameraHead* desc, void* stream) {
   // one spinning grid at a time per device: a launch waits (on its own stream) for the previous camera-head launch of this process, wherever
   // that was enqueued.  Two of these grids on different streams (pipelined requests) could otherwise each be PARTLY resident and starve each
   // other at their barriers.  Two host calls per launch, nothing on the GPU when the streams are the same.
+#ifdef UD_AB_PREV       // A/B builds only (tools/r6/sessions.sh): the launch without the ordering events
+  hipLaunchKernelGGL(camera_head_kernel, dim3(G), dim3(256), CH_LDS, (hipStream_t)stream, d);
+  UD_CHECK_LAUNCH("ud_camera_head_f32 launch");
+  return UD_OK;
+#endif
   static std::mutex mu;
   static hipEvent_t last[UD_MAX_DEVICES];
   static bool have[UD_MAX_DEVICES];

@@ -1402,27 +1402,44 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(biasp + o0 + j * 16 + 4 * fq);
         const bool lre = p.act2 == UD_ACT_LRELU;
+        // Round 6: a two-stage software pipeline over the wave's row tiles.  This epilogue IS the kernel for the transposed convolutions (K = 512: 8
+        // K-tiles per tile behind 0.5 MB of fp32 read-modify-write per tile), and the old values of row tile i + 1 -- 16 gathered 16-byte loads per
+        // lane with UdGemm.up_src -- used to be requested only after the stores of row tile i (the compiler cannot move a load above a store that
+        // may alias it): one memory round trip per row tile, 6-8 in a row per output tile.  Now the requests of i + 1 are in flight under the
+        // arithmetic and the stores of i.  Padding rows read pixel 0 of their image (valid memory) and store nothing: no branch around the loads.
+        auto pixel_of = [&](int i, int& img, int& Y, int& X, bool& ok) -> long long {
+          const int m = mbase + i * 16 + frow;
+          img = m / p.d2s_rows_in_img;
+          int pp = m - img * p.d2s_rows_in_img;
+          ok = pp < p.d2s_Hin * p.d2s_Win;                                 // rows past the image are padding tokens
+          pp = ok ? pp : 0;
+          const int y = pp / p.d2s_Win, x = pp - y * p.d2s_Win;
+          Y = y * k + sa; X = x * k + sc;
+          return (long long)img * p.d2s_out_img_pix + (long long)Y * Wout + X;
+        };
+        auto fetch_old = [&](int i, f32x4 (&v)[4]) {
+          int img, Y, X; bool ok;
+          const long long pix = pixel_of(i, img, Y, X, ok);
+          if (p.up_src) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ud_up2_fetch(p, img, Y, X, o0 + j * 16 + 4 * fq);
+          } else {
+            const float* src = (const float*)p.out + pix * p.ldc + o0 + 4 * fq;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = *(const f32x4*)(src + j * 16);
+          }
+        };
+        f32x4 nxt[4];
+        fetch_old(0, nxt);
 #pragma unroll
         for (int i = 0; i < TMC; ++i) {
-          const int m = mbase + i * 16 + frow;
-          const int img = m / p.d2s_rows_in_img;
-          const int pp = m - img * p.d2s_rows_in_img;
-          const int y = pp / p.d2s_Win, x = pp - y * p.d2s_Win;
-          const bool ok = pp < p.d2s_Hin * p.d2s_Win;                       // rows past the image are padding tokens
-          const long long pix = (long long)img * p.d2s_out_img_pix + (long long)(y * k + sa) * Wout + (x * k + sc);
+          int img, Y, X; bool ok;
+          const long long pix = pixel_of(i, img, Y, X, ok);
           float* dst = (float*)p.out + pix * p.ldc + o0 + 4 * fq;
           f32x4 v[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (ok) {
-            if (p.up_src) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = ud_up2_fetch(p, img, y * k + sa, x * k + sc, o0 + j * 16 + 4 * fq);
-            } else {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = *(const f32x4*)(dst + j * 16);
-            }
-          }
+          for (int j = 0; j < 4; ++j) v[j] = nxt[j];
+          if (i + 1 < TMC) fetch_old(i + 1, nxt);
           unsigned w[4][2];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {

@@ -111,8 +111,9 @@ __global__ __launch_bounds__(256) void rays_kernel(const float* Kinv33, float* r
       x *= n1; y *= n1; z *= n1;
       nmin = 1e-4f;
     }
-    const float inv = 1.0f / fmaxf(sqrtf(x * x + y * y + z * z), nmin);
-    float* r = rays + (size_t)b * 3 * HW + pix;
+    const float nrm = sqrtf(x * x + y * y + z * z);
+    const float inv = 1.0f / (nrm < nmin ? nmin : nrm);        // == fmaxf(nrm, nmin) for numbers; a NaN camera (the camera head's loud failure,
+    float* r = rays + (size_t)b * 3 * HW + pix;                // UdCameraHead.sync_ws) stays NaN in all three components instead of being clamped away
     r[0] = x * inv; r[HW] = y * inv; r[2 * (size_t)HW] = z * inv;
   }
 }

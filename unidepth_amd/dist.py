@@ -43,9 +43,53 @@ def all_gather_direct(out: torch.Tensor, mine: torch.Tensor, group=None) -> None
             req.wait()
 
 
+# ---- the exchange step behind the C-ABI (include/unidepth_hip.h ud_rccl_*): when the library's communicator exists, the gathers of this module
+# run through ud_rccl_allgather_outputs -- the same entry a non-Python host binds -- and torch.distributed is the bootstrap only (it carries the
+# 128-byte unique id from rank 0 to the others).  One communicator per process (csrc/rccl.cpp), spanning the default group.
+_cabi = {"world": 0, "rank": -1}
+
+
+def init_cabi_exchange(group=None) -> None:
+    """Create the library's RCCL communicator over the ranks of `group` (default: the world).  The calling thread's current HIP device is the
+    one the communicator binds to.  torch.distributed (any backend) only broadcasts the unique id."""
+    import ctypes as C
+    from ._lib import check, lib
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    uid = C.create_string_buffer(128)
+    if rank == 0:
+        check(lib.ud_rccl_unique_id(uid), "ud_rccl_unique_id")
+    box = [bytes(uid.raw) if rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    check(lib.ud_rccl_init(box[0], world, rank), "ud_rccl_init")
+    _cabi.update(world=world, rank=rank)
+
+
+def finalize_cabi_exchange() -> None:
+    from ._lib import check, lib
+    if _cabi["world"]:
+        check(lib.ud_rccl_finalize(), "ud_rccl_finalize")
+    _cabi.update(world=0, rank=-1)
+
+
+def cabi_exchange_ready(group=None) -> bool:
+    return _cabi["world"] > 0 and _cabi["world"] == dist.get_world_size(group) and _cabi["rank"] == dist.get_rank(group)
+
+
+def _on_device(t: torch.Tensor) -> bool:
+    return t.is_cuda
+
+
+def _cabi_allgather(buf: torch.Tensor, mine: torch.Tensor, direct: bool) -> None:
+    """buf [world * n, ...] <- every rank's contiguous `mine` [n, ...] through ud_rccl_allgather_outputs on the current HIP stream."""
+    from ._lib import check, lib
+    check(lib.ud_rccl_allgather_outputs(mine.data_ptr(), buf.data_ptr(), mine.numel() * mine.element_size(), int(direct),
+                                        torch.cuda.current_stream(mine.device).cuda_stream), "ud_rccl_allgather_outputs")
+
+
 def all_gather_batch(t: torch.Tensor, counts: List[int], group=None, algo: Optional[str] = None) -> torch.Tensor:
     """All-gather tensors whose dim 0 differs per rank (counts[r] rows on rank r): pad to max, one exchange (`algo`: see GATHER_ALGOS),
-    trim.  Works on any backend (RCCL on GPUs, gloo on CPU for the tests)."""
+    trim.  Device tensors go through the library's own communicator when it exists (init_cabi_exchange: the C-ABI exchange step),
+    otherwise through torch.distributed on whatever backend the group has (RCCL on GPUs, gloo on CPU for the tests)."""
     algo = algo or DEFAULT_GATHER_ALGO
     if algo not in GATHER_ALGOS:
         raise ValueError(f"gather algo {algo!r}: one of {GATHER_ALGOS}")
@@ -54,7 +98,11 @@ def all_gather_batch(t: torch.Tensor, counts: List[int], group=None, algo: Optio
     pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     pad[: t.shape[0]] = t
     buf = torch.empty((world * mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    if algo == "direct":
+    if mx == 0:
+        return buf
+    if _on_device(t) and cabi_exchange_ready(group):
+        _cabi_allgather(buf, pad, algo == "direct")
+    elif algo == "direct":
         all_gather_direct(buf, pad, group)
     else:
         dist.all_gather_into_tensor(buf, pad, group=group)
