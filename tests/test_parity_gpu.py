@@ -278,6 +278,16 @@ def test_batch_camera_one_model_per_image(engine_cls):
         assert torch.equal(out["rays"][i], one["rays"][0]), i
         arel = ((out["depth"][i] - one["depth"][0]).abs() / one["depth"][0]).mean().item()
         assert arel < 2e-3, (i, arel)                                   # bs = 4 and bs = 1 plans differ in GEMM tile shapes, not in the camera
+    # another ORDER of the same models: same plan (images are sorted by model inside infer(): no 2.6 GB plan per ordering), and,
+    # infer() being batch-permutation equivariant, the same bits per image
+    n_plans = len(model._plans)
+    perm = [2, 0, 3, 1]
+    outp = model.infer(rgb[perm], C.BatchCamera([cams[i] for i in perm]))
+    torch.cuda.synchronize()
+    assert len(model._plans) == n_plans
+    for k in out:
+        if out[k].shape[0] == 4:
+            assert torch.equal(outp[k], out[k][perm]), k
     pins = [C.Pinhole(params=torch.tensor([[300.0 + 5 * i, 301.0, 200.0, 150.0]])) for i in range(4)]
     a = model.infer(rgb, C.BatchCamera(pins))
     b = model.infer(rgb, torch.cat([p.K for p in pins]).cuda())

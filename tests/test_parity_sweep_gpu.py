@@ -79,6 +79,12 @@ def _report_and_assert(tag, rows, kbar):
     wins_k = sum(r[1] <= max(1e-3, r[5]) for r in rows)
     worst = max(r[0] / max(1e-3, r[4]) for r in rows)
     print(f"   paired: engine <= max(1e-3, reference as shipped) on {wins_e2e} of {n} cases end to end, {wins_k} of {n} on K; worst ratio {worst:.2f}")
+    # an absolute per-case cap beside the distributional comparison: a single case may exceed 1e-3 end to end only through the camera
+    # sensitivity of its checkpoint (depth at equal camera is held to 1e-3 per case above), and then by no more than 4x what the reference as
+    # shipped loses on the same case, never beyond 1e-2 (round 5's worst: 9.1e-3 against 2.6e-3 on seed 301; everything else <= 2.3e-3)
+    for r in rows:
+        assert r[0] <= min(1e-2, max(2e-3, 4.0 * r[4])), ("end-to-end cap", r[0], r[4])
+    assert sum(v > 1e-3 for v in e2e) <= 2, ("cases above 1e-3 end to end", [v for v in e2e if v > 1e-3])
     assert sum(v <= 1e-3 for v in e2e) >= sum(v <= 1e-3 for v in ref_e2e), "fewer cases within 1e-3 than the reference as shipped"
     assert float(np.median(e2e)) <= float(np.median(ref_e2e)) and float(np.median(kk)) <= float(np.median(ref_k)), "median worse than the reference as shipped"
     assert 4 * wins_e2e >= 3 * n and 4 * wins_k >= 3 * n, ("paired comparison against the reference as shipped", wins_e2e, wins_k, n)
@@ -203,7 +209,8 @@ def test_v1_depth_error_distribution(arch):
     if arch == "cnvnxtl":
         assert max(dep) <= 1e-3 and max(kk) <= 1e-3, (float(np.median(dep)), max(dep), max(kk))
     else:
-        assert float(np.median(dep)) <= 1.0e-3 and max(dep) <= 1.5e-3 and over <= 3 and max(kk) <= 1e-3, (float(np.median(dep)), max(dep), over, max(kk))
+        # strict on the count: one case above the bar is what this variant has had since round 5 (1.08e-3); a second one is a regression
+        assert float(np.median(dep)) <= 1.0e-3 and max(dep) <= 1.25e-3 and over <= 1 and max(kk) <= 1e-3, (float(np.median(dep)), max(dep), over, max(kk))
         if over:
             pytest.xfail(f"UniDepthV1 ViT-L/14: {over} of {len(dep)} cases above the 1e-3 bar (worst {max(dep):.2e}): the north-star bar is NOT met on every checkpoint "
                          "for this variant (fp16-operand encoder against the reference's fp32 path)")

@@ -16,7 +16,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = colle
 for f in sorted(glob.glob(__import__("os").environ.get("UD_PMC_DIR", "/root/repo/gpurun_out") + "/pmcg_[0-9]*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
-        if "gemm256" not in k: continue
+        if "gemm256" not in k and "gemm_pp" not in k: continue
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += 1
 for k in sorted(acc):
     a = {c: acc[k][c] / n[k][c] for c in acc[k]}

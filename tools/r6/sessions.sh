@@ -119,4 +119,47 @@ timeout 300 python bench.py --steps 24 --warmup 4 --no-cpu-baseline --no-extra-c
 cat $O/tests.txt $O/fork_ab.txt $O/bench.txt; tail -3 $O/err.txt
 }
 
+# round 6, final-tree evidence (one box): rocprofv3 kernel stats + FETCH / WRITE passes of the bench workload (profiles/r06_*), MFMA-busy counters of the
+# encoder GEMM launches, the full bench line with the per-launch table, the whole GPU suite (with the parity sweep printed), smoke()
+final() {
+O=gpurun_out/r6final && mkdir -p $O
+t0=$(date +%s)
+timeout 700 bash tools/profile_bench.sh r06 > $O/profile_bench.log 2>&1
+python tools/update_profiles.py r06 r06_bench_bs8_vitl >> $O/profile_bench.log 2>&1
+echo "[profiles done $(( $(date +%s) - t0 )) s]"
+timeout 300 bash tools/pmc_gemm.sh 2>&1 | grep -v amdgpu.ids > $O/gemm_pmc.txt
+echo "[pmc done $(( $(date +%s) - t0 )) s]"
+timeout 900 python bench.py --dump-ops $O/ops_per_launch.tsv > $O/bench.json 2> $O/bench.err
+echo "[bench done $(( $(date +%s) - t0 )) s]"
+mkdir -p $O/profiles && cp profiles/r06_bench_bs8_vitl_kernel_stats.csv profiles/r06_hbm_traffic.json profiles/r06_v1_cnvnxtl_640x480_bs16_kernel_stats.csv $O/profiles/ 2>/dev/null
+cp gpurun_out/prof_r06.v1.log $O/profiles/r06_v1_trace_breakdown.txt 2>/dev/null
+rm -rf gpurun_out/prof_r06/*/ gpurun_out/pmcg_* gpurun_out/pmca_*          # raw traces stay on the box
+timeout 1800 python -m pytest tests/ -q -s -m gpu 2>&1 | grep -v "^$\|amdgpu.ids" > $O/suite_full.txt
+tail -15 $O/suite_full.txt > $O/suite.txt
+echo "[suite done $(( $(date +%s) - t0 )) s]" >> $O/suite.txt
+timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('__SMOKE_OK__')" 2>&1 | grep -v amdgpu.ids | tail -4 > $O/smoke.txt
+tail -4 $O/profile_bench.log; head -12 $O/gemm_pmc.txt; cat $O/suite.txt $O/smoke.txt; tail -3 $O/bench.err
+python - <<'P'
+import json
+d = json.loads(open("gpurun_out/r6final/bench.json").read().strip().splitlines()[-1])
+print({k: d[k] for k in ("value", "ms_per_step", "p50_latency_ms", "value_one_call")})
+print(json.dumps(d["roofline"])[:1200])
+print(json.dumps(d.get("cpu_baseline"))[:400])
+for k, v in d.get("configs", {}).items():
+    print(k, v.get("value"), v.get("ms_per_step"), v.get("p50_latency_ms"), v.get("error"))
+P
+}
+
+# what the driver runs at the end of the round, in its order and with its flags, on a fresh box
+rehearsal() {
+O=gpurun_out/r6rehearsal && mkdir -p $O
+t0=$(date +%s)
+timeout 1500 python -m pytest tests/ -x -q -m gpu 2>&1 | grep -v "^$\|amdgpu.ids" | tail -8 > $O/suite.txt
+echo "[suite $(( $(date +%s) - t0 )) s]" >> $O/suite.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('__SMOKE_OK__')" 2>&1 | grep -v amdgpu.ids | tail -3 > $O/smoke.txt
+timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
+echo "[all $(( $(date +%s) - t0 )) s]" >> $O/suite.txt
+cat $O/suite.txt $O/smoke.txt; tail -2 $O/bench.err; cut -c1-400 $O/bench.json
+}
+
 "$@"

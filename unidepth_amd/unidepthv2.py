@@ -657,8 +657,20 @@ class UniDepthV2(EngineModule):
             assert cam_nb in (0, 1, B), f"camera batch {cam_nb} does not match the image batch {B} (one camera, or one per image)"
             gt_mode = 0 if camera is None else (GT_PINHOLE if Kc is not None else cam_obj.gt_mode)
             mixed = isinstance(cam_obj, BatchCamera)               # one camera per image, models differ (or are iterative): one ray launch per image
+            unsort = None
             if mixed:
                 assert cam_nb == B, f"BatchCamera of {cam_nb} cameras for a batch of {B} images (one per image)"
+                # canonical order: images sorted by camera model (stable), so a plan (2.6 GB at bs = 8, keyed on the tuple of per-image models)
+                # is shared by every ORDERING of the same models instead of being rebuilt per ordering; infer() is bit-exactly
+                # batch-permutation equivariant, the outputs are put back in the caller's order below
+                modes = cam_obj.gt_modes
+                order = sorted(range(B), key=lambda i: modes[i])
+                if order != list(range(B)):
+                    idx = torch.tensor(order, device=rgb.device)
+                    rgb = rgb.index_select(0, idx)
+                    cam_obj = BatchCamera([cam_obj.cameras[i] for i in order])
+                    unsort = torch.empty(B, dtype=torch.long)
+                    unsort[torch.tensor(order)] = torch.arange(B)
                 gt_mode = cam_obj.gt_modes
             self._check_camera_head()
             plan = self._plan(B, H, W, cam_nb, is_u8, bool(normalize), int(slot), gt_mode)
@@ -690,7 +702,11 @@ class UniDepthV2(EngineModule):
                 Kn[:, :2, :] *= plan.rf
                 plan.kinv_gt.copy_(torch.inverse(Kn).reshape(-1, 9))
             self._run(plan, 0, len(plan.prog), taps)
-            return self._collect(plan, B)
+            out = self._collect(plan, B)
+            if unsort is not None:
+                ui = unsort.to(self._device)
+                out = {k: (v.index_select(0, ui) if v.shape[0] == B else v) for k, v in out.items()}
+            return out
 
     def _check_camera_head(self):
         """The one-launch camera head (csrc/camera_f32.hip) needs its grid co-resident; a barrier that times out (CU mask, partitioned device,
