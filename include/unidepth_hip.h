@@ -481,12 +481,6 @@ int ud_program_add_patchify4(UdProgram*, const float* img, void* out, int B, int
 int ud_program_add_max(UdProgram*, float* dst, const float* src, long long n, int init);
 int ud_program_add_spatial_mean(UdProgram*, const float* x, float* out, int B, int HW, int C, int ldo);
 int ud_program_add_v1_op(UdProgram*, const UdV1Op*);
-/* side sections: the ops recorded between fork and side_end run on a second stream (owned by the library, one per caller stream) beside the
- * ops recorded between side_end and join; the list order must be a valid serial order (ud_program_run of a sub-range that cuts a section runs
- * it in list order on `stream` and re-joins before returning) */
-int ud_program_add_fork(UdProgram*);
-int ud_program_add_side_end(UdProgram*);
-int ud_program_add_join(UdProgram*);
 /* run ops [first, last) on `stream`; returns 0 or the first failing op's error code.  Stateless: a recorded program is never modified by a replay */
 int ud_program_run(const UdProgram*, int first, int last, void* stream);
 

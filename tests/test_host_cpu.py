@@ -512,29 +512,18 @@ def test_v2_plan_builder_dry_run_order_and_descriptors(monkeypatch):
     plan = m._plan(1, 462, 616, 0, True, True)
     assert len(seen) > 60 and not [r for r in seen if r[0] != -2], [r for r in seen if r[0] != -2][:3]     # -2 = UD_ERR_LAUNCH: arguments accepted
     tags = [t[1] for t in plan.prog.meta]
-    # round 6: the camera branch is a side section of the program (fork .. side_end), the feature branch runs beside it (side_end .. join);
-    # the list order is a valid serial order: camera branch, feature branch, cross-attention
-    i0 = tags.index("fork")
+    i0 = tags.index("dec.adapters(x4)")
     assert plan.dec_first == plan.enc_last == i0
-    cam = tags[i0 + 1:tags.index("side_end")]
+    cam = tags[i0 + 1:tags.index("ray_embed") + 1]
     # the token adapters and the CameraHead are ONE launch (UdCameraHead); its descriptor is inside the kernel's limits for every backbone
-    assert cam.count("cam.head") == 1 and cam[-3:] == ["rays", "ray_embed", "dh.kv(x4)"] and "camera_intrinsics" in cam and not any(t.startswith("dec.") for t in cam)
-    assert tags[tags.index("side_end") + 1:tags.index("join") + 2] == ["dec.adapters(x4)", "layernorm", "dh.q(x4)", "join", "dh.attn(x4)"]
-    # the single-stream form of the same plan: no section ops, the round-5 order
-    m._fork_camera_branch = False
-    m.clear_plans()
-    plan1 = m._plan(1, 462, 616, 0, True, True)
-    tags1 = [t[1] for t in plan1.prog.meta]
-    assert not {"fork", "side_end", "join"} & set(tags1) and len(plan1.prog) == len(plan.prog) - 3 and plan1.dec_first == tags1.index("dec.adapters(x4)")
-    assert tags1[tags1.index("ray_embed") + 1:tags1.index("ray_embed") + 4] == ["layernorm", "dh.q(x4)", "dh.kv(x4)"]
-    assert sorted(tags1) == sorted(t for t in tags if t not in ("fork", "side_end", "join"))
+    assert cam.count("cam.head") == 1 and cam[-2:] == ["rays", "ray_embed"] and "camera_intrinsics" in cam and not any(t.startswith("dh.") for t in cam)
+    assert tags[tags.index("ray_embed") + 1:tags.index("ray_embed") + 4] == ["layernorm", "dh.q(x4)", "dh.kv(x4)"]
     # outside the one-launch kernel's limits the same layers are recorded one by one (4 adapters, 14 Linears, 6 LayerNorms, 2 attentions: 26 launches)
     monkeypatch.setattr(ops, "camera_head_supported", lambda d: False)
-    m._fork_camera_branch = True
     m.clear_plans()
     plan2 = m._plan(1, 462, 616, 0, True, True)
     tags2 = [t[1] for t in plan2.prog.meta]
-    cam2 = tags2[tags2.index("fork") + 1:tags2.index("ray_embed") + 1]
+    cam2 = tags2[tags2.index("dec.adapters(x4)") + 1:tags2.index("ray_embed") + 1]
     assert "cam.head" not in cam2 and cam2.count("cam.adapter") == 4 and cam2.count("attention_small") == 2
     assert sum(t.startswith("cam.cam.") for t in cam2) == 14 and len(plan2.prog) == len(plan.prog) + 25
 

@@ -113,8 +113,9 @@ cat $O/tests.txt $O/d2s_new.txt $O/d2s_prev.txt $O/bench_ab.txt; tail -3 $O/err.
 call8() {
 O=gpurun_out/r6c8 && mkdir -p $O
 timeout 1200 python -m pytest tests/test_infer_gpu.py tests/test_parity_gpu.py -q -m gpu -x 2>&1 | grep -v "^$\|amdgpu.ids" | tail -8 > $O/tests.txt
-timeout 600 python tools/r6_fork_ab.py --batch 8 --rounds 5 2>&1 | grep -v amdgpu.ids > $O/fork_ab.txt
-timeout 600 python tools/r6_fork_ab.py --batch 1 --rounds 5 --calls 60 2>&1 | grep -v amdgpu.ids >> $O/fork_ab.txt
+# (tools/r6_fork_ab.py and the side-section ops exist in commits 5c0... "launch programs: side sections" .. the one after; removed when the A/B came back negative)
+[ -f tools/r6_fork_ab.py ] && timeout 600 python tools/r6_fork_ab.py --batch 8 --rounds 5 2>&1 | grep -v amdgpu.ids > $O/fork_ab.txt
+[ -f tools/r6_fork_ab.py ] && timeout 600 python tools/r6_fork_ab.py --batch 1 --rounds 5 --calls 60 2>&1 | grep -v amdgpu.ids >> $O/fork_ab.txt
 timeout 300 python bench.py --steps 24 --warmup 4 --no-cpu-baseline --no-extra-configs 2>$O/err.txt | line "bench" > $O/bench.txt
 cat $O/tests.txt $O/fork_ab.txt $O/bench.txt; tail -3 $O/err.txt
 }

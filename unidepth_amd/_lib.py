@@ -186,7 +186,6 @@ def _load():
         "ud_knn_points": [P(UdKnn), vp],
         "ud_knn_split": [P(UdKnn)],
         "ud_extract_patches": [P(UdExtractPatches), vp],
-        "ud_program_add_fork": [vp], "ud_program_add_side_end": [vp], "ud_program_add_join": [vp],
         "ud_program_run": [vp, i32, i32, vp],
         "ud_calib_mfma_stream": [vp, i32, i32, vp, C.POINTER(C.c_double), vp],
         "ud_version": [],

@@ -2,17 +2,11 @@
 // (model, batch, shape) as a flat list of kernel descriptors and replayed with ONE call from Python, so the
 // per-launch host cost is a C++ switch instead of a ctypes round trip.  A program is immutable once recorded and ud_program_run keeps no
 // state: any number of threads / streams may replay one program concurrently as long as they may share its buffers.
-// (Rounds 1 and 4 replayed programs through hipGraphs: bit-identical, measured neutral twice -- the programs are paced by dependent kernels on
-// the GPU, not by this launch loop -- and removed in round 5.)
-// Round 6: SIDE SECTIONS.  ops between ud_program_add_fork and ud_program_add_side_end are enqueued on a second HIP stream that starts where the
-// main stream stands at the fork; the main stream carries on with the ops behind side_end and waits for the side section at
-// ud_program_add_join.  The op list stays a valid SERIAL order (a side section never reads what the main ops beside it write, and vice versa):
-// a replay of a sub-range that starts inside a section, or ends before the join, simply runs those ops in list order on the caller's stream
-// and re-joins before it returns -- taps, module seams and per-op timing need no special case.  The side stream and its two events belong to
-// the CALLER'S stream (a small table under a mutex), so replays of one program on different streams (pipeline slots) never share them.
+// (Rounds 1 and 4 replayed programs through hipGraphs and round 4 forked the camera branch onto a second stream: both bit-identical, both
+// measured neutral twice -- the programs are paced by dependent kernels on the GPU, not by this launch loop -- and removed in round 5.
+// Round 6 measured side sections (fork / side_end / join ops on a library-owned second stream) once more with the one-launch camera head: slower at
+// bs 8 and bs 1 (profiles/r06_side_section_ab.txt); removed again.)
 #include <hip/hip_runtime.h>
-#include <map>
-#include <mutex>
 #include <vector>
 #include <new>
 #include "../../include/unidepth_hip.h"
@@ -20,7 +14,7 @@
 void ud_set_error(const char* msg);
 
 namespace {
-enum Kind { K_LIN32, K_ATTS, K_GEMM, K_LN, K_ATTN, K_PRE, K_FILL, K_CAM, K_RAYS, K_RAYS_CAM, K_EMBED, K_UP2, K_RESIZE, K_FINAL, K_T, K_DW7, K_LNP2, K_PATCH4, K_MAX, K_MEAN, K_V1, K_RSF, K_CAMHEAD, K_FORK, K_SIDE_END, K_JOIN };
+enum Kind { K_LIN32, K_ATTS, K_GEMM, K_LN, K_ATTN, K_PRE, K_FILL, K_CAM, K_RAYS, K_RAYS_CAM, K_EMBED, K_UP2, K_RESIZE, K_FINAL, K_T, K_DW7, K_LNP2, K_PATCH4, K_MAX, K_MEAN, K_V1, K_RSF, K_CAMHEAD };
 struct FillArgs { float* dst; const float* src; int n_img, rows_per_img, row_off, D, ld; };
 struct CamArgs { const float* raw; int raw_stride; float* intr4; float* K33; float* Kinv33; float* Kpost33; int B, Hn, Wn; float rf; int pad_l, pad_t; };
 struct RaysArgs { const float* Kinv33; float* rays; int nb, Hn, Wn, gt_mode; };
@@ -41,24 +35,6 @@ struct Op {
   };
   Op() {}
 };
-}  // namespace
-
-namespace {
-struct Side { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
-std::mutex g_side_mu;
-std::map<void*, Side> g_sides;          // caller's stream -> its side stream (created on first use, kept for the life of the process)
-bool side_of(void* main, Side& out) {
-  std::lock_guard<std::mutex> lk(g_side_mu);
-  auto it = g_sides.find(main);
-  if (it == g_sides.end()) {
-    Side sd;
-    if (hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) != hipSuccess) return false;
-    if (hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess) return false;
-    it = g_sides.emplace(main, sd).first;
-  }
-  out = it->second;
-  return true;
-}
 }  // namespace
 
 struct UdProgram {
@@ -138,39 +114,13 @@ int ud_program_add_row_stats_finalize(UdProgram* p, const float* partials, float
   RsfArgs a = {partials, stats, M, slabs, D, eps};
   ADD(K_RSF, rsf, a)
 }
-int ud_program_add_fork(UdProgram* p) { ADD(K_FORK, camhead, 0) }
-int ud_program_add_side_end(UdProgram* p) { ADD(K_SIDE_END, camhead, 0) }
-int ud_program_add_join(UdProgram* p) { ADD(K_JOIN, camhead, 0) }
-
 int ud_program_run(const UdProgram* p, int first, int last, void* stream) {
   if (!p || first < 0 || last > (int)p->ops.size() || first > last) { ud_set_error("ud_program_run: bad range"); return UD_ERR_BAD_ARG; }
-  void* cur = stream;
-  Side side;
-  bool on_side = false, pending = false;      // inside a side section / a finished section the main stream has not waited for yet
-  auto fail = [&](const char* what) { ud_set_error(what); return UD_ERR_LAUNCH; };
-  auto end_side = [&]() -> bool {             // side section complete: its end becomes an event, launches go to the main stream again
-    if (hipEventRecord(side.join, side.s) != hipSuccess) return false;
-    on_side = false; pending = true; cur = stream;
-    return true;
-  };
-  auto join = [&]() -> bool {
-    if (on_side && !end_side()) return false;
-    if (pending && hipStreamWaitEvent((hipStream_t)stream, side.join, 0) != hipSuccess) return false;
-    pending = false;
-    return true;
-  };
+  void* const cur = stream;
   for (int i = first; i < last; ++i) {
     const Op& op = p->ops[i];
     int rc = UD_OK;
     switch (op.kind) {
-      case K_FORK:
-        if (on_side || pending) { if (!join()) return fail("ud_program_run: join before a second fork failed"); }
-        if (!side_of(stream, side)) return fail("ud_program_run: cannot create the side stream");
-        if (hipEventRecord(side.fork, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(side.s, side.fork, 0) != hipSuccess) return fail("ud_program_run: fork failed");
-        on_side = true; cur = side.s;
-        break;
-      case K_SIDE_END: if (on_side && !end_side()) return fail("ud_program_run: side_end failed"); break;
-      case K_JOIN: if (!join()) return fail("ud_program_run: join failed"); break;
       case K_GEMM: rc = ud_gemm_f16(&op.gemm, cur); break;
       case K_LIN32: rc = ud_linear_f32(&op.lin32, cur); break;
       case K_ATTS: rc = ud_attention_small_f32(op.atts.q, op.atts.kv, op.atts.out, op.atts.B, op.atts.T, op.atts.H, op.atts.C, op.atts.scale, cur); break;
@@ -195,9 +145,8 @@ int ud_program_run(const UdProgram* p, int first, int last, void* stream) {
       case K_RSF: rc = ud_row_stats_finalize(op.rsf.part, op.rsf.stats, op.rsf.M, op.rsf.slabs, op.rsf.D, op.rsf.eps, cur); break;
       case K_T: rc = ud_nhwc_to_nchw_f32(op.t.in, op.t.out, op.t.B, op.t.hw, op.t.C, op.t.ld, op.t.rows_per_img, cur); break;
     }
-    if (rc != UD_OK) { join(); return rc; }
+    if (rc != UD_OK) return rc;
   }
-  if (!join()) return fail("ud_program_run: join at the end of the range failed");       // a range that ends inside / beside an open section
   return UD_OK;
 }
 }

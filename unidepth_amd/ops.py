@@ -103,7 +103,6 @@ class Program:
         self.keep = []          # keep tensors referenced by raw pointers alive
         self.meta = []          # per op: (kernel class, tag, algorithmic flops, algorithmic bytes) for bench / profiling
         self._splitk = None     # scratch of the two-way K split (UdGemm.splitk_ws / splitk_cnt), one per program = per stream
-        self._side = False      # recording inside a side section (fork .. side_end)
 
     def __del__(self):
         try:
@@ -136,7 +135,7 @@ class Program:
         if (g == 1 and kw.get("amode", 0) == UD_A_DENSE and kw.get("epi", 0) in (UD_EPI_F16, UD_EPI_F32) and tiles <= 128
                 and kw["K"] >= 1024 and kw["K"] % 128 == 0 and "splitk_ws" not in kw):
             # small problems (small batches): see UdGemm.splitk_ws in include/unidepth_hip.h; one workspace per program
-            key = (0, self._side)             # ops of a side section run beside the main ones: their own scratch
+            key = 0
             if not isinstance(self._splitk, dict):
                 self._splitk = {}
             if key not in self._splitk:
@@ -152,13 +151,12 @@ class Program:
             if not isinstance(self._splitk, dict):
                 self._splitk = {}
             need = 2 * tiles192 * 192 * 256 * 4
-            k1 = (1, self._side)
-            if k1 not in self._splitk or self._splitk[k1][0].numel() * 4 < need:
+            if 1 not in self._splitk or self._splitk[1][0].numel() * 4 < need:
                 dev = kw["A"].device
-                self._splitk[k1] = (torch.empty(need // 4, dtype=torch.float32, device=dev), torch.zeros(128, dtype=torch.int32, device=dev))
-                self.keep += list(self._splitk[k1])
-            kw["splitk_ws"], kw["splitk_cnt"] = self._splitk[k1]
-            kw["splitk_ws_bytes"] = self._splitk[k1][0].numel() * 4
+                self._splitk[1] = (torch.empty(need // 4, dtype=torch.float32, device=dev), torch.zeros(128, dtype=torch.int32, device=dev))
+                self.keep += list(self._splitk[1])
+            kw["splitk_ws"], kw["splitk_cnt"] = self._splitk[1]
+            kw["splitk_ws_bytes"] = self._splitk[1][0].numel() * 4
         d = mk(UdGemm, **kw)
         pick, epi, amode = lib.ud_gemm_pick(C.byref(d)), kw.get("epi", 0), kw.get("amode", 0)
         lnc, grp = "true" if pick & 16 else "false", "true" if pick & 32 else "false"
@@ -292,18 +290,6 @@ class Program:
         self.keep += [t for t in (a, b, c, out, out2) if isinstance(t, torch.Tensor)]
         self.meta.append(("v1." + tag, tag, 0.0, 0.0))
         return check(lib.ud_program_add_v1_op(self.h, C.byref(v1_desc(kind, a, b, c, out, out2, i, f))))
-
-    # ---- side sections (csrc/program.cpp): fork() ... side ops ... side_end() ... main ops ... join()
-    def fork(self):
-        self._side = True
-        self.meta.append(("misc", "fork", 0.0, 0.0)); return check(lib.ud_program_add_fork(self.h))
-
-    def side_end(self):
-        self._side = False
-        self.meta.append(("misc", "side_end", 0.0, 0.0)); return check(lib.ud_program_add_side_end(self.h))
-
-    def join(self):
-        self.meta.append(("misc", "join", 0.0, 0.0)); return check(lib.ud_program_add_join(self.h))
 
     def run(self, first=0, last=None, stream=None):
         """Replay ops [first, last) on the current (or given) stream."""

@@ -220,12 +220,14 @@ class _Plan:
         Md = B * hwp
         feat_all = z(4, Md, C, dtype=f32)
         ct = z(B * 4, C, dtype=f32)
-        # The camera branch (camera head -> intrinsics -> rays -> ray embedding -> K / V projection of the four prompt blocks) and the feature
-        # branch (grouped adapter GEMM -> LayerNorm -> q projection) are independent until the cross-attention.  Round 4 ran them on two streams
-        # when the camera branch was ~30 small launches: neutral (the feature-branch launches fill every CU's LDS; the small kernels waited for
-        # them).  Round 6: the camera head is ONE 128-workgroup launch of ~160 us that leaves half of the CUs free, so the camera branch is a
-        # SIDE SECTION of the launch program (csrc/program.cpp: fork / side_end / join) and the feature branch runs beside it; the op list stays a
-        # valid serial order (camera branch first), which taps, module seams and per-op timing replay on one stream.
+        # The camera branch (4 token adapters, the fp32 camera head, intrinsics, rays, ray embedding: ~30 dependent launches of a few workgroups
+        # each, 0.35-0.45 ms) and the feature branch (grouped adapter GEMM, LayerNorm, the q projection of the four cross-attention blocks) are
+        # independent until the K / V projection of the ray embedding.  Round 4 ran them on two streams (fork / join by events): same bits,
+        # one-call p50 14.22 ms on one stream against 14.25 ms forked (profiles/r04_side_branch_ab.txt) -- the feature-branch launches fill every
+        # CU's LDS, the camera kernels wait for them instead of running beside them.  One stream; the mechanism was removed in round 5.
+        # Round 6 re-measured it with the camera head as ONE 128-workgroup launch (side section of the launch program, fork / join by events):
+        # p50 14.06 vs 14.01 ms at bs 8, 4.84 vs 4.67 ms at bs 1 (profiles/r06_side_section_ab.txt) -- the spinning grid holds half of the CUs and
+        # the two cross-stream waits cost more than the overlap hides.  Dropped again.
         self.dec_first = self.enc_last
 
         def feature_branch_head():
@@ -234,11 +236,7 @@ class _Plan:
                    )
             for j in range(4):
                 tap(f"input_adapter.{j}", lambda j=j: feat_all[j].view(B, hwp, C)[:, :hw].clone())
-        forked = bool(model._fork_camera_branch)
-        if forked:
-            P.fork()
-        else:
-            feature_branch_head()
+        feature_branch_head()
         # ---- camera token adapters + camera head (decoder.py:34-45,48-114) on the 4 camera tokens per image: an fp32 island (UdLinearF32
         # explains why).  ONE launch (UdCameraHead: a persistent grid walks the ~18 dependent layers as phases between grid barriers) where
         # the kernel's limits allow it, otherwise the per-layer launches it replaces (same arithmetic, ~26 launches).
@@ -358,21 +356,12 @@ class _Plan:
         c16_all = z(4, Md, C)
         c16 = [c16_all[j] for j in range(4)]
         G4 = dict(groups=4)
-        def q_proj():
-            ln(feat_all, fn, 4 * Md)
-            P.gemm(A=fn, W=w["dhg.q.w"], bias=w["dhg.q.b"], out=qd, M=Md, N=HC, K=C, lda=C, ldw=C, ldc=HC, epi=UD_EPI_F16,
-                   gA=Md * C, gW=HC * C, gBias=HC, gOut=Md * HC, tag="dh.q(x4)", **G4)
-
-        if not forked:
-            q_proj()
+        ln(feat_all, fn, 4 * Md)
+        P.gemm(A=fn, W=w["dhg.q.w"], bias=w["dhg.q.b"], out=qd, M=Md, N=HC, K=C, lda=C, ldw=C, ldc=HC, epi=UD_EPI_F16,
+               gA=Md * C, gW=HC * C, gBias=HC, gOut=Md * HC, tag="dh.q(x4)", **G4)
         P.gemm(A=emb, W=w["dhg.kv.w"], bias=w["dhg.kv.b"], out=kd, out2=vtd, M=Mk, N=2 * HC, K=C, lda=C, ldw=C, ldc=HC, epi=UD_EPI_QKV,
                vsplit=HC, tok_per_img=hwp, kv_ld=hwkp, heads_v=Hd, gA=0, gW=2 * HC * C, gBias=2 * HC, gOut=Mk * HC,
                gOut2=nb * Hd * 64 * hwkp, tag="dh.kv(x4)", **G4)
-        if forked:
-            P.side_end()
-            feature_branch_head()
-            q_proj()
-            P.join()
         bc = int(nb == 1 and B > 1)
         P.attention(Q=qd, K=kd, Vt=vtd, O=aod, B=4 * B, H=Hd, Nq=hw, Nk=hw, ldq=HC, ldk=HC, ldo=HC, kv_ld=hwkp, q_rows_per_img=hwp,
                     k_rows_per_img=hwp, scale=scale_d, kv_broadcast=bc, kv_group=B, q_prescaled=1, tag="dh.attn(x4)")
@@ -491,7 +480,6 @@ class UniDepthV2(EngineModule):
         self._plans: "collections.OrderedDict" = collections.OrderedDict()
         self.max_plans = int(os.environ.get("UNIDEPTH_MAX_PLANS", "6"))   # LRU bound on cached (batch, shape, camera, slot) plans
         self._pos_cache: dict = {}
-        self._fork_camera_branch = True    # the camera branch as a side section of the launch program (second HIP stream) beside the feature branch
         self._cam_one_launch = True        # False after a reported grid-barrier time-out of the one-launch camera head (_check_camera_head)
         self._cam_spin_limit = 0           # 0 = the kernel's default (seconds); tests force the time-out with 1
         # True: a plan's launch program is replayed as ONE hipGraph launch (recorded on the second call of a signature).  For the launch-bound
