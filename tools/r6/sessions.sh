@@ -163,4 +163,30 @@ echo "[all $(( $(date +%s) - t0 )) s]" >> $O/suite.txt
 cat $O/suite.txt $O/smoke.txt; tail -2 $O/bench.err; cut -c1-400 $O/bench.json
 }
 
+# round 6, GPU call 9: decoder token rows padded to a tile-aligned group height (1392 rows per image at bs 8: the x4 launches as 192-row tile lists,
+# accumulating ones included) against the plain multiple of 8, one process; kernel tests of the grouped launches; infer / parity tests on the new plans
+# (negative: profiles/r06_decoder_rows_ab.txt; the aligned rows, the 192-row grouped form and tools/r6_rows_ab.py were removed again)
+call9() {
+O=gpurun_out/r6c9 && mkdir -p $O
+timeout 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu -x -k "grouped" 2>&1 | grep -v "^$\|amdgpu.ids" | tail -6 > $O/tests.txt
+[ -f tools/r6_rows_ab.py ] && timeout 900 python tools/r6_rows_ab.py --batch 8 --rounds 5 2>&1 | grep -v amdgpu.ids > $O/rows_ab.txt
+timeout 1500 python -m pytest tests/test_infer_gpu.py tests/test_parity_gpu.py -q -m gpu -x 2>&1 | grep -v "^$\|amdgpu.ids" | tail -6 >> $O/tests.txt
+timeout 300 python bench.py --steps 24 --warmup 4 --no-cpu-baseline --no-extra-configs 2>$O/err.txt | line "bench" > $O/bench.txt
+cat $O/tests.txt $O/rows_ab.txt $O/bench.txt; tail -3 $O/err.txt
+}
+
+# round 6, GPU calls 10 / 11: where the dispatcher puts 4-wave / 80 KB workgroups (tools/ubench/placement), then the
+# two-workgroups-per-CU instantiation of the ping-pong kernel against the product's schedules, hot and with the caches flushed between launches
+call10() {
+O=gpurun_out/r6c10 && mkdir -p $O
+for a in "464 81920" "512 81920" "464 65536" "464 81984"; do tools/ubench/placement $a 2>&1 | grep -v amdgpu.ids; done > $O/placement.txt
+cat $O/placement.txt
+}
+call11() {
+O=gpurun_out/r6c11 && mkdir -p $O
+timeout 300 python tools/r6_duo_ab.py 2>&1 | grep -v amdgpu.ids > $O/duo_ab.txt
+timeout 300 python tools/r6_duo_ab.py --cold 2>&1 | grep -v amdgpu.ids >> $O/duo_ab.txt
+cat $O/duo_ab.txt
+}
+
 "$@"

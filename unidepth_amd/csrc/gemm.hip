@@ -1660,8 +1660,8 @@ inline int pick_tiles(const UdGemm& d) {
     if (a_bytes >= 2147483648.0 || 2.0 * d.N * d.ldw >= 2147483648.0) return 0;
   }
   if (d.epi == UD_EPI_QKV && (d.vsplit & 255)) return 0;
-  if (d.tile_hint == 1 || (d.tile_hint >= 5 && d.tile_hint != 8 && d.tile_hint != 9 && d.tile_hint != 10 && d.tile_hint != 11)) return 0;
-  if (d.tile_hint == 11) return 3;                              // ping-pong form refused (gemm_pp.hip ud_gemm_pp_ok): the 192-row list
+  if (d.tile_hint == 1 || (d.tile_hint >= 5 && d.tile_hint != 8 && d.tile_hint != 9 && d.tile_hint != 10 && (d.tile_hint < 11 || d.tile_hint > 14))) return 0;
+  if (d.tile_hint >= 11 && d.tile_hint <= 14) return 3;         // ping-pong / duo forms refused (gemm_pp.hip): the 192-row list                              // ping-pong form refused (gemm_pp.hip ud_gemm_pp_ok): the 192-row list
   if (d.tile_hint == 2) return 4;
   if (d.tile_hint == 10) return big_split_ok(d) ? 10 : 0;       // 10: 192-row tile list with the two-way K split (when eligible)
   if (d.tile_hint == 3 || d.tile_hint == 9) return 3;      // 9: 192-row tile list with the 2-deep weight ring (A/B and tests of the 3-deep form)
@@ -2225,6 +2225,8 @@ inline bool grouped_as_big(const UdGemm& d, UdGemm& m) {
 // where eligible, 0 picks it when the cost model would take the 192-row list and the list fits one round)
 bool ud_gemm_pp_ok(const UdGemm& d);
 int ud_gemm_pp_launch(const UdGemm& d, hipStream_t s);
+bool ud_gemm_duo_ok(const UdGemm& d);
+int ud_gemm_duo_launch(const UdGemm& d, hipStream_t s, int prio_mode);
 namespace {
 inline bool pp_pick(const UdGemm& d) {
 #ifdef UD_AB_PREV      // A/B builds only (tools/r6/sessions.sh: ab/libprev.so = this tree with the round-6 schedules switched off, same ABI)
@@ -2371,6 +2373,7 @@ extern "C" int ud_gemm_f16(const UdGemm* desc, void* stream) {
       UdGemm mg;
       if (grouped_as_big(d, mg)) return launch256<4, UD_EPI_F32, UD_A_DENSE, false, true>(mg, s);
     }
+    if (d.tile_hint >= 12 && d.tile_hint <= 14 && ud_gemm_duo_ok(d)) return ud_gemm_duo_launch(d, s, d.tile_hint == 12 ? 1 : d.tile_hint == 13 ? 0 : 2);
     if (pp_pick(d)) return ud_gemm_pp_launch(d, s);
     if (const int bt = pick_tiles(d))
       return d.amode == UD_A_DENSE ? launch_big<UD_EPI_F32>(d, s, bt) : launch_big<UD_EPI_F32, UD_A_CONV3_ZERO>(d, s, bt);
@@ -2398,6 +2401,7 @@ extern "C" int ud_gemm_pick(const UdGemm* desc) {
     if ((d.epi == UD_EPI_F16 || d.epi == UD_EPI_F32 || d.epi == UD_EPI_QKV) && grouped_as_big(d, mg)) return 4 + 32;
   }
   if (conv_tile_ok(d) && (d.epi == UD_EPI_HEAD || d.epi == UD_EPI_F16)) return 5;
+  if (d.epi == UD_EPI_F32 && d.tile_hint >= 12 && d.tile_hint <= 14 && ud_gemm_duo_ok(d)) return 12;
   if (d.epi == UD_EPI_F32 && pp_pick(d)) return 11;
   if (d.epi != UD_EPI_HEAD) {
     int bt = pick_tiles(d);

@@ -18,6 +18,7 @@
 //     WAR: A(b^1) was last read in P3 of kt-1 (two barriers before P1's issue); W(b) is last read in P2 of kt, whose reads are retired
 //     (lgkmcnt(0)) BEFORE that phase's first barrier.  RAW: a wave waits for its own DMA (vmcnt) before a barrier every reader passes.
 #include "ud_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -63,20 +64,39 @@ __device__ __forceinline__ void pp_stats_store(const UdGemm& p, float s1, float 
     __builtin_amdgcn_sched_barrier(0);       \
   } while (0)
 
-template <int MQ>
-__global__ __launch_bounds__(512) void gemm_pp_f32_kernel(const UdGemm p) {
+// NW = 8: one workgroup of 8 waves (2 x 4) per CU on a 64 MQ x 256 tile.
+// NW = 4 ("duo"): 4 waves (2 x 2) on a 64 MQ x 128 tile, 80 KB of LDS and <= 256 registers per lane, so that TWO workgroups share a
+// CU -- one wave of each on every SIMD (tools/ubench/placement.hip, profiles/r06_placement.txt: workgroups j and j + 32 of an XCD's dispatch order land on
+// the same CU, both resident from the start; 81 920 B of LDS is exactly half a CU, one byte more and the second workgroup waits for the first).  The
+// per-wave code (96 x 64 sub-tile, fragment addresses, K order, epilogue) is the 8-wave kernel's: same bits.  The two workgroups of a CU are independent
+// instruction streams: the second-dispatched one runs at lower priority (prio_mode), so it falls behind the first and its K loop covers the first one's
+// store burst -- the only form in which one tile's bursts overlap another tile's K loop when a launch is a single round of tiles.
+template <int MQ, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_pp_f32_kernel(const UdGemm p, const int prio_mode) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = 64 * MQ;
+  constexpr int BN = NW * 32;                   // 4 (8 waves) or 2 (4 waves) wave columns of 64
+  constexpr int NWC = NW / 2;
   constexpr int TMC = 2 * MQ;
   constexpr int A_BYTES = BM * 128;
-  constexpr int BUFB = A_BYTES + 32768;
-  constexpr int A_LD = BM / 64;                 // DMA instructions per thread per K-tile of A (64 rows each)
+  constexpr int BUFB = A_BYTES + BN * 128;
+  constexpr int RPI = NW * 8;                   // tile rows one DMA instruction of the workgroup covers (16 bytes per lane, 8 lanes per row)
+  constexpr int A_LD = BM / RPI;                // DMA instructions per thread per K-tile of A
+  constexpr int W_LD = BN / RPI;                // ... of W (4 for both forms: the counted waits below say 4)
+  static_assert(W_LD == 4, "the counted vmcnt waits assume four W instructions per K-tile");
+  constexpr int A_H = NW == 8 ? 2 : 3;          // A instructions issued in phase 1 (the rest in phase 2)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wv >> 2, wc = wv & 3;
+  const int wr = wv / NWC, wc = wv % NWC;
   const int nk = p.K >> 6;                      // even, >= 4 (launch condition)
-  const int tiles_n = p.N >> 8, tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
   const int nblk = tiles_m * tiles_n;
+  if (NW == 4) {
+    // static priority per workgroup (s_setprio is a scalar instruction: branch on a uniform value)
+    const bool second = (int)(blockIdx.x >> 3) >= 32;
+    if (prio_mode == 1) { if (second) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2); }
+    else if (prio_mode == 2) { if (second) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
+  }
   const ud_rsrc_t rA = ud_make_rsrc(p.A, 0x80000000u), rW = ud_make_rsrc(p.W, 0x80000000u);
   const int lrow = tid >> 3;
   const int csrc = (tid & 7) ^ ((lrow >> 1) & 7);
@@ -93,33 +113,33 @@ __global__ __launch_bounds__(512) void gemm_pp_f32_kernel(const UdGemm p) {
       const int q = nblk >> 3, r = nblk & 7;
       const int xcd = t & 7, idx = t >> 3;
       const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-      const int GM = nblk <= 256 ? 1 : 8;
+      const int GM = nblk <= (NW == 8 ? 256 : 512) ? 1 : 8;
       const int gsz = GM * tiles_n;
       const int grp = bid / gsz;
       const int first_m = grp * GM;
       const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
       const int rem = bid - grp * gsz;
       m0 = (first_m + rem % gm) * BM;
-      n0 = (rem / gm) << 8;
+      n0 = (rem / gm) * BN;
     }
-    unsigned va[A_LD], vb[4];                    // rows past M re-read the last row (their outputs are never stored)
+    unsigned va[A_LD], vb[W_LD];                    // rows past M re-read the last row (their outputs are never stored)
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
-      int m = m0 + lrow + 64 * j;
+      int m = m0 + lrow + RPI * j;
       m = m < p.M ? m : p.M - 1;
       va[j] = ((unsigned)m * (unsigned)p.lda + csrc * 8) * 2u;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) vb[j] = ((unsigned)(n0 + lrow + 64 * j) * (unsigned)p.ldw + csrc * 8) * 2u;
+    for (int j = 0; j < W_LD; ++j) vb[j] = ((unsigned)(n0 + lrow + RPI * j) * (unsigned)p.ldw + csrc * 8) * 2u;
     auto issueA = [&](int kt, int buf, auto J0, auto J1) {
       char* sb = smem + buf * BUFB + wv * 1024;
 #pragma unroll
-      for (int j = decltype(J0)::value; j < decltype(J1)::value; ++j) ud_bufl16(rA, va[j], kt * 128, sb + j * 8192);
+      for (int j = decltype(J0)::value; j < decltype(J1)::value; ++j) ud_bufl16(rA, va[j], kt * 128, sb + j * (RPI * 128));
     };
     auto issueB = [&](int kt, int buf, auto J0, auto J1) {
       char* sb = smem + buf * BUFB + A_BYTES + wv * 1024;
 #pragma unroll
-      for (int j = decltype(J0)::value; j < decltype(J1)::value; ++j) ud_bufl16(rW, vb[j], kt * 128, sb + j * 8192);
+      for (int j = decltype(J0)::value; j < decltype(J1)::value; ++j) ud_bufl16(rW, vb[j], kt * 128, sb + j * (RPI * 128));
     };
 
     const int mbase = m0 + wr * (BM / 2), nbase = n0 + wc * 64;
@@ -189,7 +209,7 @@ __global__ __launch_bounds__(512) void gemm_pp_f32_kernel(const UdGemm p) {
         a[i][0] = *(const half8*)(sb + a_off + i * 2048 + c0);
         a[i][1] = *(const half8*)(sb + a_off + i * 2048 + c1);
       }
-      if (n1) issueA(kt + 1, buf ^ 1, IntTag<0>{}, IntTag<2>{});
+      if (n1) issueA(kt + 1, buf ^ 1, IntTag<0>{}, IntTag<A_H>{});
       PP_BAR();
       PP_MFMA_QUAD(0, 0, b0)
       PP_BAR();
@@ -199,7 +219,7 @@ __global__ __launch_bounds__(512) void gemm_pp_f32_kernel(const UdGemm p) {
         b1[j][0] = *(const half8*)(sb + b_off + (2 + j) * 2048 + c0);
         b1[j][1] = *(const half8*)(sb + b_off + (2 + j) * 2048 + c1);
       }
-      if (n1) issueA(kt + 1, buf ^ 1, IntTag<2>{}, IntTag<A_LD>{});
+      if (n1) issueA(kt + 1, buf ^ 1, IntTag<A_H>{}, IntTag<A_LD>{});
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b1[0][0]), "+v"(b1[0][1]), "+v"(b1[1][0]), "+v"(b1[1][1])::"memory");
       PP_BAR();
       PP_MFMA_QUAD(0, 1, b1)
@@ -293,7 +313,7 @@ __global__ __launch_bounds__(512) void gemm_pp_f32_kernel(const UdGemm p) {
     }
     if (p.row_stats_final) {
       // the LAST of the tiles_n workgroups of this row tile reduces the partial sums of all column tiles (ascending slab order), gemm.hip
-      unsigned* flag = (unsigned*)(smem + 2 * BUFB);
+      unsigned* flag = (unsigned*)(smem + (NW == 8 ? 2 * BUFB : 0));      // duo: no byte beyond the two buffers (all LDS reads are retired here)
       if (tid == 0) *flag = ticket_val;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -350,12 +370,35 @@ int ud_gemm_pp_launch(const UdGemm& d, hipStream_t s) {
   const int tiles = (d.N >> 8) * ((d.M + 64 * MQ - 1) / (64 * MQ));
   static bool attr_set[UD_MAX_DEVICES];
   if (!ud_attr_once(attr_set)) {
-    if (hipFuncSetAttribute((const void*)gemm_pp_f32_kernel<MQ>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)gemm_pp_f32_kernel<MQ, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
       ud_set_error("ud_gemm_f16: cannot reserve the LDS buffers of the ping-pong large-tile kernel");
       return UD_ERR_LAUNCH;
     }
   }
-  hipLaunchKernelGGL(gemm_pp_f32_kernel<MQ>, dim3(tiles < 256 ? tiles : 256), dim3(512), LDS, s, d);
+  hipLaunchKernelGGL((gemm_pp_f32_kernel<MQ, 8>), dim3(tiles < 256 ? tiles : 256), dim3(512), LDS, s, d, 0);
   UD_CHECK_LAUNCH("ud_gemm_f16 (large tile, ping-pong) launch");
+  return UD_OK;
+}
+
+// the two-workgroups-per-CU form: 192 x 128 tiles, one round of at most 512
+bool ud_gemm_duo_ok(const UdGemm& d) {
+  if (!ud_gemm_pp_ok(d) || (d.N & 127)) return false;
+  const int tiles = (d.N >> 7) * ((d.M + 191) / 192);
+  return tiles <= 512;
+}
+
+int ud_gemm_duo_launch(const UdGemm& d, hipStream_t s, int prio_mode) {
+  constexpr int MQ = 3;
+  constexpr int LDS = 2 * (64 * MQ * 128 + 16384);          // 81 920 B: exactly half of a CU's LDS
+  const int tiles = (d.N >> 7) * ((d.M + 64 * MQ - 1) / (64 * MQ));
+  static bool attr_set[UD_MAX_DEVICES];
+  if (!ud_attr_once(attr_set)) {
+    if (hipFuncSetAttribute((const void*)gemm_pp_f32_kernel<MQ, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+      ud_set_error("ud_gemm_f16: cannot reserve the LDS buffers of the two-workgroups-per-CU kernel");
+      return UD_ERR_LAUNCH;
+    }
+  }
+  hipLaunchKernelGGL((gemm_pp_f32_kernel<MQ, 4>), dim3(tiles), dim3(256), LDS, s, d, prio_mode);
+  UD_CHECK_LAUNCH("ud_gemm_f16 (two workgroups per CU) launch");
   return UD_OK;
 }
