@@ -26,18 +26,25 @@ def _device_asm():
         return open(out).read()
 
 
-def test_ping_pong_prologue_order_and_counted_wait():
-    asm = _device_asm()
-    m = re.search(r"^(_ZN\S*gemm_pp_f32_kernelILi3EE[^:\s]*):[^\n]*\n(.*?)\n\s*s_endpgm", asm, re.S | re.M)
-    assert m, "gemm_pp_f32_kernel<3> not found in the device assembly"
+_ASM = {}
+
+
+@pytest.mark.parametrize("nw,n_dma", [(8, 11), (4, 14)])
+def test_ping_pong_prologue_order_and_counted_wait(nw, n_dma):
+    """nw = 8: the product's 8-wave form (A(0): 3 DMA instructions per thread); nw = 4: the two-workgroups-per-CU instantiation (A(0): 6)."""
+    if "asm" not in _ASM:
+        _ASM["asm"] = _device_asm()
+    asm = _ASM["asm"]
+    m = re.search(r"^(_ZN\S*gemm_pp_f32_kernelILi3ELi%dEE[^:\s]*):[^\n]*\n(.*?)\n\s*s_endpgm" % nw, asm, re.S | re.M)
+    assert m, "gemm_pp_f32_kernel<3, %d> not found in the device assembly" % nw
     body = m.group(2).splitlines()
     ins = [l.strip() for l in body if l.strip() and not l.strip().startswith((";", ".", "//"))]
     first_wait = next(i for i, l in enumerate(ins) if l.startswith("s_waitcnt") and "vmcnt(28)" in l)
     vmem = [l.split()[0] + (" lds" if l.rstrip().endswith("lds") else "") for l in ins[:first_wait]
             if l.split()[0].startswith(("buffer_", "global_", "flat_", "scratch_"))]
-    # the accumulate path (full tile): 11 operand DMA instructions, then the 24 old-value loads, nothing else on the vector-memory queue
-    tail = vmem[-35:]
-    assert tail == ["buffer_load_dwordx4 lds"] * 11 + ["global_load_dwordx4"] * 24, tail
+    # the accumulate path (full tile): 11 (14) operand DMA instructions, then the 24 old-value loads, nothing else on the vector-memory queue
+    tail = vmem[-(n_dma + 24):]
+    assert tail == ["buffer_load_dwordx4 lds"] * n_dma + ["global_load_dwordx4"] * 24, tail
     assert not any(v.startswith(("global_store", "buffer_store", "scratch_")) for v in vmem), "stores / scratch traffic before the counted wait"
     # every other vector-memory load before that wait belongs to another path of the prologue (partial tile: guarded loads + vmcnt(0))
     assert all(v in ("buffer_load_dwordx4 lds", "global_load_dwordx4") for v in vmem), set(vmem)
