@@ -551,6 +551,45 @@ def test_gemm_conv3x3_big_tiles(ops, hint, Cin, Cout, H, W):
     assert rel(l16.view(B, rows_img, Cout)[:, :H * W].float(), F.leaky_relu(want, 0.01)) < 1e-3
 
 
+@pytest.mark.parametrize("Cin,Cout,H,W", [(64, 256, 150, 148), (128, 512, 96, 101)])
+def test_gemm_conv3x3_row_balanced(ops, Cin, Cout, H, W):
+    """Round 6: the row-balanced schedule of the large-tile kernel (tile_hint 8: one contiguous span of 64-row units per workgroup, cut into tiles of
+    128 / 192 / 256 rows) takes zero-padded 3x3 implicit-GEMM operands too (the decoder's stage-2 convolutions: 685 tiles of 256 rows = 2.67 rounds
+    -> 10-11 units per CU, 191 vs 205 us).  Same K order per output element: bit-identical to the 256-row tile list (tile_hint 2), fp16 + LeakyReLU and
+    fp32 residual-accumulate + fp16 copy epilogues (the copy-only form accumulate = 2 included), and right against torch."""
+    B = 2
+    rows_img = ((H * W + 7) // 8) * 8
+    x = rnd(B, rows_img, Cin, seed=1).half()
+    wt = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=2)
+    bias = rnd(Cout, seed=3)
+    Wg = wt.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().half()
+    zeros = torch.zeros(256, dtype=torch.half, device="cuda")
+    M = B * rows_img
+    lat0 = rnd(M, Cout, seed=5)
+    res = {}
+    for hint in (2, 8):
+        conv = dict(A=x, W=Wg, bias=bias, zeros=zeros, M=M, N=Cout, K=9 * Cin, ldw=9 * Cin, amode=ops.UD_A_CONV3_ZERO, Himg=H, Wimg=W,
+                    Cin=Cin, cstride=Cin, coff=0, rows_img=rows_img, img_stride=rows_img * Cin, tile_hint=hint)
+        assert ops.lib.ud_gemm_pick(ops.C.byref(ops.mk(ops.UdGemm, out=lat0, ldc=Cout, epi=ops.UD_EPI_F32, **conv))) == (4 if hint == 2 else 8)
+        out = torch.zeros(M, Cout, dtype=torch.half, device="cuda")
+        ops.gemm(out=out, ldc=Cout, epi=ops.UD_EPI_F16, act=ops.UD_ACT_LRELU, **conv)
+        lat = lat0.clone(); l16 = torch.zeros(M, Cout, dtype=torch.half, device="cuda")
+        ops.gemm(out=lat, out2=l16, ldc=Cout, ldc2=Cout, epi=ops.UD_EPI_F32, accumulate=1, act2=ops.UD_ACT_LRELU, **conv)
+        lat2 = lat0.clone(); l162 = torch.zeros(M, Cout, dtype=torch.half, device="cuda")
+        ops.gemm(out=lat2, out2=l162, ldc=Cout, ldc2=Cout, epi=ops.UD_EPI_F32, accumulate=2, **conv)
+        torch.cuda.synchronize()
+        res[hint] = (out, lat, l16, lat2, l162)
+    for a, b in zip(res[2], res[8]):
+        assert torch.equal(a, b)
+    xin = x[:, :H * W].float().view(B, H, W, Cin).permute(0, 3, 1, 2)
+    ref = F.conv2d(xin, Wg.float().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2), bias, padding=1).permute(0, 2, 3, 1).reshape(B, H * W, Cout)
+    out, lat, l16, lat2, l162 = res[8]
+    v = lambda t: t.view(B, rows_img, Cout)[:, :H * W]
+    assert rel(v(out).float(), F.leaky_relu(ref, 0.01)) < 1e-3
+    assert rel(v(lat), v(lat0) + ref) < 2e-4 and rel(v(l16).float(), F.leaky_relu(v(lat0) + ref, 0.01)) < 1e-3
+    assert torch.equal(lat2, lat0) and rel(v(l162).float(), v(lat0) + ref) < 1e-3
+
+
 _TICKETS = {}
 
 

@@ -951,6 +951,11 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const UdGemm p) {
       const int cx = tiles_n >> 1, rx = cpc >> 2;                  // columns / row spans per XCD
       col = (x & 1) * cx + j % cx;
       r = (x >> 1) * rx + j / cx;
+    } else if (tiles_n == 1 && (G & 7) == 0) {
+      // one column of tiles (the decoder's 256-channel 3x3 convolutions): every XCD takes a contiguous run of row spans, so the image rows two
+      // neighbouring spans share as 3x3 halo meet in one L2
+      col = 0;
+      r = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
     } else {
       const int lc = blockIdx.x;
       col = lc / cpc;
@@ -1631,19 +1636,19 @@ inline double bal_time(const UdGemm& d) {
   return 8.0 + (un * (30.0 / 4.0) + (k - 1) * 2.5) * ((double)d.K / 1024.0);
 }
 
-template <int EPI, bool LNC = false>
+template <int EPI, bool LNC = false, int AMODE = UD_A_DENSE>
 int launch256bal(const UdGemm& d, hipStream_t s) {
   const int tiles_n = (d.N + 255) >> 8;
   const int cpc = bal_cpc(d);
   const int lds = 2 * BigCfg<4>::STAGE + (LNC ? LNC_LDS : 0);
   static bool attr_set[UD_MAX_DEVICES];
   if (!ud_attr_once(attr_set)) {
-    if (hipFuncSetAttribute((const void*)gemm256_kernel<4, EPI, UD_A_DENSE, true, LNC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)gemm256_kernel<4, EPI, AMODE, true, LNC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       ud_set_error("ud_gemm_f16: cannot reserve the LDS ring of the large-tile kernel");
       return UD_ERR_LAUNCH;
     }
   }
-  hipLaunchKernelGGL((gemm256_kernel<4, EPI, UD_A_DENSE, true, LNC>), dim3(cpc * tiles_n), dim3(512), lds, s, d);
+  hipLaunchKernelGGL((gemm256_kernel<4, EPI, AMODE, true, LNC>), dim3(cpc * tiles_n), dim3(512), lds, s, d);
   UD_CHECK_LAUNCH("ud_gemm_f16 (large tile, row-balanced) launch");
   return UD_OK;
 }
@@ -1661,11 +1666,12 @@ inline int pick_tiles(const UdGemm& d) {
   }
   if (d.epi == UD_EPI_QKV && (d.vsplit & 255)) return 0;
   if (d.tile_hint == 1 || (d.tile_hint >= 5 && d.tile_hint != 8 && d.tile_hint != 9 && d.tile_hint != 10 && (d.tile_hint < 11 || d.tile_hint > 14))) return 0;
-  if (d.tile_hint >= 11 && d.tile_hint <= 14) return 3;         // ping-pong / duo forms refused (gemm_pp.hip): the 192-row list                              // ping-pong form refused (gemm_pp.hip ud_gemm_pp_ok): the 192-row list
+  if (d.tile_hint >= 11 && d.tile_hint <= 14) return 3;         // ping-pong / duo forms refused (gemm_pp.hip): the 192-row list
   if (d.tile_hint == 2) return 4;
   if (d.tile_hint == 10) return big_split_ok(d) ? 10 : 0;       // 10: 192-row tile list with the two-way K split (when eligible)
   if (d.tile_hint == 3 || d.tile_hint == 9) return 3;      // 9: 192-row tile list with the 2-deep weight ring (A/B and tests of the 3-deep form)
-  const bool bal_ok = d.amode == UD_A_DENSE && (d.epi == UD_EPI_F16 || d.epi == UD_EPI_F32 || d.epi == UD_EPI_QKV) && bal_cpc(d) > 0;
+  const bool bal_ok = (d.amode == UD_A_DENSE || (d.amode == UD_A_CONV3_ZERO && d.epi != UD_EPI_QKV)) &&
+                      (d.epi == UD_EPI_F16 || d.epi == UD_EPI_F32 || d.epi == UD_EPI_QKV) && bal_cpc(d) > 0;
   if (d.tile_hint == 8 && bal_ok) return 8;
   const double kk = (double)d.K / 1024.0;
   const double tn = (double)((d.N + 255) / 256);
@@ -1710,6 +1716,9 @@ int launch_big(const UdGemm& d, hipStream_t s, int which) {
   }
   if constexpr (AMODE == UD_A_DENSE && (EPI == UD_EPI_F16 || EPI == UD_EPI_F32 || EPI == UD_EPI_QKV)) {
     if (which == 8 && !d.row_stats_final) return launch256bal<EPI>(d, s);
+  }
+  if constexpr (AMODE == UD_A_CONV3_ZERO && (EPI == UD_EPI_F16 || EPI == UD_EPI_F32)) {
+    if (which == 8 && !d.row_stats_final) return launch256bal<EPI, false, UD_A_CONV3_ZERO>(d, s);
   }
   if constexpr (EPI == UD_EPI_F16 || EPI == UD_EPI_F32) {
     if (which == 10) return launch256sk<EPI, AMODE>(d, s);
