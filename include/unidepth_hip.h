@@ -170,6 +170,10 @@ typedef struct UdLayerNorm {
   const float* beta;      /* Needed where no linear consumer follows: the ConvNeXt stem's LayerNorm2d feeds a zero-padded depth-wise conv.  */
   const float* add;       /* optional fp32 [*, ldx] added to the input row BEFORE the statistics, indexed by the row's position inside its output
                            * image (out_row_off + p): `features + pos_embed` ahead of an MLP's norm (unidepthv1/decoder.py:80-83). */
+  float* cls_y;           /* optional (round 6, fp16 output only): the launch covers rows_per_img + 1 rows per image (`rows` counts them); the FIRST of an */
+  int ldcls;              /* image's rows -- input row in_row_off - 1, the class token in front of the patch tokens -- is normalised the same way and
+                           * written as fp32 to cls_y[image * ldcls ..] (it feeds the fp32 camera head), the others as usual.  One launch instead of
+                           * two per tapped layer of the encoder (dinov2.py:254 norm on x_norm_clstoken / x_norm_patchtokens). */
 } UdLayerNorm;
 int ud_layernorm_f32_f16(const UdLayerNorm* desc, void* stream);
 

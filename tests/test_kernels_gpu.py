@@ -933,6 +933,35 @@ def test_layernorm(ops, D, eps):
     assert y.view(B, rows_out, D)[:, n:].abs().max() == 0
 
 
+@pytest.mark.parametrize("D", [384, 1024])
+def test_layernorm_class_token_side_output(ops, D):
+    """Round 6: UdLayerNorm.cls_y -- one launch over rows_per_img + 1 rows per image: the row in front of an image's patch rows (the class token)
+    leaves as fp32 into its own buffer, the patch rows as fp16 as before (dinov2.py:254 on both halves of x); same bits as the two launches it
+    replaces; bad combinations are refused."""
+    B, rows_in, rows_out, n, eps = 3, 24, 24, 19, 1e-5
+    x = rnd(B * rows_in, D, seed=1) * 3 + 0.7
+    y = torch.zeros(B * rows_out, D, dtype=torch.half, device="cuda")
+    c = torch.zeros(8, D, device="cuda")
+    ops.layernorm(x=x, y=y, rows=B * (n + 1), D=D, ldx=D, ldy=D, eps=eps, rows_per_img=n, in_rows_per_img=rows_in, in_row_off=1,
+                  out_rows_per_img=rows_out, out_row_off=0, cls_y=c, ldcls=D)
+    y2 = torch.zeros_like(y); c2 = torch.zeros_like(c)
+    ops.layernorm(x=x, y=y2, rows=B * n, D=D, ldx=D, ldy=D, eps=eps, rows_per_img=n, in_rows_per_img=rows_in, in_row_off=1,
+                  out_rows_per_img=rows_out, out_row_off=0)
+    ops.layernorm(x=x, y=c2, rows=B, D=D, ldx=D, ldy=D, eps=eps, rows_per_img=1, in_rows_per_img=rows_in, in_row_off=0, out_rows_per_img=1,
+                  out_row_off=0, out_f32=1)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2) and torch.equal(c, c2)
+    ref = F.layer_norm(x.view(B, rows_in, D), (D,), eps=eps)
+    assert rel(y.view(B, rows_out, D)[:, :n].float(), ref[:, 1:1 + n]) < 6e-4 and rel(c[:B], ref[:, 0]) < 1e-5
+    assert y.view(B, rows_out, D)[:, n:].abs().max() == 0 and c[B:].abs().max() == 0
+    with pytest.raises(RuntimeError):
+        ops.layernorm(x=x, y=y, rows=B * (n + 1), D=D, ldx=D, ldy=D, eps=eps, rows_per_img=n, in_rows_per_img=rows_in, in_row_off=0,
+                      out_rows_per_img=rows_out, out_row_off=0, cls_y=c, ldcls=D)
+    with pytest.raises(RuntimeError):
+        ops.layernorm(x=x, y=y, rows=B * n, D=D, ldx=D, ldy=D, eps=eps, rows_per_img=n, in_rows_per_img=rows_in, in_row_off=1,
+                      out_rows_per_img=rows_out, out_row_off=0, cls_y=c, ldcls=D)
+
+
 @pytest.mark.parametrize("B,H,Nq,Nk,bc", [(2, 3, 1370, 1370, 0), (1, 2, 200, 77, 0), (3, 8, 4, 4, 0), (2, 2, 130, 1369, 1)])
 def test_attention(ops, B, H, Nq, Nk, bc):
     D = H * 64

@@ -41,7 +41,7 @@ class UdGemm(C.Structure):
 class UdLayerNorm(C.Structure):
     _fields_ = [("x", fp), ("y", vp), ("rows", i32), ("D", i32), ("ldx", i32), ("ldy", i32), ("eps", f32),
                 ("rows_per_img", i32), ("in_rows_per_img", i32), ("in_row_off", i32), ("out_rows_per_img", i32),
-                ("out_row_off", i32), ("out_f32", i32), ("gamma", fp), ("beta", fp), ("add", fp)]
+                ("out_row_off", i32), ("out_f32", i32), ("gamma", fp), ("beta", fp), ("add", fp), ("cls_y", fp), ("ldcls", i32)]
 
 
 class UdLinearF32(C.Structure):

@@ -10,10 +10,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const UdLayerNorm p) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= p.rows) return;
-  const int img = r / p.rows_per_img;
-  const int pp = r - img * p.rows_per_img;
+  // cls_y: rows_per_img + 1 rows per image, the first one = the row in front of the others (class token), normalised to fp32
+  const int rpi = p.rows_per_img + (p.cls_y ? 1 : 0);
+  const int img = r / rpi;
+  const int pp = r - img * rpi - (p.cls_y ? 1 : 0);
+  const bool is_cls = pp < 0;
   const size_t irow = (size_t)img * p.in_rows_per_img + pp + p.in_row_off;
-  const size_t orow = (size_t)img * p.out_rows_per_img + pp + p.out_row_off;
+  const size_t orow = (size_t)img * p.out_rows_per_img + (is_cls ? 0 : pp) + p.out_row_off;
   const float* x = p.x + irow * p.ldx;
   const float* addp = p.add ? p.add + (size_t)(pp + p.out_row_off) * p.ldx : nullptr;
   half_t* y = (half_t*)p.y + (F32OUT ? 0 : orow * p.ldy);
@@ -55,6 +58,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const UdLayerNorm p) {
       if (p.gamma) o = o * *(const f32x4*)(p.gamma + c) + (p.beta ? *(const f32x4*)(p.beta + c) : (f32x4){0.f, 0.f, 0.f, 0.f});
       if constexpr (F32OUT) {
         *(f32x4*)(yf + c) = o;
+      } else if (is_cls) {
+        *(f32x4*)(p.cls_y + (size_t)img * p.ldcls + c) = o;
       } else {
         half4 h;
 #pragma unroll
@@ -106,6 +111,10 @@ extern "C" int ud_layernorm_f32_f16(const UdLayerNorm* desc, void* stream) {
   const UdLayerNorm& d = *desc;
   if (!d.x || !d.y || d.rows <= 0 || d.D <= 0 || (d.D & 3) || d.D > 2048 || (d.ldx & 3) || (d.ldy & 3) || d.rows_per_img <= 0) {
     ud_set_error("ud_layernorm_f32_f16: bad argument (D % 4 == 0, D <= 2048)");
+    return UD_ERR_BAD_ARG;
+  }
+  if (d.cls_y && (d.out_f32 || d.add || d.in_row_off < 1 || (d.ldcls & 3) || d.ldcls < d.D || d.rows % (d.rows_per_img + 1))) {
+    ud_set_error("ud_layernorm_f32_f16: cls_y needs fp16 y, no add, in_row_off >= 1, ldcls % 4 == 0 and rows = images x (rows_per_img + 1)");
     return UD_ERR_BAD_ARG;
   }
   dim3 grid((d.rows + 3) / 4);

@@ -208,10 +208,9 @@ class _Plan:
                 tap(f"block{i}", lambda: x.view(B, Np, D)[:, :N].clone())      # residual stream after block i
             if (i + 1) in a["output_idx"]:
                 # final LayerNorm (eps 1e-5, dinov2.py:254) only on the 4 consumed outputs; patch rows and cls row separately
-                P.layernorm(x=x, y=featn[lvl], rows=B * hw, D=D, ldx=D, ldy=D, eps=1e-5, rows_per_img=hw, in_rows_per_img=Np,
-                            in_row_off=1, out_rows_per_img=hwp, out_row_off=0)
-                P.layernorm(x=x, y=clsn[lvl], rows=B, D=D, ldx=D, ldy=D, eps=1e-5, rows_per_img=1, in_rows_per_img=Np, in_row_off=0,
-                            out_rows_per_img=1, out_row_off=0, out_f32=1)
+                # (one launch: the class-token row in front of an image's patch rows goes out as fp32, UdLayerNorm.cls_y -- it was a launch of B rows)
+                P.layernorm(x=x, y=featn[lvl], rows=B * (hw + 1), D=D, ldx=D, ldy=D, eps=1e-5, rows_per_img=hw, in_rows_per_img=Np,
+                            in_row_off=1, out_rows_per_img=hwp, out_row_off=0, cls_y=clsn[lvl], ldcls=D)
                 lvl += 1
         self.enc_last = len(P)
         self.x, self.featn, self.clsn = x, featn, clsn
