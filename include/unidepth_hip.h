@@ -493,6 +493,8 @@ int ud_program_run(const UdProgram*, int first, int last, void* stream);
  * (2 MiB); `sink`: workgroups * 256 floats, never written for finite operands; *flop_out = FLOP of the launch.  What the matrix pipes of this box
  * sustain at their power-limited clock: boxes of one pool differ by several per cent, the datasheet peak (2.5 PFLOP/s) is a constant. */
 int ud_calib_mfma_stream(const void* operands, int iters, int workgroups, void* sink, double* flop_out, void* stream);
+/* the same for v_mfma_f32_16x16x32_f16 (the GEMM family's instruction): workgroups of 8 waves, sink >= workgroups * 512 floats (round 6) */
+int ud_calib_mfma_stream16(const void* operands, int iters, int workgroups, void* sink, double* flop_out, void* stream);
 
 /* library info; ud_struct_size(i): sizeof the i-th descriptor struct in declaration order (UdGemm = 0 ... UdLinearF32 = 8, UdDwConv7 = 9, UdV1Op = 10, UdKnn = 11, UdExtractPatches = 12, UdCameraHead = 13) */
 int ud_version(void);

@@ -55,7 +55,8 @@ template <int I> struct IntTag { static constexpr int value = I; };
   } while (0)
 
 // MQ: m-tiles (16 rows) per quadrant; STAGGER: m-row 1 one barrier behind m-row 0; PRIO: s_setprio 1 around the MFMA clusters
-template <int MQ, bool STAGGER, bool PRIO>
+// ABL (timing only, results wrong): 1 = no operand DMA after the prologue, 2 = no barriers in the K loop (with 1), 4 = no fragment reads after K-tile 0
+template <int MQ, bool STAGGER, bool PRIO, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm8p_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, half_t* __restrict__ C, int M, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = 64 * MQ;
@@ -91,12 +92,12 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const half_t* __restrict__ 
     unsigned va[A_LD], vb[4];                    // rows past M re-read the last row (their outputs are never stored)
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
-      int m = m0 + lrow + 64 * j;
+      int m = ((ABL & 8) ? 0 : m0) + lrow + 64 * j;      // ABL 8: every workgroup streams the operands of tile (0, 0): all DMA hits L2
       m = m < M ? m : M - 1;
       va[j] = ((unsigned)m * (unsigned)K + csrc * 8) * 2u;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) vb[j] = ((unsigned)(n0 + lrow + 64 * j) * (unsigned)K + csrc * 8) * 2u;
+    for (int j = 0; j < 4; ++j) vb[j] = ((unsigned)(((ABL & 8) ? 0 : n0) + lrow + 64 * j) * (unsigned)K + csrc * 8) * 2u;
     auto issueA = [&](int kt, int buf, int j0, int j1) {
       char* sb = smem + buf * BUFB + wv * 1024;
 #pragma unroll
@@ -140,11 +141,14 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const half_t* __restrict__ 
     if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);                                                                     \
   } while (0)
 
+#define KBAR() do { if constexpr (!(ABL & 2)) BAR(); } while (0)
     auto ktile = [&](auto BUFT, int kt) {
       constexpr int buf = decltype(BUFT)::value;
       const char* sb = smem + buf * BUFB;
-      const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
+      const bool n1 = !(ABL & 1) && kt + 1 < nk, n2 = !(ABL & 1) && kt + 2 < nk;
+      const bool rd = !(ABL & 4) || kt < 2;
       // ---- P1: quadrant (0, 0)
+      if (rd) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         b0[j][0] = *(const half8*)(sb + b_off + j * 2048 + c0);
@@ -155,31 +159,36 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const half_t* __restrict__ 
         a[i][0] = *(const half8*)(sb + a_off + i * 2048 + c0);
         a[i][1] = *(const half8*)(sb + a_off + i * 2048 + c1);
       }
+      }
       if (n1) issueA(kt + 1, buf ^ 1, 0, 2);
-      BAR();
+      KBAR();
       MFMA_QUAD(0, 0, b0);
-      BAR();
+      KBAR();
       // ---- P2: quadrant (0, 1); the W reads of this buffer end here: retired before the barrier (P3 re-stages the W region)
+      if (rd) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         b1[j][0] = *(const half8*)(sb + b_off + (2 + j) * 2048 + c0);
         b1[j][1] = *(const half8*)(sb + b_off + (2 + j) * 2048 + c1);
       }
+      }
       if (n1) issueA(kt + 1, buf ^ 1, 2, A_LD);
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b1[0][0]), "+v"(b1[0][1]), "+v"(b1[1][0]), "+v"(b1[1][1])::"memory");
-      BAR();
+      KBAR();
       MFMA_QUAD(0, 1, b1);
-      BAR();
+      KBAR();
       // ---- P3: quadrant (1, 1)
+      if (rd) {
 #pragma unroll
       for (int i = 0; i < MQ; ++i) {
         a[i][0] = *(const half8*)(sb + a_off + (MQ + i) * 2048 + c0);
         a[i][1] = *(const half8*)(sb + a_off + (MQ + i) * 2048 + c1);
       }
+      }
       if (n2) issueB(kt + 2, buf, 0, 2);
-      BAR();
+      KBAR();
       MFMA_QUAD(1, 1, b1);
-      BAR();
+      KBAR();
       // ---- P4: quadrant (1, 0); next K-tile's operands landed (own DMA) before the barrier every reader passes
       if (n2) {
         issueB(kt + 2, buf, 2, 4);
@@ -187,9 +196,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const half_t* __restrict__ 
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      BAR();
+      KBAR();
       MFMA_QUAD(1, 0, b0);
-      BAR();
+      KBAR();
     };
     for (int kt = 0; kt < nk; kt += 2) {
       ktile(IntTag<0>{}, kt);
@@ -240,9 +249,9 @@ struct Ctx {
   std::vector<int> mi, ni; int *dmi, *dni; float* dref;
 };
 
-template <int MQ, bool STAGGER, bool PRIO>
+template <int MQ, bool STAGGER, bool PRIO, int ABL = 0>
 double run(Ctx& c, int rounds) {
-  auto kern = gemm8p_kernel<MQ, STAGGER, PRIO>;
+  auto kern = gemm8p_kernel<MQ, STAGGER, PRIO, ABL>;
   constexpr int LDS = 2 * (64 * MQ * 128 + 32768);
   hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   const int BM = 64 * MQ;
@@ -267,9 +276,10 @@ double run(Ctx& c, int rounds) {
     best = fmin(best, ms * 100.0); sum += ms * 100.0;
   }
   const double us = sum / rounds;
+  if (ABL) printf("[ablation %d: %s%s%s%s] ", ABL, (ABL & 1) ? "no operand DMA " : "", (ABL & 2) ? "no barriers " : "", (ABL & 4) ? "no fragment reads " : "", (ABL & 8) ? "all workgroups stream tile (0,0): L2 hits" : "");
   printf("gemm8p MQ %d stagger %d prio %d: M %d N %d K %d, %d tiles on %d workgroups: mean %.1f us (%.0f TFLOP/s), best %.1f us (%.0f), max rel err %.2e %s\n", MQ,
          (int)STAGGER, (int)PRIO, c.M, c.N, c.K, tiles, grid, us, 2.0 * c.M * c.N * c.K / us / 1e6, best, 2.0 * c.M * c.N * c.K / best / 1e6, maxerr,
-         maxerr < 2e-3 ? "ok" : "WRONG");
+         ABL ? "(ablation: not a product)" : maxerr < 2e-3 ? "ok" : "WRONG");
   return us;
 }
 
@@ -332,6 +342,19 @@ int main(int argc, char** argv) {
   }
   float* dbias; hipMalloc(&dbias, N * 4); hipMemset(dbias, 0, N * 4);
   const int R = 3;
+  if (getenv("UD_ABLATE")) {                     // the ablation ladder of the 256-row ping-pong loop (what separates it from a pure MFMA stream)
+    for (int rep = 0; rep < 2; ++rep) {
+      run<4, true, true>(c, R);
+      run<4, true, true, 1>(c, R);
+      run<4, true, true, 3>(c, R);
+      run<4, true, true, 4>(c, R);
+      run<4, true, true, 5>(c, R);
+      run<4, true, true, 7>(c, R);
+      run<4, true, true, 8>(c, R);
+      run<4, true, true, 12>(c, R);
+    }
+    return 0;
+  }
   for (int rep = 0; rep < 3; ++rep) {            // interleaved rounds
     run<3, true, true>(c, R);
     if (prod) run_product(c, prod, 3, dbias, R);

@@ -188,6 +188,7 @@ def _load():
         "ud_extract_patches": [P(UdExtractPatches), vp],
         "ud_program_run": [vp, i32, i32, vp],
         "ud_calib_mfma_stream": [vp, i32, i32, vp, C.POINTER(C.c_double), vp],
+        "ud_calib_mfma_stream16": [vp, i32, i32, vp, C.POINTER(C.c_double), vp],
         "ud_version": [],
         "ud_struct_size": [i32],
     }

@@ -38,6 +38,37 @@ __global__ __launch_bounds__(256) void mfma_stream_kernel(const half8* __restric
     for (int r = 0; r < 16; ++r) s += acc[i][r];
   if (s == 123.456f) sink[blockIdx.x * 256 + threadIdx.x] = s;        // keeps the stream alive; never true for the random operands used
 }
+
+// The product GEMM family's own instruction: v_mfma_f32_16x16x32_f16, 4 A x 4 B fragments, 16 independent accumulators of 4 registers (a 64 x 64 register
+// tile per wave); 8 waves per workgroup, one workgroup per CU's worth of grid (two waves per SIMD).  On random operands this stream sustains MORE than the
+// 32 x 32 x 16 one above (1.90 against 1.2-1.7 PFLOP/s, profiles/r06_kloop_ablation.txt): bench.py runs both and reports the higher as attainable_this_box.
+__global__ __launch_bounds__(512) void mfma_stream16_kernel(const half8* __restrict__ operands, int iters, float* __restrict__ sink) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const half8* src = operands + ((size_t)(blockIdx.x & 31) * 8 + wv) * 8 * 64 + lane;
+  half8 a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = src[i * 64];
+    b[i] = src[(4 + i) * 64];
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+  if (s == 123.456f) sink[blockIdx.x * 512 + threadIdx.x] = s;
+}
 }  // namespace
 
 // operands: 64 * 4 * 8 * 64 * 16 bytes = 2 MiB of fp16 values (|x| <~ 1 keeps the fp32 accumulators finite for millions of iterations);
@@ -50,5 +81,17 @@ extern "C" int ud_calib_mfma_stream(const void* operands, int iters, int workgro
   hipLaunchKernelGGL(mfma_stream_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (const half8*)operands, iters, (float*)sink);
   UD_CHECK_LAUNCH("ud_calib_mfma_stream launch");
   if (flop_out) *flop_out = (double)workgroups * 4.0 * iters * 16.0 * 32768.0;
+  return UD_OK;
+}
+
+// the 16 x 16 x 32 stream: workgroups of 8 waves; sink: workgroups * 512 floats; same operand buffer
+extern "C" int ud_calib_mfma_stream16(const void* operands, int iters, int workgroups, void* sink, double* flop_out, void* stream) {
+  if (!operands || !sink || iters < 1 || workgroups < 1) {
+    ud_set_error("ud_calib_mfma_stream16: bad arguments");
+    return UD_ERR_BAD_ARG;
+  }
+  hipLaunchKernelGGL(mfma_stream16_kernel, dim3(workgroups), dim3(512), 0, (hipStream_t)stream, (const half8*)operands, iters, (float*)sink);
+  UD_CHECK_LAUNCH("ud_calib_mfma_stream16 launch");
+  if (flop_out) *flop_out = (double)workgroups * 8.0 * iters * 16.0 * 16384.0;
   return UD_OK;
 }
