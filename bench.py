@@ -475,7 +475,7 @@ def kernel_timing(torch, model, fl, B, dump="", attainable=None):
                               "and fc2 (K = 4096, 92 GFLOP) launches with the fp32 residual accumulate epilogue; where the LayerNorm fold is on "
                               "(DESIGN 9.2) the same launches also write the fp16 copy of their rows and the rows' LayerNorm statistics, i.e. "
                               "they carry the work of the 47 LayerNorm launches that are gone from the step -- the block-scope fraction below "
-                              "is the one to compare across rounds") if dom.startswith("gemm256_kernel<3, 1, 0") else None},
+                              "is the one to compare across rounds") if dom.startswith(("gemm256_kernel<3, 1, 0", "gemm_pp_f32_kernel")) else None},
         "roofline_enc_attention_mlp": {"achieved": round(enc_fl / (enc_ms * 1e-3) / 1e12, 2), "peak": MFMA_PEAK_TFLOPS,
                                        "unit": "TFLOP/s", "frac": round(enc_fl / (enc_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
                                        "frac_of_attainable": round(enc_fl / (enc_ms * 1e-3) / 1e12 / att, 4),

@@ -56,7 +56,7 @@ template <int I> struct IntTag { static constexpr int value = I; };
 
 // MQ: m-tiles (16 rows) per quadrant; STAGGER: m-row 1 one barrier behind m-row 0; PRIO: s_setprio 1 around the MFMA clusters
 // ABL (timing only, results wrong): 1 = no operand DMA after the prologue, 2 = no barriers in the K loop (with 1), 4 = no fragment reads after K-tile 0
-template <int MQ, bool STAGGER, bool PRIO, int ABL = 0>
+template <int MQ, bool STAGGER, bool PRIO, int ABL = 0, bool PH2 = false>
 __global__ __launch_bounds__(512) void gemm8p_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, half_t* __restrict__ C, int M, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = 64 * MQ;
@@ -200,9 +200,54 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const half_t* __restrict__ 
       MFMA_QUAD(1, 0, b0);
       KBAR();
     };
+    // PH2: TWO phases per K-tile (an m-half each: 8 MQ MFMAs between a pair of barriers instead of 4 MQ; 4 barriers per K-tile instead of 8)
+    auto ktile2 = [&](auto BUFT, int kt) {
+      constexpr int buf = decltype(BUFT)::value;
+      const char* sb = smem + buf * BUFB;
+      const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        b0[j][0] = *(const half8*)(sb + b_off + j * 2048 + c0);
+        b0[j][1] = *(const half8*)(sb + b_off + j * 2048 + c1);
+        b1[j][0] = *(const half8*)(sb + b_off + (2 + j) * 2048 + c0);
+        b1[j][1] = *(const half8*)(sb + b_off + (2 + j) * 2048 + c1);
+      }
+#pragma unroll
+      for (int i = 0; i < MQ; ++i) {
+        a[i][0] = *(const half8*)(sb + a_off + i * 2048 + c0);
+        a[i][1] = *(const half8*)(sb + a_off + i * 2048 + c1);
+      }
+      if (n1) issueA(kt + 1, buf ^ 1, 0, A_LD);
+      // the W reads of this buffer end here: retired before the barrier (phase 2 re-stages the W region)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b1[0][0]), "+v"(b1[0][1]), "+v"(b1[1][0]), "+v"(b1[1][1]), "+v"(b0[0][0]), "+v"(b0[0][1]), "+v"(b0[1][0]), "+v"(b0[1][1])::"memory");
+      BAR();
+      MFMA_QUAD(0, 0, b0);
+      MFMA_QUAD(0, 1, b1);
+      BAR();
+#pragma unroll
+      for (int i = 0; i < MQ; ++i) {
+        a[i][0] = *(const half8*)(sb + a_off + (MQ + i) * 2048 + c0);
+        a[i][1] = *(const half8*)(sb + a_off + (MQ + i) * 2048 + c1);
+      }
+      if (n2) {
+        issueB(kt + 2, buf, 0, 4);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      BAR();
+      MFMA_QUAD(1, 1, b1);
+      MFMA_QUAD(1, 0, b0);
+      BAR();
+    };
     for (int kt = 0; kt < nk; kt += 2) {
-      ktile(IntTag<0>{}, kt);
-      ktile(IntTag<1>{}, kt + 1);
+      if constexpr (PH2) {
+        ktile2(IntTag<0>{}, kt);
+        ktile2(IntTag<1>{}, kt + 1);
+      } else {
+        ktile(IntTag<0>{}, kt);
+        ktile(IntTag<1>{}, kt + 1);
+      }
     }
 #undef MFMA_QUAD
     if constexpr (STAGGER) {
@@ -249,9 +294,9 @@ struct Ctx {
   std::vector<int> mi, ni; int *dmi, *dni; float* dref;
 };
 
-template <int MQ, bool STAGGER, bool PRIO, int ABL = 0>
+template <int MQ, bool STAGGER, bool PRIO, int ABL = 0, bool PH2 = false>
 double run(Ctx& c, int rounds) {
-  auto kern = gemm8p_kernel<MQ, STAGGER, PRIO, ABL>;
+  auto kern = gemm8p_kernel<MQ, STAGGER, PRIO, ABL, PH2>;
   constexpr int LDS = 2 * (64 * MQ * 128 + 32768);
   hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   const int BM = 64 * MQ;
@@ -277,6 +322,7 @@ double run(Ctx& c, int rounds) {
   }
   const double us = sum / rounds;
   if (ABL) printf("[ablation %d: %s%s%s%s] ", ABL, (ABL & 1) ? "no operand DMA " : "", (ABL & 2) ? "no barriers " : "", (ABL & 4) ? "no fragment reads " : "", (ABL & 8) ? "all workgroups stream tile (0,0): L2 hits" : "");
+  if (PH2) printf("[two phases per K-tile] ");
   printf("gemm8p MQ %d stagger %d prio %d: M %d N %d K %d, %d tiles on %d workgroups: mean %.1f us (%.0f TFLOP/s), best %.1f us (%.0f), max rel err %.2e %s\n", MQ,
          (int)STAGGER, (int)PRIO, c.M, c.N, c.K, tiles, grid, us, 2.0 * c.M * c.N * c.K / us / 1e6, best, 2.0 * c.M * c.N * c.K / best / 1e6, maxerr,
          ABL ? "(ablation: not a product)" : maxerr < 2e-3 ? "ok" : "WRONG");
@@ -342,6 +388,16 @@ int main(int argc, char** argv) {
   }
   float* dbias; hipMalloc(&dbias, N * 4); hipMemset(dbias, 0, N * 4);
   const int R = 3;
+  if (getenv("UD_PH2")) {                        // two phases per K-tile against four, interleaved
+    for (int rep = 0; rep < 3; ++rep) {
+      run<4, true, true>(c, R);
+      run<4, true, true, 0, true>(c, R);
+      run<3, true, true>(c, R);
+      run<3, true, true, 0, true>(c, R);
+      run<4, true, false, 0, true>(c, R);
+    }
+    return 0;
+  }
   if (getenv("UD_ABLATE")) {                     // the ablation ladder of the 256-row ping-pong loop (what separates it from a pure MFMA stream)
     for (int rep = 0; rep < 2; ++rep) {
       run<4, true, true>(c, R);

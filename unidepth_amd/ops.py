@@ -172,7 +172,7 @@ class Program:
         elif pick == 8:     # row-balanced schedule of the 256-column kernel
             cls = "gemm256_kernel<4, %d, %d, true, %s, false, false, false>" % (epi, amode, lnc)
         elif pick == 11:    # 192-row tiles, ping-pong schedule (csrc/gemm_pp.hip)
-            cls = "gemm_pp_f32_kernel<3>"
+            cls = "gemm_pp_f32_kernel<3, 8>"
         elif pick == 10:    # 192-row tile list, two-way K split (2 * tiles workgroups)
             cls = "gemm256_kernel<3, %d, %d, false, false, false, false, true>" % (epi, amode)
         elif amode == 3 and kw.get("Cin", 0) == 64 and epi == UD_EPI_HEAD:
