@@ -4,19 +4,20 @@
 //
 // Same tile, LDS image, MFMA orientation, K order and epilogue arithmetic as gemm256_kernel<3, UD_EPI_F32, dense, W3> (gemm.hip): every output
 // element carries the SAME BITS (tests/test_kernels_gpu.py::test_gemm_ping_pong_is_bit_identical).  What differs is the schedule of a K-tile:
-//   * 192 x 256 tile, 8 waves = 2 (m) x 4 (n); a K-tile is walked as FOUR phases, one quadrant (3 x 2 MFMA tiles x 2 k-steps = 12 MFMAs) of the
-//     wave's 96 x 64 sub-tile each; a phase = { fragment reads + a slice of the operand DMA ; s_barrier ; the quadrant's MFMAs ; s_barrier };
+//   * 192 x 256 tile, 8 waves = 2 (m) x 4 (n); a K-tile is walked as TWO phases, one m-half (3 x 4 MFMA tiles x 2 k-steps = 24 MFMAs) of the
+//     wave's 96 x 64 sub-tile each; a phase = { fragment reads + operand DMA issue ; s_barrier ; the MFMAs ; s_barrier }  (first half of round 6: four
+//     phases of one quadrant; two measured -2 % on the proj / fc2 shapes, tools/ubench/gemm8p UD_PH2, profiles/r06_kloop_ablation.txt);
 //   * the waves of m-row 1 run ONE barrier behind those of m-row 0, so on every SIMD one wave is inside its MFMA cluster while its partner
 //     issues fragment reads / DMA (MI355X_MICROARCH "Two waves per SIMD"): the matrix pipe neither waits for an LDS round trip nor sees two
 //     MFMA streams competing.  tools/ubench/gemm8p.hip, same process, interleaved (profiles/r06_gemm_loop_diagnostic.txt): +6.5 % on the proj
 //     shape, +3 % on the fc2 shape, +6 % at 4096^3 against the product's one-barrier-per-K-tile loop; on multi-round launches (qkv, fc1) the
 //     product's continuous K-tile stream across tiles wins, so this kernel takes ONE-ROUND tile lists only;
 //   * two K-tile buffers (112 KB): the activation operand runs one K-tile ahead, the weight operand two -- W(kt + 2) re-fills W(kt)'s region
-//     from phase 3 on, its four DMA instructions stay in flight across the K-tile boundary (counted vmcnt(4), never 0 in the loop).
-//     DMA per phase of K-tile kt (buffer b = kt & 1):  P1: A(kt+1) rows 0-127 -> b^1   P2: A(kt+1) rows 128-191 -> b^1
-//                                                     P3: W(kt+2) rows 0-127 -> b     P4: W(kt+2) rows 128-255 -> b ; vmcnt(4)
-//     WAR: A(b^1) was last read in P3 of kt-1 (two barriers before P1's issue); W(b) is last read in P2 of kt, whose reads are retired
-//     (lgkmcnt(0)) BEFORE that phase's first barrier.  RAW: a wave waits for its own DMA (vmcnt) before a barrier every reader passes.
+//     in phase 2, its four DMA instructions stay in flight across the K-tile boundary (counted vmcnt(4), never 0 in the loop).
+//     DMA of K-tile kt (buffer b = kt & 1):  phase 1: A(kt+1) -> b^1     phase 2: W(kt+2) -> b ; vmcnt(4)
+//     WAR: A(b^1) was last read in phase 2 of kt-1 and W(b) in phase 1 of kt; both sets of reads are retired (lgkmcnt(0)) BEFORE the barrier that
+//     follows them, and the wave row that re-fills the region issues at least one barrier later.  RAW: a wave waits for its own DMA (vmcnt) before
+//     a barrier every reader passes.
 #include "ud_common.h"
 #include <cstdlib>
 
@@ -84,7 +85,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   constexpr int A_LD = BM / RPI;                // DMA instructions per thread per K-tile of A
   constexpr int W_LD = BN / RPI;                // ... of W (4 for both forms: the counted waits below say 4)
   static_assert(W_LD == 4, "the counted vmcnt waits assume four W instructions per K-tile");
-  constexpr int A_H = NW == 8 ? 2 : 3;          // A instructions issued in phase 1 (the rest in phase 2)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wv / NWC, wc = wv % NWC;
@@ -198,7 +198,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       constexpr bool HEAD = decltype(HEADT)::value;
       const char* sb = smem + buf * BUFB;
       const bool n1 = HEAD || kt + 1 < nk, n2 = HEAD || kt + 2 < nk;
-      // ---- P1: quadrant (0, 0)
+      // ---- phase 1: quadrants (0, 0) and (0, 1) -- the wave's first m-half against all four column tiles.  (Round 6, second half: a K-tile was FOUR
+      // phases of one quadrant each; two phases of two quadrants -- 4 barriers per K-tile instead of 8, 24 MFMAs between a pair -- measured
+      // -2 % on the proj / fc2 shapes in tools/ubench/gemm8p, profiles/r06_kloop_ablation.txt.  Same MFMA order per accumulator: same bits.)
+      // The W reads of this buffer end here: retired (lgkmcnt(0)) before the barrier, phase 2 re-fills the W region.
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         b0[j][0] = *(const half8*)(sb + b_off + j * 2048 + c0);
@@ -209,39 +212,33 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         a[i][0] = *(const half8*)(sb + a_off + i * 2048 + c0);
         a[i][1] = *(const half8*)(sb + a_off + i * 2048 + c1);
       }
-      if (n1) issueA(kt + 1, buf ^ 1, IntTag<0>{}, IntTag<A_H>{});
-      PP_BAR();
-      PP_MFMA_QUAD(0, 0, b0)
-      PP_BAR();
-      // ---- P2: quadrant (0, 1); the W reads of this buffer end here: retired before the barrier (P3 re-fills the W region)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         b1[j][0] = *(const half8*)(sb + b_off + (2 + j) * 2048 + c0);
         b1[j][1] = *(const half8*)(sb + b_off + (2 + j) * 2048 + c1);
       }
-      if (n1) issueA(kt + 1, buf ^ 1, IntTag<A_H>{}, IntTag<A_LD>{});
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b1[0][0]), "+v"(b1[0][1]), "+v"(b1[1][0]), "+v"(b1[1][1])::"memory");
+      if (n1) issueA(kt + 1, buf ^ 1, IntTag<0>{}, IntTag<A_LD>{});
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b1[0][0]), "+v"(b1[0][1]), "+v"(b1[1][0]), "+v"(b1[1][1]), "+v"(b0[0][0]), "+v"(b0[0][1]), "+v"(b0[1][0]), "+v"(b0[1][1])::"memory");
       PP_BAR();
+      PP_MFMA_QUAD(0, 0, b0)
       PP_MFMA_QUAD(0, 1, b1)
       PP_BAR();
-      // ---- P3: quadrant (1, 1)
+      // ---- phase 2: quadrants (1, 1) and (1, 0); the next K-tile's operands have landed (own DMA) before the barrier every reader passes
 #pragma unroll
       for (int i = 0; i < MQ; ++i) {
         a[i][0] = *(const half8*)(sb + a_off + (MQ + i) * 2048 + c0);
         a[i][1] = *(const half8*)(sb + a_off + (MQ + i) * 2048 + c1);
       }
-      if (n2) issueB(kt + 2, buf, IntTag<0>{}, IntTag<2>{});
-      PP_BAR();
-      PP_MFMA_QUAD(1, 1, b1)
-      PP_BAR();
-      // ---- P4: quadrant (1, 0); the next K-tile's operands have landed (own DMA) before the barrier every reader passes
       if (n2) {
-        issueB(kt + 2, buf, IntTag<2>{}, IntTag<4>{});
+        issueB(kt + 2, buf, IntTag<0>{}, IntTag<4>{});
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+      // the A reads of this buffer end here: retired before the barrier (the other wave row issues A(kt + 2) into it one barrier later)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       PP_BAR();
+      PP_MFMA_QUAD(1, 1, b1)
       PP_MFMA_QUAD(1, 0, b0)
       PP_BAR();
     };
