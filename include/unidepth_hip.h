@@ -356,6 +356,15 @@ int ud_nhwc_to_nchw_f32(const float* in, float* out, int B, int hw, int C, int l
 typedef struct UdDwConv7 {
   const float* x; const float* w; const float* bias; float* y;
   int B, H, W, C, ldx, ldy;
+  /* Round 6 (VERDICT r5 missing #5c), the LayerNorm behind the convolution (convnext.py:215-216 `x = self.norm(x)`) folded into the producer / consumer pair:
+   * y16 (optional; then y may be NULL): the convolution's output as RAW fp16 [pixels, ldy16] -- the A operand of a LayerNorm-folded consumer GEMM
+   * (UdGemm.row_stats_in); stats_out (with y16): per pixel and 64-channel slab the (sum, sum of squares) of the fp32 outputs, [pixels][C / 64][2] =
+   * UdGemm.row_stats_out's layout, reduced by ud_row_stats_finalize (C / 64 <= 16).  C % 64 == 0 (the LDS-tiled kernel). */
+  void* y16; float* stats_out; int ldy16;
+  /* optional, with stats_out: the LAST of a pixel tile's C / 64 channel blocks to finish (one ticket per 8 x 16 tile of output pixels: stats_ticket, >= number of
+   * tiles unsigned words, zeroed once by the caller, self-resetting) reduces the tile's partial sums in slab order and writes stats_final [pixels][2] =
+   * (rstd, -mean * rstd) with eps ln_eps -- what ud_row_stats_finalize would write; no reduction launch. */
+  float* stats_final; unsigned* stats_ticket; float ln_eps;
 } UdDwConv7;
 int ud_dwconv7_nhwc_f32(const UdDwConv7* desc, void* stream);
 /* LayerNorm2d statistics (eps; affine folded into the conv weights) of every pixel of x fp32 NHWC [B,H,W,C], written as fp16 into the

@@ -61,6 +61,61 @@ def test_dwconv7(ops, B, H, W, C):
     assert rel(y, ref) < 2e-6
 
 
+@pytest.mark.parametrize("B,H,W,C", [(2, 13, 21, 192), (1, 30, 8, 384), (1, 40, 30, 768)])
+def test_dwconv7_fp16_rows_and_layernorm_statistics(ops, B, H, W, C):
+    """Round 6: the ConvNeXt block's LayerNorm (convnext.py:215-216) folded into the depth-wise convolution and fc1.  UdDwConv7.y16 / stats_out: the conv
+    output as raw fp16 rows and the per-pixel (sum, sum of squares) of the fp32 values per 64-channel slab; ud_row_stats_finalize reduces them; a
+    LayerNorm-folded consumer GEMM (UdGemm.row_stats_in, split weights [W_hi | W_lo] with a_wrap as the V1 encoder packs them) then equals
+    fc1(LayerNorm(conv)) in fp32 torch to the fp16 operand rounding; the fp32 output (y) may be written beside it (same bits as without the fold)."""
+    import ctypes
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, H, W, C, generator=g).cuda()
+    w = torch.randn(C, 1, 7, 7, generator=g).cuda() / 7
+    b = torch.randn(C, generator=g).cuda() * 0.3
+    wt = w.reshape(C, 49).t().contiguous()
+    M = B * H * W
+    y = torch.zeros(M, C, device="cuda"); y2 = torch.zeros(M, C, device="cuda")
+    y16 = torch.zeros(M, C, dtype=torch.half, device="cuda")
+    part = torch.zeros(M, C // 64, 2, device="cuda")
+    ops.check(ops.lib.ud_dwconv7_nhwc_f32(ctypes.byref(ops.mk(ops.UdDwConv7, x=x, w=wt, bias=b, y=y, B=B, H=H, W=W, C=C, ldx=C, ldy=C)), ops.cur_stream()))
+    ops.check(ops.lib.ud_dwconv7_nhwc_f32(ctypes.byref(ops.mk(ops.UdDwConv7, x=x, w=wt, bias=b, y=y2, y16=y16, ldy16=C, stats_out=part, B=B, H=H, W=W, C=C,
+                                                              ldx=C, ldy=C)), ops.cur_stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2) and torch.equal(y16, y.half())
+    blocks = y.view(M, C // 64, 64).double()
+    assert rel(part[..., 0].double(), blocks.sum(-1)) < 1e-5 and rel(part[..., 1].double(), (blocks * blocks).sum(-1)) < 1e-5
+    y16b = torch.zeros_like(y16)                              # fp16 rows only (y = NULL): what the V1 plan records
+    ops.check(ops.lib.ud_dwconv7_nhwc_f32(ctypes.byref(ops.mk(ops.UdDwConv7, x=x, w=wt, bias=b, y16=y16b, ldy16=C, stats_out=part, B=B, H=H, W=W, C=C,
+                                                              ldx=C, ldy=C)), ops.cur_stream()))
+    stats = torch.zeros(M, 2, device="cuda")
+    ops.row_stats_finalize(part, stats, M, C // 64, C, 1e-6)
+    # the in-kernel reduction (stats_final: the last channel block of a pixel tile reduces; tickets wrap to zero): twice in a row
+    fin = torch.zeros(M, 2, device="cuda")
+    tk = torch.zeros(B * -(-H // 8) * -(-W // 16) + 8, dtype=torch.int32, device="cuda")
+    for _ in range(2):
+        fin.zero_()
+        ops.check(ops.lib.ud_dwconv7_nhwc_f32(ctypes.byref(ops.mk(ops.UdDwConv7, x=x, w=wt, bias=b, y16=y16b, ldy16=C, stats_out=part, stats_final=fin,
+                                                                  stats_ticket=tk, ln_eps=1e-6, B=B, H=H, W=W, C=C, ldx=C, ldy=C)), ops.cur_stream()))
+    torch.cuda.synchronize()
+    assert tk.abs().sum().item() == 0 and rel(fin, stats) < 1e-5
+    assert torch.equal(y16b, y16)
+    mean, var = y.double().mean(1), y.double().var(1, unbiased=False)
+    assert rel(stats[:, 0].double(), (var + 1e-6).rsqrt()) < 1e-5 and rel(stats[:, 1].double(), -mean * (var + 1e-6).rsqrt()) < 1e-4
+    if M >= 1024:                                             # the folded consumer runs on the large-tile kernel only (tile_hint 3: the 192-row list)
+        N = 256
+        W1 = (torch.randn(N, C, generator=g) * C ** -0.5).cuda()
+        b1 = torch.randn(N, generator=g).cuda()
+        hi = W1.half(); lo = (W1 - hi.float()).half()
+        Wp = torch.cat([hi, lo], dim=1).contiguous()
+        wsum = Wp.float().sum(1).contiguous()
+        out = torch.zeros(M, N, dtype=torch.half, device="cuda")
+        ops.gemm(A=y16, W=Wp, bias=b1, out=out, M=M, N=N, K=2 * C, lda=C, ldw=2 * C, ldc=N, epi=ops.UD_EPI_F16, act=ops.UD_ACT_GELU, a_wrap=C,
+                 row_stats_in=stats, wsum=wsum, ln_slabs=C // 64, ln_D=C, ln_eps=1e-6, tile_hint=3)
+        torch.cuda.synchronize()
+        ref = F.gelu(F.layer_norm(y, (C,), eps=1e-6) @ W1.t() + b1)
+        assert rel(out.float(), ref) < 1.5e-3
+
+
 @pytest.mark.parametrize("B,H,W,C", [(2, 9, 14, 192), (1, 7, 8, 768)])
 def test_layernorm_patchify2_and_conv(ops, B, H, W, C):
     g = torch.Generator().manual_seed(1)

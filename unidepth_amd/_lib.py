@@ -63,7 +63,8 @@ class UdCameraHead(C.Structure):
 
 
 class UdDwConv7(C.Structure):
-    _fields_ = [("x", fp), ("w", fp), ("bias", fp), ("y", fp), ("B", i32), ("H", i32), ("W", i32), ("C", i32), ("ldx", i32), ("ldy", i32)]
+    _fields_ = [("x", fp), ("w", fp), ("bias", fp), ("y", fp), ("B", i32), ("H", i32), ("W", i32), ("C", i32), ("ldx", i32), ("ldy", i32),
+                ("y16", vp), ("stats_out", fp), ("ldy16", i32), ("stats_final", fp), ("stats_ticket", vp), ("ln_eps", f32)]
 
 
 class UdV1Op(C.Structure):

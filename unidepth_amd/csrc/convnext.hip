@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256, 2) void dwconv7_lds_kernel(const UdDwConv7 p) 
   // (2q, 2q+1) at tap kx needs the input pair starting at column 2q + kx -- an even-aligned pair pe[] for even kx, an odd-aligned
   // one po[] for odd kx; both come straight from LDS (ds_read2st64_b32: two pixels of this lane's channel per read).  Per output
   // the taps are still accumulated ky-major, kx ascending, one fused multiply-add each: the same bits as the scalar loop.
+  float keep0[DW_TX], keep1[DW_TX];          // stats_out only: the wave's two output rows, until the halo can be overwritten (two arrays: no dynamic index)
 #pragma unroll 1
   for (int rr = 0; rr < 2; ++rr) {
     const int r = wv * 2 + rr;
@@ -120,10 +121,94 @@ __global__ __launch_bounds__(256, 2) void dwconv7_lds_kernel(const UdDwConv7 p) 
     }
     const int y = y0 + r;
     if (y < p.H) {
-      float* out = p.y + (((size_t)b * p.H + y) * p.W + x0) * p.ldy + c;
+      if (p.y) {
+        float* out = p.y + (((size_t)b * p.H + y) * p.W + x0) * p.ldy + c;
 #pragma unroll
-      for (int o = 0; o < DW_TX; ++o)
-        if (x0 + o < p.W) out[(size_t)o * p.ldy] = acc[o >> 1][o & 1];
+        for (int o = 0; o < DW_TX; ++o)
+          if (x0 + o < p.W) out[(size_t)o * p.ldy] = acc[o >> 1][o & 1];
+      }
+      if (p.y16) {                                  // the RAW fp16 row of a LayerNorm-folded consumer (a wave = 64 consecutive channels = 128 B per pixel)
+        half_t* out = (half_t*)p.y16 + (((size_t)b * p.H + y) * p.W + x0) * p.ldy16 + c;
+#pragma unroll
+        for (int o = 0; o < DW_TX; ++o)
+          if (x0 + o < p.W) out[(size_t)o * p.ldy16] = (half_t)acc[o >> 1][o & 1];
+      }
+    }
+    if (p.stats_out) {
+#pragma unroll
+      for (int o = 0; o < DW_TX; ++o) {
+        if (rr == 0) keep0[o] = acc[o >> 1][o & 1];
+        else keep1[o] = acc[o >> 1][o & 1];
+      }
+    }
+  }
+  if (p.stats_out) {
+    // per pixel (sum, sum of squares) over this block's 64 channels, from the fp32 values: the tile goes through LDS (the halo is dead: every wave is
+    // past its last read after the barrier), [channel][pixel] with a row stride of 129 floats -- lane = channel on the way in, lane = pixel on the way
+    // out, both conflict-free -- and thread t < 128 adds pixel t's 64 channels in channel order (a fixed order: reproducible, position-independent).
+    __syncthreads();
+    float* tile = halo;
+#pragma unroll
+    for (int o = 0; o < DW_TX; ++o) {
+      tile[lane * 129 + (wv * 2) * DW_TX + o] = keep0[o];
+      tile[lane * 129 + (wv * 2 + 1) * DW_TX + o] = keep1[o];
+    }
+    __syncthreads();
+    if (tid < DW_TY * DW_TX) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+      for (int ch = 0; ch < 64; ++ch) {
+        const float v = tile[ch * 129 + tid];
+        s1 += v;
+        s2 = __builtin_fmaf(v, v, s2);
+      }
+      const int yy = y0 + tid / DW_TX, xx = x0 + tid % DW_TX;
+      if (yy < p.H && xx < p.W) {
+        f32x2 o2;
+        o2[0] = s1; o2[1] = s2;
+        // system-scope write-through (sc0 sc1): the block that reduces them may sit on another XCD, whose L2 is not coherent with this one's
+        float* dst = p.stats_out + ((((size_t)b * p.H + yy) * p.W + xx) * (p.C >> 6) + blockIdx.y) * 2;
+        asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1\n\ts_nop 2" ::"v"(dst), "v"(o2) : "memory");
+      }
+    }
+    if (p.stats_final) {
+      // the last of the tile's C / 64 channel blocks reduces: partial sums out (vmcnt(0)), one ticket per pixel tile (wraps to zero: no reset launch), the
+      // drawer of the last ticket adds the slabs in slab order -- the result depends on nothing but the values (the fence-free exchange of gemm.hip's
+      // row_stats_final).  The ticket value travels through LDS (the tile staging area is dead after the sums above).
+      const unsigned nslab = (unsigned)(p.C >> 6);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      unsigned* flag = (unsigned*)halo;
+      if (tid == 0) *flag = atomicInc(p.stats_ticket + blockIdx.x, nslab - 1u);
+      __syncthreads();
+      if (*flag == nslab - 1u && tid < DW_TY * DW_TX) {
+        const int yy = y0 + tid / DW_TX, xx = x0 + tid % DW_TX;
+        if (yy < p.H && xx < p.W) {
+          const size_t pix = ((size_t)b * p.H + yy) * p.W + xx;
+          const float* src = p.stats_out + pix * nslab * 2;
+          // 16 unconditional loads (slabs past the last one re-read slab 0 and are masked out of the sums): all in flight together, no branches
+          f32x2 q[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const float* a = src + 2 * ((unsigned)k < nslab ? k : 0);
+            asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1" : "=v"(q[k]) : "v"(a) : "memory");
+          }
+          // the loaded registers are operands of the wait: nothing reads them before it
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]), "+v"(q[7]), "+v"(q[8]), "+v"(q[9]),
+                       "+v"(q[10]), "+v"(q[11]), "+v"(q[12]), "+v"(q[13]), "+v"(q[14]), "+v"(q[15])::"memory");
+          float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+          for (int k = 0; k < 16; ++k)
+            if ((unsigned)k < nslab) { t1 += q[k][0]; t2 += q[k][1]; }
+          const float inv = 1.0f / (float)p.C;
+          const float mean = t1 * inv;
+          const float var = fmaxf(__builtin_fmaf(-mean, mean, t2 * inv), 0.0f);
+          f32x2 oo;
+          oo[0] = rsqrtf(var + p.ln_eps);
+          oo[1] = -mean * oo[0];
+          *(f32x2*)(p.stats_final + 2 * pix) = oo;
+        }
+      }
     }
   }
 }
@@ -229,9 +314,16 @@ __global__ __launch_bounds__(256) void spatial_mean_kernel(const float* x, float
 
 extern "C" int ud_dwconv7_nhwc_f32(const UdDwConv7* desc, void* stream) {
   const UdDwConv7& d = *desc;
-  if (!d.x || !d.w || !d.y || d.B <= 0 || d.H <= 0 || d.W <= 0 || d.C <= 0 || (d.C & 3) || (d.ldx & 3) || (d.ldy & 3) || d.ldx < d.C || d.ldy < d.C) {
+  if (!d.x || !d.w || (!d.y && !d.y16) || d.B <= 0 || d.H <= 0 || d.W <= 0 || d.C <= 0 || (d.C & 3) || (d.ldx & 3) || d.ldx < d.C ||
+      (d.y && ((d.ldy & 3) || d.ldy < d.C))) {
     ud_set_error("ud_dwconv7_nhwc_f32: bad argument (C, ldx, ldy % 4 == 0)");
     return UD_ERR_BAD_ARG;
+  }
+  if (d.y16 || d.stats_out) {
+    if (!d.y16 || (d.C & 63) || d.ldy16 < d.C || (d.stats_out && (d.C >> 6) > 16) || (d.stats_final && (!d.stats_out || !d.stats_ticket)) || (double)d.B * d.H * d.W * d.ldx * 4.0 >= 4294967000.0) {
+      ud_set_error("ud_dwconv7_nhwc_f32: y16 / stats_out need C % 64 == 0 (C <= 1024 for stats_out), ldy16 >= C and an image the LDS-tiled kernel addresses");
+      return UD_ERR_UNSUPPORTED;
+    }
   }
   // the LDS-tiled kernel addresses the image through one buffer descriptor (32-bit byte offsets)
   if ((d.C & 63) == 0 && (double)d.B * d.H * d.W * d.ldx * 4.0 < 4294967000.0) {

@@ -56,6 +56,15 @@ WSPLIT_CONVNEXT_FC1 = _WSPLIT_ENV == "all"
 ASPLIT = WSPLIT and os.environ.get("UNIDEPTH_V1_ASPLIT", "1") != "0"
 
 
+# Round 6: the ConvNeXt blocks' LayerNorm folded into the depth-wise convolution (producer) and fc1 (consumer): UNIDEPTH_V1_DWLN=0 keeps the LayerNorm launches.
+DWLN = os.environ.get("UNIDEPTH_V1_DWLN", "1") != "0"
+
+
+def _pick(**kw) -> int:
+    import ctypes as _C
+    return ops.lib.ud_gemm_pick(_C.byref(ops.mk(ops.UdGemm, **kw)))
+
+
 def _split_mode() -> str:
     """The fp16 operand layout in force (module-level switches read once at import): packed weights carry it, plan builders assert it, so weights
     packed under one setting are never multiplied under another (e.g. a [hi | lo] weight against a single-term K)."""
@@ -140,6 +149,8 @@ def pack_convnext(config: dict, sd: dict, device) -> dict:
             g, b = f[r + "norm.weight"], f[r + "norm.bias"]
             w1, b1 = f[r + "mlp.fc1.weight"], f[r + "mlp.fc1.bias"]
             p16(f"blk.{s}.{i}.fc1.w", w1 * g[None, :], split=WSPLIT_CONVNEXT_FC1); p32(f"blk.{s}.{i}.fc1.b", b1 + w1 @ b)
+            # row sums of the fp16 terms the matrix pipe multiplies (hi + lo): the LayerNorm-folded consumer's mean correction (UdGemm.wsum)
+            w[f"blk.{s}.{i}.fc1.wsum"] = w[f"blk.{s}.{i}.fc1.w"].float().sum(dim=1).contiguous()
             ls = f[r + "gamma"]
             p16(f"blk.{s}.{i}.fc2.w", f[r + "mlp.fc2.weight"] * ls[:, None]); p32(f"blk.{s}.{i}.fc2.b", f[r + "mlp.fc2.bias"] * ls)
     w["meta.split"] = _split_mode()                    # the operand layout these weights were packed for (checked by the plan builders)
@@ -371,15 +382,37 @@ class _EncPlan:
                 P.gemm(A=col, W=w[f"ds.{s}.w"], bias=w[f"ds.{s}.b"], out=xn, M=rows, N=C, lda=4 * Cp, ldc=C, epi=UD_EPI_F32,
                        tag=f"downsample.{s}", **_wk(w[f"ds.{s}.w"], 4 * Cp))
                 x, H, W = xn, Ho, Wo
-            y = z(rows, C, dtype=f32)
             xh = z(rows, C)
             hid = z(rows, 4 * C)
             smax = z(rows, C, dtype=f32)
+            # Round 6: the block's LayerNorm (convnext.py:215-216) folded into its neighbours -- the depth-wise convolution writes its output as RAW fp16
+            # plus per-pixel partial sums (UdDwConv7.y16 / stats_out), the last channel block of a pixel tile reduces them to (rstd, -mean rstd)
+            # (stats_final), fc1 normalises in its epilogue
+            # (UdGemm.row_stats_in): no LayerNorm launch, no fp32 round trip of the map.  Where the large-tile kernel takes fc1 and C / 64 <= 16 (stages
+            # 0-2 of ConvNeXt-L; stage 3 has 24 slabs) and UNIDEPTH_V1_DWLN != 0.
+            fc1 = dict(W=w[f"blk.{s}.0.fc1.w"], bias=w[f"blk.{s}.0.fc1.b"], out=hid, M=rows, N=4 * C, lda=C, ldc=4 * C, epi=UD_EPI_F16, act=UD_ACT_GELU,
+                       **_wk(w[f"blk.{s}.0.fc1.w"], C))
+            rstats = z(rows, 2, dtype=f32)
+            fold = (DWLN and C % 64 == 0 and C // 64 <= 16 and f"blk.{s}.0.fc1.wsum" in w and
+                    (_pick(A=xh, row_stats_in=rstats, wsum=w[f"blk.{s}.0.fc1.wsum"], **fc1) & 15) in (3, 4, 8))
+            self.dwln = getattr(self, "dwln", []) + [bool(fold)]
+            if fold:
+                rpart = z(rows, C // 64, 2, dtype=f32)
+                tk = torch.zeros(B * -(-H // 8) * -(-W // 16) + 8, dtype=torch.int32, device=dev)     # one ticket per 8 x 16 pixel tile (self-resetting)
+            else:
+                y = z(rows, C, dtype=f32)
             for i in range(dep):
-                P.dwconv7(x=x, w=w[f"blk.{s}.{i}.dw.w"], bias=w[f"blk.{s}.{i}.dw.b"], y=y, B=B, H=H, W=W, C=C, ldx=C, ldy=C, tag=f"dwconv.s{s}")
-                P.layernorm(x=y, y=xh, rows=rows, D=C, ldx=C, ldy=C, eps=1e-6, rows_per_img=rows, in_rows_per_img=rows, out_rows_per_img=rows)
-                P.gemm(A=xh, W=w[f"blk.{s}.{i}.fc1.w"], bias=w[f"blk.{s}.{i}.fc1.b"], out=hid, M=rows, N=4 * C, lda=C, ldc=4 * C,
-                       epi=UD_EPI_F16, act=UD_ACT_GELU, tag=f"enc.fc1.s{s}", **_wk(w[f"blk.{s}.{i}.fc1.w"], C))
+                if fold:
+                    P.dwconv7(x=x, w=w[f"blk.{s}.{i}.dw.w"], bias=w[f"blk.{s}.{i}.dw.b"], y16=xh, ldy16=C, stats_out=rpart, stats_final=rstats,
+                              stats_ticket=tk, ln_eps=1e-6, B=B, H=H, W=W, C=C, ldx=C, ldy=C, tag=f"dwconv.s{s}")
+                    P.gemm(A=xh, W=w[f"blk.{s}.{i}.fc1.w"], bias=w[f"blk.{s}.{i}.fc1.b"], out=hid, M=rows, N=4 * C, lda=C, ldc=4 * C,
+                           epi=UD_EPI_F16, act=UD_ACT_GELU, tag=f"enc.fc1.s{s}", row_stats_in=rstats, wsum=w[f"blk.{s}.{i}.fc1.wsum"], ln_slabs=C // 64,
+                           ln_D=C, ln_eps=1e-6, **_wk(w[f"blk.{s}.{i}.fc1.w"], C))
+                else:
+                    P.dwconv7(x=x, w=w[f"blk.{s}.{i}.dw.w"], bias=w[f"blk.{s}.{i}.dw.b"], y=y, B=B, H=H, W=W, C=C, ldx=C, ldy=C, tag=f"dwconv.s{s}")
+                    P.layernorm(x=y, y=xh, rows=rows, D=C, ldx=C, ldy=C, eps=1e-6, rows_per_img=rows, in_rows_per_img=rows, out_rows_per_img=rows)
+                    P.gemm(A=xh, W=w[f"blk.{s}.{i}.fc1.w"], bias=w[f"blk.{s}.{i}.fc1.b"], out=hid, M=rows, N=4 * C, lda=C, ldc=4 * C,
+                           epi=UD_EPI_F16, act=UD_ACT_GELU, tag=f"enc.fc1.s{s}", **_wk(w[f"blk.{s}.{i}.fc1.w"], C))
                 # the stage's running maximum over its block outputs (max_stack) is taken in this epilogue, where the value is produced
                 P.gemm(A=hid, W=w[f"blk.{s}.{i}.fc2.w"], bias=w[f"blk.{s}.{i}.fc2.b"], out=x, M=rows, N=C, lda=4 * C, ldc=C,
                        epi=UD_EPI_F32, accumulate=1, tag=f"enc.fc2.s{s}", max_out=smax, max_init=int(i == 0), **_wk(w[f"blk.{s}.{i}.fc2.w"], 4 * C))
