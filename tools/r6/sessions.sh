@@ -189,4 +189,23 @@ timeout 300 python tools/r6_duo_ab.py --cold 2>&1 | grep -v amdgpu.ids >> $O/duo
 cat $O/duo_ab.txt
 }
 
+# round 6, GPU calls 12-28 (second half of the round), as run (one gpurun call each; outputs under gpurun_out/r6cNN, summaries under profiles/r06_*):
+#  12  UD_TILE_HINTS=15,8,15,8,0 tools/bench_enc_gemms.py            rotated tall tiles of the balanced schedule on fc1 (no effect; removed)      -> r06_schedules_ab.txt
+#  13  tools/r6_dec_ab.py --match dh.ups.{1,2}.*conv --hints 2,3,15,8,0   balanced schedule for zero-padded 3x3 operands                          -> r06_schedules_ab.txt
+#  14  kernel + infer + parity tests, bench line with the balanced convs
+#  15  bench_enc_gemms with / without epilogue stores (-DUD_EXP_NOSTORE build)                                                                      -> r06_schedules_ab.txt
+#  16  UdLayerNorm.cls_y tests, infer / parity tests, bench line
+#  17  tools/r6_conv2_epi.py                                           epilogue variants of the stage-2 conv2                                       -> r06_conv2_epilogue.txt
+#  18  tools/r6_conv2_trace.py with ab/libtrace.so / libtraced.so (-DUD_TRACE [-DUD_TRACE_DRAIN])                                                   -> r06_conv2_epilogue.txt
+#  19  the same with every other workgroup 36 us late (-DUD_EXP_DELAY=3500 experiment build)                                                        -> r06_conv2_epilogue.txt
+#  20  tools/ubench/mfma_shape_power                                   pure MFMA streams per shape / operand fill                                   -> r06_kloop_ablation.txt
+#  21, 22  UD_ABLATE=1 tools/ubench/gemm8p 4096^3, 16384 x 4096 x 4096   K-loop ablation ladder                                                     -> r06_kloop_ablation.txt
+#  (final)  bash tools/r6/sessions.sh final                            kernel stats, FETCH / WRITE, PMC, bench + per-launch table, suite, smoke      -> r06_bench*.json, r06_*kernel_stats.csv, ...
+#  23  UD_PH2=1 tools/ubench/gemm8p (three shapes)                     two phases per K-tile                                                         -> r06_kloop_ablation.txt
+#  24  kernel tests, tools/r6_duo_ab.py --hints 3,11 and bench.py against ab/libpp4.so (four-phase build of HEAD~)                                  -> r06_schedules_ab.txt
+#  25  UD_PH2=1 gemm8p with the one-phase variant (dropped)                                                                                         -> r06_kloop_ablation.txt
+#  (rehearsal)  bash tools/r6/sessions.sh rehearsal                    driver order on a fresh box                                                  -> r06_bench_rehearsal.json, r06_rehearsal.txt
+#  26-28  tests/test_v1_gpu.py, the V1 parity sweep, tools/bench_v1.py 16 --no-cpu [--by-tag] with UNIDEPTH_V1_DWLN=1 / 0 interleaved              -> r06_v1_dwconv_ln_ab.txt
+#  (rehearsal, again on the last commit)                                                                                                            -> r06_bench_rehearsal2.json, r06_rehearsal2.txt
+
 "$@"
