@@ -357,56 +357,69 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const UdUpsample2x p) {
 // pixel's C/8 threads are an aligned lane group of one wave (xor-shuffle LayerNorm statistics), 16-byte fp16 stores
 // (the 4-channel version stored 8 bytes per lane and ran at 2.0 TB/s).
 __global__ __launch_bounds__(256) void upsample2x_ln8_kernel(const UdUpsample2x p) {
+  // Round 6: a thread produces the TWO output rows that interpolate between the same pair of source rows (oy = 2 j - 1 and 2 j: source rows j - 1 and j, weights
+  // 0.25 / 0.75 and 0.75 / 0.25; the first and the last output row stand alone) from ONE set of four source-pixel loads: half the L1 / L2 read traffic of one
+  // output pixel per thread (1.4 GB per launch at bs = 8, the kernel's bound).  Per output the same expression with the same weights as before: same bits.
   const int Ho = p.H * 2, Wo = p.W * 2;
   const int G = p.C >> 3;
   const int ppb = 256 / G;
   const int tl = threadIdx.x;
   const int pl = tl / G, cg = tl - pl * G;
-  for (int row = blockIdx.y; row < p.B * Ho; row += gridDim.y) {
-    const int b = row / Ho, oy = row - b * Ho;
-    float fy = 0.5f * ((float)oy + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
-    const int y0 = (int)fy;
-    const int y1 = y0 + (y0 < p.H - 1);
-    const float ly = fy - (float)y0;
+  const int pairs = p.H + 1;                     // row pairs per image: j = 0 .. H
+  for (int row = blockIdx.y; row < p.B * pairs; row += gridDim.y) {
+    const int b = row / pairs, j = row - b * pairs;
+    const int ya = j > 0 ? j - 1 : 0, yb = j < p.H ? j : p.H - 1;
+    const int oyA = 2 * j - 1, oyB = 2 * j;      // oyA valid for j >= 1, oyB valid for j < H
+    // the weights the one-output kernel computed for these rows: fy = 0.5 (oy + 0.5) - 0.5 clamped at 0, ly = fy - floor(fy)
+    const float lyA = 0.25f;
+    const float lyB = j == 0 ? 0.0f : 0.75f;
     const float* img = (const float*)p.in + (size_t)b * (p.in_img_rows > 0 ? p.in_img_rows : p.H * p.W) * p.ldin + cg * 8;
     for (int base = blockIdx.x * ppb; base < Wo; base += gridDim.x * ppb) {
       const int ox = base + pl;
       const bool active = ox < Wo;
-      f32x4 v[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+      f32x4 vA[2], vB[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) { vA[h] = (f32x4){0.f, 0.f, 0.f, 0.f}; vB[h] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
       if (active) {
         float fx = 0.5f * ((float)ox + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
         const int x0 = (int)fx;
         const int x1 = x0 + (x0 < p.W - 1);
         const float lx = fx - (float)x0;
-        const float* r00 = img + ((size_t)y0 * p.W + x0) * p.ldin;
-        const float* r01 = img + ((size_t)y0 * p.W + x1) * p.ldin;
-        const float* r10 = img + ((size_t)y1 * p.W + x0) * p.ldin;
-        const float* r11 = img + ((size_t)y1 * p.W + x1) * p.ldin;
+        const float* r00 = img + ((size_t)ya * p.W + x0) * p.ldin;
+        const float* r01 = img + ((size_t)ya * p.W + x1) * p.ldin;
+        const float* r10 = img + ((size_t)yb * p.W + x0) * p.ldin;
+        const float* r11 = img + ((size_t)yb * p.W + x1) * p.ldin;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const f32x4 v00 = *(const f32x4*)(r00 + 4 * h), v01 = *(const f32x4*)(r01 + 4 * h);
           const f32x4 v10 = *(const f32x4*)(r10 + 4 * h), v11 = *(const f32x4*)(r11 + 4 * h);
-          v[h] = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
+          const f32x4 top = (1.0f - lx) * v00 + lx * v01, bot = (1.0f - lx) * v10 + lx * v11;
+          vA[h] = (1.0f - lyA) * top + lyA * bot;
+          vB[h] = (1.0f - lyB) * top + lyB * bot;
         }
       }
-      float s1 = ((v[0][0] + v[0][1]) + (v[0][2] + v[0][3])) + ((v[1][0] + v[1][1]) + (v[1][2] + v[1][3]));
-      for (int o = G >> 1; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64);
-      const float mean = s1 / (float)p.C;
-      float q = 0.f;
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) q += (v[h][e] - mean) * (v[h][e] - mean);
-      for (int o = G >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-      if (active) {
-        const float rstd = rsqrtf(q / (float)p.C + p.eps);
-        half8 hv;
+      auto finish = [&](const f32x4 (&v)[2], int oy, bool valid) {
+        float s1 = ((v[0][0] + v[0][1]) + (v[0][2] + v[0][3])) + ((v[1][0] + v[1][1]) + (v[1][2] + v[1][3]));
+        for (int o = G >> 1; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+        const float mean = s1 / (float)p.C;
+        float q = 0.f;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) hv[4 * h + e] = (half_t)((v[h][e] - mean) * rstd);
-        *(half8*)((half_t*)p.out + ((size_t)row * Wo + ox) * p.ldy + cg * 8) = hv;
-      }
+          for (int e = 0; e < 4; ++e) q += (v[h][e] - mean) * (v[h][e] - mean);
+        for (int o = G >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        if (active && valid) {
+          const float rstd = rsqrtf(q / (float)p.C + p.eps);
+          half8 hv;
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hv[4 * h + e] = (half_t)((v[h][e] - mean) * rstd);
+          *(half8*)((half_t*)p.out + (((size_t)b * Ho + oy) * Wo + ox) * p.ldy + cg * 8) = hv;
+        }
+      };
+      finish(vA, oyA, j >= 1);
+      finish(vB, oyB, j < p.H);
     }
   }
 }
@@ -645,7 +658,8 @@ extern "C" int ud_upsample2x_nhwc(const UdUpsample2x* desc, void* stream) {
   const dim3 grid((2 * d.W + ppb - 1) / ppb, rows < 65535 ? rows : 65535);
   const int G8 = d.C >> 3;
   if (d.mode == 1 && (d.C & 7) == 0 && (G8 & (G8 - 1)) == 0 && G8 <= 64 && (d.ldy & 7) == 0) {
-    const dim3 grid8((2 * d.W + 256 / G8 - 1) / (256 / G8), rows < 65535 ? rows : 65535);
+    const int prow = d.B * (d.H + 1);                            // row PAIRS (upsample2x_ln8_kernel)
+    const dim3 grid8((2 * d.W + 256 / G8 - 1) / (256 / G8), prow < 65535 ? prow : 65535);
     hipLaunchKernelGGL(upsample2x_ln8_kernel, grid8, dim3(256), 0, (hipStream_t)stream, d);
   } else if (d.mode == 0) hipLaunchKernelGGL(upsample2x_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, d);
   else hipLaunchKernelGGL(upsample2x_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, d);
