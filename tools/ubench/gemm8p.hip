@@ -281,6 +281,178 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const half_t* __restrict__ 
   }
 }
 
+// gemm8c: the two-phase staggered loop with a CONTINUOUS K-tile stream across the tiles of a workgroup (what gemm256_kernel has and gemm_pp.hip lacks): the DMA schedule of
+// the last two K-tiles of tile t simply continues with the addresses of tile t + gridDim.x (A'(0) in phase 1 of the last K-tile, W'(0) / W'(1) in phase 2 of the last two),
+// the stagger runs on across the tile boundary (no re-synchronisation: the epilogue touches no LDS), a wave stores its tile between its last phase and its next first phase.
+// K / 64 even and >= 4.
+template <int MQ>
+__global__ __launch_bounds__(512) void gemm8c_kernel(const half_t* __restrict__ A, const half_t* __restrict__ W, half_t* __restrict__ C, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = 64 * MQ;
+  constexpr int A_BYTES = BM * 128;
+  constexpr int BUFB = A_BYTES + 32768;
+  constexpr int A_LD = BM / 64;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wv >> 2, wc = wv & 3;
+  const int nk = K >> 6;
+  const int tiles_n = N >> 8, tiles_m = (M + BM - 1) / BM;
+  const int nblk = tiles_m * tiles_n;
+  const rsrc_t rA = make_rsrc(A, (unsigned)((size_t)M * K * 2)), rW = make_rsrc(W, (unsigned)((size_t)N * K * 2));
+  const int lrow = tid >> 3;
+  const int csrc = (tid & 7) ^ ((lrow >> 1) & 7);
+  const int fswz = (lane & 15) >> 1;
+  const int c0 = ((lane >> 4) ^ fswz) << 4, c1 = ((4 + (lane >> 4)) ^ fswz) << 4;
+  const int a_off = (wr * (BM / 2) + (lane & 15)) * 128;
+  const int b_off = A_BYTES + (wc * 64 + (lane & 15)) * 128;
+  auto tile_of = [&](int t, int& m0, int& n0) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = t & 7, idx = t >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    // groups of 8 row tiles x all column tiles (the product's walk for multi-round lists)
+    const int GM = 8, gsz = GM * tiles_n, grp = bid / gsz, first_m = grp * GM;
+    const int gm = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int rem = bid - grp * gsz;
+    m0 = (first_m + rem % gm) * BM;
+    n0 = (rem / gm) << 8;
+  };
+  auto offsets = [&](int m0, int n0, unsigned (&va)[A_LD], unsigned (&vb)[4]) {
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+      int m = m0 + lrow + 64 * j;
+      m = m < M ? m : M - 1;
+      va[j] = ((unsigned)m * (unsigned)K + csrc * 8) * 2u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vb[j] = ((unsigned)(n0 + lrow + 64 * j) * (unsigned)K + csrc * 8) * 2u;
+  };
+  auto issueA = [&](const unsigned (&va)[A_LD], int kt, int buf) {
+    char* sb = smem + buf * BUFB + wv * 1024;
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) bufl16(rA, va[j], kt * 128, sb + j * 8192);
+  };
+  auto issueB = [&](const unsigned (&vb)[4], int kt, int buf) {
+    char* sb = smem + buf * BUFB + A_BYTES + wv * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bufl16(rW, vb[j], kt * 128, sb + j * 8192);
+  };
+  int t = blockIdx.x;
+  if (t >= nblk) return;
+  int m0, n0;
+  tile_of(t, m0, n0);
+  unsigned va[A_LD], vb[4], van[A_LD], vbn[4];
+  offsets(m0, n0, va, vb);
+  issueA(va, 0, 0);
+  issueB(vb, 0, 0);
+  issueB(vb, 1, 1);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  BAR();
+  if (wr == 1) BAR();
+  f32x4 acc[2 * MQ][4];
+  half8 a[MQ][2], b0[2][2], b1[2][2];
+  for (;;) {
+    const int tn = t + (int)gridDim.x;
+    const bool has_next = tn < nblk;
+    int m0n = 0, n0n = 0;
+    if (has_next) { tile_of(tn, m0n, n0n); offsets(m0n, n0n, van, vbn); }
+#pragma unroll
+    for (int i = 0; i < 2 * MQ; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define QUAD(MQI, NQI, BF)                                                                                               \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < MQ; ++i)                        \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[(MQI) * MQ + i][(NQI) * 2 + j] =                                 \
+          __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[j][ks], a[i][ks], acc[(MQI) * MQ + i][(NQI) * 2 + j], 0, 0, 0);
+    auto ktile = [&](auto BUFT, int kt) {
+      constexpr int buf = decltype(BUFT)::value;
+      const char* sb = smem + buf * BUFB;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        b0[j][0] = *(const half8*)(sb + b_off + j * 2048 + c0);
+        b0[j][1] = *(const half8*)(sb + b_off + j * 2048 + c1);
+        b1[j][0] = *(const half8*)(sb + b_off + (2 + j) * 2048 + c0);
+        b1[j][1] = *(const half8*)(sb + b_off + (2 + j) * 2048 + c1);
+      }
+#pragma unroll
+      for (int i = 0; i < MQ; ++i) {
+        a[i][0] = *(const half8*)(sb + a_off + i * 2048 + c0);
+        a[i][1] = *(const half8*)(sb + a_off + i * 2048 + c1);
+      }
+      {
+        const bool cur = kt + 1 < nk;
+        if (cur || has_next) {
+          unsigned oa[A_LD];
+#pragma unroll
+          for (int j = 0; j < A_LD; ++j) oa[j] = cur ? va[j] : van[j];
+          issueA(oa, cur ? kt + 1 : 0, buf ^ 1);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b1[0][0]), "+v"(b1[0][1]), "+v"(b1[1][0]), "+v"(b1[1][1]), "+v"(b0[0][0]), "+v"(b0[0][1]), "+v"(b0[1][0]), "+v"(b0[1][1])::"memory");
+      BAR();
+      __builtin_amdgcn_s_setprio(1);
+      QUAD(0, 0, b0)
+      QUAD(0, 1, b1)
+      __builtin_amdgcn_s_setprio(0);
+      BAR();
+#pragma unroll
+      for (int i = 0; i < MQ; ++i) {
+        a[i][0] = *(const half8*)(sb + a_off + (MQ + i) * 2048 + c0);
+        a[i][1] = *(const half8*)(sb + a_off + (MQ + i) * 2048 + c1);
+      }
+      const bool curw = kt + 2 < nk;
+      const bool issued = curw || has_next;
+      if (issued) {
+        unsigned ob[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ob[j] = curw ? vb[j] : vbn[j];
+        issueB(ob, curw ? kt + 2 : kt + 2 - nk, buf);
+      }
+      if (issued) asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      BAR();
+      __builtin_amdgcn_s_setprio(1);
+      QUAD(1, 1, b1)
+      QUAD(1, 0, b0)
+      __builtin_amdgcn_s_setprio(0);
+      BAR();
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+      ktile(IntTag<0>{}, kt);
+      ktile(IntTag<1>{}, kt + 1);
+    }
+#undef QUAD
+    {
+      const int frow = lane & 15, fq = lane >> 4;
+      const int mbase = m0 + wr * (BM / 2), nbase = n0 + wc * 64;
+      half_t* o = C + (size_t)(mbase + frow) * N + nbase + 16 * (fq & 1) + 8 * (fq >> 1);
+#pragma unroll
+      for (int i = 0; i < 2 * MQ; ++i) {
+        unsigned w[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          w[j][0] = pack2(acc[i][j][0], acc[i][j][1]);
+          w[j][1] = pack2(acc[i][j][2], acc[i][j][3]);
+        }
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          pair16(w[2 * jp][0], w[2 * jp + 1][0]);
+          pair16(w[2 * jp][1], w[2 * jp + 1][1]);
+          u32x4 s;
+          s[0] = w[2 * jp][0]; s[1] = w[2 * jp][1]; s[2] = w[2 * jp + 1][0]; s[3] = w[2 * jp + 1][1];
+          if (mbase + i * 16 + frow < M) *(u32x4*)(o + (size_t)(i * 16) * N + jp * 32) = s;
+        }
+      }
+    }
+    if (!has_next) break;
+    t = tn; m0 = m0n; n0 = n0n;
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) va[j] = van[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vb[j] = vbn[j];
+  }
+  if (wr == 0) BAR();
+}
+
 __global__ void ref_kernel(const half_t* A, const half_t* W, const int* mi, const int* ni, float* out, int K, int cnt) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= cnt) return;
@@ -326,6 +498,38 @@ double run(Ctx& c, int rounds) {
   printf("gemm8p MQ %d stagger %d prio %d: M %d N %d K %d, %d tiles on %d workgroups: mean %.1f us (%.0f TFLOP/s), best %.1f us (%.0f), max rel err %.2e %s\n", MQ,
          (int)STAGGER, (int)PRIO, c.M, c.N, c.K, tiles, grid, us, 2.0 * c.M * c.N * c.K / us / 1e6, best, 2.0 * c.M * c.N * c.K / best / 1e6, maxerr,
          ABL ? "(ablation: not a product)" : maxerr < 2e-3 ? "ok" : "WRONG");
+  return us;
+}
+
+template <int MQ>
+double run_c(Ctx& c, int rounds) {
+  auto kern = gemm8c_kernel<MQ>;
+  constexpr int LDS = 2 * (64 * MQ * 128 + 32768);
+  hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  const int BM = 64 * MQ;
+  const int tiles = ((c.M + BM - 1) / BM) * (c.N >> 8);
+  const int grid = tiles < 256 ? tiles : 256;
+  auto launch = [&]() { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, 0, c.dA, c.dW, c.dC, c.M, c.N, c.K); };
+  hipMemset(c.dC, 0, (size_t)c.M * c.N * 2);
+  launch();
+  if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); exit(1); }
+  std::vector<half_t> out((size_t)c.M * c.N);
+  std::vector<float> ref(c.mi.size());
+  hipMemcpy(out.data(), c.dC, out.size() * 2, hipMemcpyDeviceToHost);
+  hipLaunchKernelGGL(ref_kernel, dim3((c.mi.size() + 63) / 64), dim3(64), 0, 0, c.dA, c.dW, c.dmi, c.dni, c.dref, c.K, (int)c.mi.size());
+  hipMemcpy(ref.data(), c.dref, ref.size() * 4, hipMemcpyDeviceToHost);
+  double maxerr = 0;
+  for (size_t t = 0; t < c.mi.size(); ++t) maxerr = fmax(maxerr, fabs((float)out[(size_t)c.mi[t] * c.N + c.ni[t]] - ref[t]) / (fabs(ref[t]) + 1.0));
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  double best = 1e30, sum = 0;
+  for (int r = 0; r < rounds; ++r) {
+    hipEventRecord(e0); for (int i = 0; i < 10; ++i) launch(); hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    best = fmin(best, ms * 100.0); sum += ms * 100.0;
+  }
+  const double us = sum / rounds;
+  printf("gemm8c MQ %d (two phases, stagger, CONTINUOUS stream): M %d N %d K %d, %d tiles on %d workgroups: mean %.1f us (%.0f TFLOP/s), best %.1f us (%.0f), max rel err %.2e %s\n", MQ,
+         c.M, c.N, c.K, tiles, grid, us, 2.0 * c.M * c.N * c.K / us / 1e6, best, 2.0 * c.M * c.N * c.K / best / 1e6, maxerr, maxerr < 2e-3 ? "ok" : "WRONG");
   return us;
 }
 
@@ -388,6 +592,18 @@ int main(int argc, char** argv) {
   }
   float* dbias; hipMalloc(&dbias, N * 4); hipMemset(dbias, 0, N * 4);
   const int R = 3;
+  if (getenv("UD_CONT")) {                       // continuous stream + stagger against the product's schedules on multi-round shapes
+    for (int rep = 0; rep < 3; ++rep) {
+      run_c<3>(c, R);
+      if (prod) run_product(c, prod, 3, dbias, R);
+      run_c<4>(c, R);
+      if (prod) run_product(c, prod, 2, dbias, R);
+      if (prod) run_product(c, prod, 8, dbias, R);
+      run<3, true, true, 0, true>(c, R);
+      run<4, true, true, 0, true>(c, R);
+    }
+    return 0;
+  }
   if (getenv("UD_PH2")) {                        // two phases per K-tile against four, interleaved
     for (int rep = 0; rep < 3; ++rep) {
       run<4, true, true>(c, R);
